@@ -1,0 +1,169 @@
+/*
+ * edhip.h -- C ABI of the MI355X-native elastic grid deformation hot path.
+ *
+ * This is the drop-in boundary.  It replaces, one for one, the three entry points of the
+ * reference's CPython extension `_deform_grid` (method table
+ * /root/reference/elasticdeform/_deform_grid.c:306-311):
+ *
+ *   _deform_grid.deform_grid(...)          _deform_grid.c:296-299  -> edhip_deform(gradient=0, ...)
+ *   _deform_grid.deform_grid_grad(...)     _deform_grid.c:301-304  -> edhip_deform(gradient=1, ...)
+ *   _deform_grid.spline_filter1d_grad(...) _deform_grid.c:61-92    -> edhip_spline_filter1d(transpose=1)
+ *   scipy.ndimage.spline_filter1d(...)     call sites deform_grid.py:160,168,271
+ *                                                                  -> edhip_spline_filter1d(transpose=0)
+ *
+ * and its argument list mirrors the C core they all funnel into,
+ *
+ *   int DeformGrid(int gradient, int ninputs, PyArrayObject** inputs, PyArrayObject* displacement,
+ *                  PyArrayObject* output_offset, PyArrayObject** outputs, int naxis, int* axis,
+ *                  int* orders, int* modes, double* cvals, double* affine);      deform.h:15-16
+ *   int NI_SplineFilter1DGrad(PyArrayObject*, int order, int axis, PyArrayObject*);  deform.h:18
+ *
+ * with `PyArrayObject*` replaced by the plain-old-data descriptor `edhip_array`
+ * (pointer + dtype code + shape + byte strides == what PyArray_DATA / PyArray_TYPE /
+ * PyArray_DIM / PyArray_STRIDE give the reference, deform.c:383-391,401,427-431).
+ *
+ * No Python, NumPy or torch type appears in any signature.  `data` pointers are DEVICE pointers
+ * (HBM on the MI355X that owns `hip_stream`); the small parameter arrays (axis, orders, modes,
+ * cvals, affine, output_offset) are HOST pointers, read before the call returns.
+ *
+ * Ownership: the caller allocates every array; the library borrows them for the duration of the
+ * enqueued work and allocates only stream-ordered scratch.  Calls are asynchronous with respect
+ * to the host: work is enqueued on `hip_stream` and the function returns; there is no implicit
+ * device synchronisation.  The library keeps no mutable global state, so it is re-entrant and
+ * may be called concurrently from several host threads on different streams / devices
+ * (reference: single-threaded, GIL released for the whole call, deform.c:377-379).
+ *
+ * Error convention (reference: return 0 with a Python exception set, deform.c:1042,
+ * _deform_grid.c:293): return EDHIP_OK (0) on success, otherwise a non-zero code and a
+ * NUL-terminated message in `err` (if errlen > 0).  The host shim maps codes to the exception
+ * classes the reference raises.
+ */
+#ifndef EDHIP_H
+#define EDHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDHIP_VERSION 100        /* 0.1.0 */
+#define EDHIP_MAX_DIMS 8         /* max ndim of any array (reference: NPY_MAXDIMS) */
+#define EDHIP_MAX_AXES 4         /* max number of deformed axes handled on the GPU */
+#define EDHIP_MAX_INPUTS 64
+
+/* dtype codes: the 13 NumPy types the reference switches over (deform.c:716-741,863-887,
+ * 907-919) collapse to these 11 distinct machine types on LP64 (long == long long). */
+enum edhip_dtype {
+    EDHIP_BOOL = 0, /* npy_bool  (unsigned char; store is a plain C cast, deform.c:287-290,907) */
+    EDHIP_U8 = 1,
+    EDHIP_I8 = 2,
+    EDHIP_U16 = 3,
+    EDHIP_I16 = 4,
+    EDHIP_U32 = 5,
+    EDHIP_I32 = 6,
+    EDHIP_U64 = 7,
+    EDHIP_I64 = 8,
+    EDHIP_F32 = 9,
+    EDHIP_F64 = 10,
+    EDHIP_NUM_DTYPES = 11
+};
+
+/* boundary modes, same integer codes as the reference (from_scipy.h:38-47,
+ * deform_grid.py:440-454) */
+enum edhip_mode {
+    EDHIP_MODE_NEAREST = 0,
+    EDHIP_MODE_WRAP = 1,
+    EDHIP_MODE_REFLECT = 2,
+    EDHIP_MODE_MIRROR = 3,
+    EDHIP_MODE_CONSTANT = 4
+};
+
+/* return codes */
+enum edhip_status {
+    EDHIP_OK = 0,
+    EDHIP_ERR_INVALID = 1,     /* shape / argument check failed   -> RuntimeError  (_deform_grid.c:121-255) */
+    EDHIP_ERR_DTYPE = 2,       /* "data type not supported"       -> RuntimeError  (deform.c:744,891,922)   */
+    EDHIP_ERR_MEMORY = 3,      /* scratch allocation failed       -> MemoryError   (deform.c:394-398 ...)   */
+    EDHIP_ERR_DEVICE = 4,      /* a HIP call / kernel launch failed -> RuntimeError                         */
+    EDHIP_ERR_UNSUPPORTED = 5  /* legal in the reference, outside this build's GPU limits (naxis > 4 ...)   */
+};
+
+/* arithmetic selection for edhip_deform / edhip_spline_filter1d */
+enum edhip_flags {
+    EDHIP_FLAG_AUTO = 0,       /* f32 data -> fast path; every other dtype -> exact path */
+    EDHIP_FLAG_EXACT = 1,      /* fp64 arithmetic in the reference's own evaluation order (bit-comparable) */
+    EDHIP_FLAG_FAST = 2        /* fp64 coordinates, restructured (separable) sums, data-width tap accumulation */
+};
+
+/* strided N-d array in device memory: the POD stand-in for PyArrayObject* */
+typedef struct edhip_array {
+    void*   data;                          /* device pointer to element [0,...,0]          */
+    int32_t dtype;                         /* enum edhip_dtype                              */
+    int32_t ndim;                          /* 0 < ndim <= EDHIP_MAX_DIMS                    */
+    int64_t shape[EDHIP_MAX_DIMS];         /* extents                                       */
+    int64_t stride_bytes[EDHIP_MAX_DIMS];  /* byte strides (any sign, any order, may be 0)  */
+} edhip_array;
+
+/* library version (EDHIP_VERSION of the build) */
+int edhip_version(void);
+
+/* static string for a status code */
+const char* edhip_status_string(int status);
+
+/* number of visible HIP devices, or -1 if the HIP runtime cannot be initialised.  Lets a host
+ * shim fail loudly before any compute call. */
+int edhip_device_count(void);
+
+/*
+ * Forward deformation (gradient == 0) or its exact adjoint (gradient != 0).
+ * Replaces DeformGrid (deform.c:340-1043) behind Py_DeformGrid_helper (_deform_grid.c:94-294).
+ *
+ *   inputs[ninputs]      forward: (prefiltered) source arrays, read.
+ *                        gradient: dX arrays, accumulated into -- MUST be zero-filled on entry
+ *                        (deform_grid.py:243).
+ *   displacement         prefiltered control-point grid, shape (naxis, ncp_0, ..., ncp_{naxis-1}),
+ *                        any dtype / strides (deform.c:388-391,715-741).
+ *   output_offset        naxis crop offsets (host int64) or NULL (deform.c:439-446).
+ *   outputs[ninputs]     forward: written.  gradient: dY arrays, read.
+ *                        outputs[i].ndim == inputs[i].ndim; deformed extents of every output equal
+ *                        those of outputs[0], of every input those of inputs[0]
+ *                        (_deform_grid.c:137-175).
+ *   axis                 host int32[ninputs * naxis], the deformed axes of each input, ascending.
+ *   orders, modes, cvals host arrays of length ninputs: spline order 0..5, enum edhip_mode, cval.
+ *   affine               host double[naxis * (naxis+1)], row-major INVERSE map output->source,
+ *                        or NULL (deform.c:771-776; built by deform_grid.py:392-438).
+ *   flags                enum edhip_flags.
+ *   hip_stream           hipStream_t to enqueue on (NULL = the legacy default stream).
+ */
+int edhip_deform(int gradient, int ninputs,
+                 const edhip_array* inputs,
+                 const edhip_array* displacement,
+                 const int64_t* output_offset,
+                 const edhip_array* outputs,
+                 int naxis, const int32_t* axis,
+                 const int32_t* orders, const int32_t* modes, const double* cvals,
+                 const double* affine,
+                 uint32_t flags, void* hip_stream,
+                 char* err, size_t errlen);
+
+/*
+ * One-dimensional B-spline prefilter along `axis`, mirror boundary.
+ *   transpose == 0 : scipy.ndimage.spline_filter1d(input, order, axis, output, mode='mirror')
+ *                    (call sites deform_grid.py:160,168,271)
+ *   transpose != 0 : its exact adjoint, NI_SplineFilter1DGrad (deform.c:1049-1168)
+ * input/output: same shape, any of the 11 dtypes each, may alias (in-place) -- the reference calls
+ * it in place from the second axis on (deform_grid.py:158-161,280-283).  order 0/1: plain copy
+ * with dtype conversion.  Arithmetic is fp64; the result is rounded to the output dtype once per
+ * call, exactly like the reference's double line buffer (deform.c:1106-1162).
+ */
+int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output,
+                          int axis, int order, int transpose,
+                          uint32_t flags, void* hip_stream,
+                          char* err, size_t errlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDHIP_H */
