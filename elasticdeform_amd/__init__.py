@@ -1,0 +1,18 @@
+"""
+elasticdeform_amd -- MI355X-native elastic grid deformation.
+
+Drop-in for the hot path of gvtulder/elasticdeform: ``deform_random_grid``, ``deform_grid`` and
+``deform_grid_gradient`` (reference: elasticdeform/__init__.py:1) with the same signatures, backed
+by hand-written HIP kernels for gfx950 behind the C ABI in include/edhip.h.
+``elasticdeform_amd.torch`` is the on-device PyTorch autograd wrapper (reference:
+elasticdeform/torch.py).
+
+    import elasticdeform_amd as elasticdeform
+    Y = elasticdeform.deform_random_grid(X, sigma=25, points=3)
+
+As in the reference, the function ``deform_grid`` shadows the submodule of the same name.
+"""
+from .deform_grid import (deform_grid, deform_grid_gradient, deform_random_grid,  # noqa: F401
+                          set_arithmetic)
+
+__version__ = '0.1.0'

@@ -1,0 +1,153 @@
+"""
+ctypes binding of the C ABI (include/edhip.h) exported by elasticdeform_amd/libedhip.so -- the
+hand-written HIP library for gfx950.  This is the Python side of the drop-in boundary: it plays
+the role the CPython extension ``_deform_grid`` plays in the reference
+(/root/reference/elasticdeform/_deform_grid.c:306-311).
+
+There is NO CPU fallback: if the library is missing or no GPU is visible the product fails loudly.
+"""
+import ctypes
+import os
+import threading
+
+import numpy
+
+MAX_DIMS = 8
+MAX_AXES = 4
+
+FLAG_AUTO, FLAG_EXACT, FLAG_FAST = 0, 1, 2
+
+# enum edhip_dtype
+DTYPE_CODES = {
+    'bool': 0, 'uint8': 1, 'int8': 2, 'uint16': 3, 'int16': 4, 'uint32': 5, 'int32': 6,
+    'uint64': 7, 'int64': 8, 'float32': 9, 'float64': 10,
+}
+
+# enum edhip_status -> the exception class the reference raises for that condition
+_STATUS_EXC = {
+    1: RuntimeError,   # EDHIP_ERR_INVALID      (PyErr_SetString(PyExc_RuntimeError, ...), _deform_grid.c:121-255)
+    2: RuntimeError,   # EDHIP_ERR_DTYPE        ('data type not supported', deform.c:744,891,922)
+    3: MemoryError,    # EDHIP_ERR_MEMORY       (PyErr_NoMemory, deform.c:394-398)
+    4: RuntimeError,   # EDHIP_ERR_DEVICE
+    5: RuntimeError,   # EDHIP_ERR_UNSUPPORTED
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libedhip.so')
+
+# every symbol include/edhip.h declares
+EXPORTS = ('edhip_version', 'edhip_status_string', 'edhip_device_count', 'edhip_deform',
+           'edhip_spline_filter1d')
+
+
+class EdhipArray(ctypes.Structure):
+    """struct edhip_array"""
+    _fields_ = [('data', ctypes.c_void_p), ('dtype', ctypes.c_int32), ('ndim', ctypes.c_int32),
+                ('shape', ctypes.c_int64 * MAX_DIMS), ('stride_bytes', ctypes.c_int64 * MAX_DIMS)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load libedhip.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'elasticdeform_amd: %s not found -- build the HIP extension first '
+                '(`make -C elasticdeform_amd/csrc` or `python -c "import __graft_entry__ as g; '
+                'g.build()"`).  There is no CPU fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.edhip_version.restype = ctypes.c_int
+        L.edhip_version.argtypes = []
+        L.edhip_status_string.restype = ctypes.c_char_p
+        L.edhip_status_string.argtypes = [ctypes.c_int]
+        L.edhip_device_count.restype = ctypes.c_int
+        L.edhip_device_count.argtypes = []
+        L.edhip_deform.restype = ctypes.c_int
+        L.edhip_deform.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.POINTER(EdhipArray), ctypes.POINTER(EdhipArray),
+            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(EdhipArray), ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+            ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
+            ctypes.POINTER(ctypes.c_double), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p,
+            ctypes.c_size_t]
+        L.edhip_spline_filter1d.restype = ctypes.c_int
+        L.edhip_spline_filter1d.argtypes = [
+            ctypes.POINTER(EdhipArray), ctypes.POINTER(EdhipArray), ctypes.c_int, ctypes.c_int,
+            ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        _lib = L
+    return _lib
+
+
+def raise_for_status(status, errbuf):
+    if status == 0:
+        return
+    msg = errbuf.value.decode('utf-8', 'replace') if errbuf is not None else ''
+    if not msg:
+        msg = load().edhip_status_string(status).decode()
+    raise _STATUS_EXC.get(status, RuntimeError)(msg)
+
+
+def describe(data_ptr, dtype_name, shape, strides_bytes):
+    """Build a struct edhip_array from raw parts."""
+    if dtype_name not in DTYPE_CODES:
+        # float16 / complex / ...: what the reference answers for them (deform.c:744,891)
+        raise RuntimeError('data type not supported')
+    nd = len(shape)
+    if nd < 1 or nd > MAX_DIMS:
+        raise RuntimeError('arrays must have 1..%d dimensions' % MAX_DIMS)
+    d = EdhipArray()
+    d.data = data_ptr
+    d.dtype = DTYPE_CODES[dtype_name]
+    d.ndim = nd
+    for i in range(nd):
+        d.shape[i] = int(shape[i])
+        d.stride_bytes[i] = int(strides_bytes[i])
+    return d
+
+
+def deform(gradient, in_descs, disp_desc, output_offset, out_descs, axis, orders, modes, cvals,
+           inverse_affine, flags, stream):
+    """edhip_deform -- argument for argument `_deform_grid.deform_grid(_grad)` of the reference
+    (_deform_grid.c:108-118) with descriptors in place of arrays, plus flags and the HIP stream."""
+    L = load()
+    n = len(in_descs)
+    axis = numpy.ascontiguousarray(numpy.asarray(axis, dtype=numpy.int32).reshape(n, -1))
+    naxis = axis.shape[1]
+    ins = (EdhipArray * n)(*in_descs)
+    outs = (EdhipArray * n)(*out_descs)
+    orders = numpy.ascontiguousarray(orders, dtype=numpy.int32)
+    modes = numpy.ascontiguousarray(modes, dtype=numpy.int32)
+    cvals = numpy.ascontiguousarray(cvals, dtype=numpy.float64)
+    off = aff = None
+    if output_offset is not None:
+        off_arr = numpy.ascontiguousarray(output_offset, dtype=numpy.int64)
+        off = off_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    if inverse_affine is not None:
+        aff_arr = numpy.ascontiguousarray(inverse_affine, dtype=numpy.float64)
+        aff = aff_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    buf = ctypes.create_string_buffer(256)
+    status = L.edhip_deform(
+        int(bool(gradient)), n, ins, ctypes.byref(disp_desc), off, outs, naxis,
+        axis.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        orders.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        modes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        cvals.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), aff, int(flags),
+        ctypes.c_void_p(stream), buf, 256)
+    raise_for_status(status, buf)
+
+
+def spline_filter1d(in_desc, out_desc, axis, order, transpose, flags, stream):
+    """edhip_spline_filter1d"""
+    L = load()
+    buf = ctypes.create_string_buffer(256)
+    status = L.edhip_spline_filter1d(ctypes.byref(in_desc), ctypes.byref(out_desc), int(axis),
+                                     int(order), int(bool(transpose)), int(flags),
+                                     ctypes.c_void_p(stream), buf, 256)
+    raise_for_status(status, buf)

@@ -1,0 +1,255 @@
+// deform_exact.hip -- K1/K2 "exact" kernels: the reference's per-voxel pipeline in fp64, in the
+// reference's own evaluation order, one thread per (output voxel, step).
+//
+// Compiled with -ffp-contract=off: every product and sum below rounds exactly like the x86-64
+// build of /root/reference/elasticdeform/deform.c (no FMA there), so float64 outputs, integer
+// label volumes and order-0 resampling are bit-comparable with the reference.  Used for every
+// dtype other than float32 by default, and for float32 when the caller asks (EDHIP_FLAG_EXACT).
+//
+// Restates DeformGrid's hot loop, deform.c:649-1001:
+//   displacement B-spline   :650-758      coordinate + boundary map   :768-824
+//   forward tap gather      :841-924      gradient scatter-add        :926-997
+// The scatter-add uses device-scope atomics (the reference is sequential); integer accumulation
+// is exact under reordering, floating-point accumulation differs from the reference only by the
+// order of the additions.
+#include "ed_device.h"
+#include "ed_params.h"
+
+namespace ed {
+
+namespace {
+
+// *(T*)p += (T)t for every dtype -- deform.c:309-312,974-987
+__device__ __forceinline__ void atomic_accumulate(char* p, int dt, double t)
+{
+    switch (dt) {
+    case EDHIP_F64: unsafeAtomicAdd((double*)p, t); break;
+    case EDHIP_F32: unsafeAtomicAdd((float*)p, (float)t); break;
+    case EDHIP_I32: atomicAdd((unsigned int*)p, (unsigned int)trunc_i32(t)); break;
+    case EDHIP_U32: atomicAdd((unsigned int*)p, (unsigned int)trunc_i64(t)); break;
+    case EDHIP_I64: atomicAdd((unsigned long long*)p, (unsigned long long)trunc_i64(t)); break;
+    case EDHIP_U64: atomicAdd((unsigned long long*)p, (unsigned long long)trunc_u64(t)); break;
+    default: {
+        // 8- and 16-bit lanes of a 32-bit word: wrap-around add inside the lane via CAS
+        const int bytes = (dt == EDHIP_U16 || dt == EDHIP_I16) ? 2 : 1;
+        const unsigned int lane_mask = bytes == 2 ? 0xffffu : 0xffu;
+        const unsigned int addend = (unsigned int)trunc_i32(t) & lane_mask;
+        if (addend == 0)
+            break;
+        const uintptr_t a = (uintptr_t)p;
+        unsigned int* word = (unsigned int*)(a & ~(uintptr_t)3);
+        const unsigned int shift = (unsigned int)(a & 3) * 8;
+        unsigned int old = *word, assumed;
+        do {
+            assumed = old;
+            const unsigned int cur = (assumed >> shift) & lane_mask;
+            const unsigned int upd = (cur + addend) & lane_mask;
+            const unsigned int next = (assumed & ~(lane_mask << shift)) | (upd << shift);
+            old = atomicCAS(word, assumed, next);
+        } while (old != assumed);
+        break;
+    }
+    }
+}
+
+template <int NAXIS>
+__global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, const IOView v,
+                                                           const int gradient)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = g.nvox * v.nsteps;
+    if (tid >= total)
+        return;
+    int64_t kk, ss;
+    if (v.steps_fastest) {
+        kk = tid / v.nsteps;
+        ss = tid - kk * v.nsteps;
+    } else {
+        ss = tid / g.nvox;
+        kk = tid - ss * g.nvox;
+    }
+
+    // output voxel index, last deformed axis fastest (from_scipy.h:67-79)
+    int64_t o[NAXIS];
+    {
+        int64_t r = kk;
+#pragma unroll
+        for (int k = NAXIS - 1; k >= 0; --k) {
+            const int64_t q = r / g.out_len[k];
+            o[k] = r - q * g.out_len[k];
+            r = q;
+        }
+    }
+
+    // ---- displacement: cubic B-spline of the control grid, deform.c:650-758 -------------------
+    double dw[NAXIS][4];
+    int64_t dtap[NAXIS][4];   // byte offsets of the 4 taps on each grid axis
+#pragma unroll
+    for (int k = 0; k < NAXIS; ++k) {
+        const double cp = control_coordinate(g.ncp[k], o[k] + g.off[k], g.in_len[k]);
+        const int64_t start = window_start(cp, 3);
+        const bool edge = start < 0 || start + 3 >= g.ncp[k];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int64_t idx = edge ? mirror_index(start + l, g.ncp[k]) : start + l;
+            dtap[k][l] = idx * g.disp_stride[k + 1];
+        }
+        spline_weights(cp, 3, dw[k]);
+    }
+    double displ[NAXIS];
+    constexpr int kDispTaps = 1 << (2 * NAXIS);
+#pragma unroll
+    for (int h = 0; h < NAXIS; ++h) {
+        const char* base = g.disp + g.disp_stride[0] * h;
+        double acc = 0.0;
+        for (int t = 0; t < kDispTaps; ++t) {   // lexicographic, last axis fastest (:623-636)
+            int64_t offs = 0;
+#pragma unroll
+            for (int k = 0; k < NAXIS; ++k)
+                offs += dtap[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
+            double coeff = load_as_double(base + offs, g.disp_dtype);
+#pragma unroll
+            for (int k = 0; k < NAXIS; ++k)
+                coeff *= dw[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
+            acc += coeff;
+        }
+        displ[h] = acc;
+    }
+
+    // ---- source coordinate, boundary map, window + weights, deform.c:768-824 ------------------
+    const int order = v.order;
+    double w[NAXIS][6];
+    int64_t tap[NAXIS][6];    // byte offsets of the taps on each deformed input axis
+    bool constant = false;
+#pragma unroll
+    for (int h = 0; h < NAXIS; ++h) {
+        double cc;
+        if (g.has_affine) {
+            cc = 0.0;
+#pragma unroll
+            for (int l = 0; l < NAXIS; ++l)
+                cc += g.affine[h * (NAXIS + 1) + l] * (double)o[l];
+            cc += g.affine[h * (NAXIS + 1) + NAXIS];
+        } else {
+            cc = (double)o[h];
+        }
+        cc = map_coordinate(cc + (double)g.off[h] + displ[h], g.in_len[h], v.mode);
+        if (!constant && cc > -1.0) {
+            const int64_t start = window_start(cc, order);
+            const bool edge = start < 0 || start + order >= g.in_len[h];
+            for (int l = 0; l <= order; ++l) {
+                const int64_t idx = edge ? mirror_index(start + l, g.in_len[h]) : start + l;
+                tap[h][l] = idx * v.in_stride[h];
+            }
+            spline_weights(cc, order, w[h]);
+        } else {
+            constant = true;   // deform.c:819-822 (first failing axis decides; later ones unused)
+        }
+    }
+
+    // ---- step (non-deformed axes) offsets, first step axis fastest, deform.c:828-838 ----------
+    int64_t in_off = 0, out_off = 0;
+    {
+        int64_t r = ss;
+        for (int l = 0; l < v.nstep; ++l) {
+            const int64_t q = r / v.step_len[l];
+            const int64_t c = r - q * v.step_len[l];
+            in_off += v.in_step_stride[l] * c;
+            out_off += v.out_step_stride[l] * c;
+            r = q;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NAXIS; ++k)
+        out_off += v.out_stride[k] * o[k];
+    char* po = v.out + out_off;
+
+    // number of taps (order+1)^NAXIS, walked lexicographically with a digit counter
+    int cnt[NAXIS];
+    if (!gradient) {
+        double t = 0.0;
+        if (!constant) {                                   // deform.c:843-901
+#pragma unroll
+            for (int k = 0; k < NAXIS; ++k)
+                cnt[k] = 0;
+            for (;;) {
+                int64_t offs = in_off;
+#pragma unroll
+                for (int k = 0; k < NAXIS; ++k)
+                    offs += tap[k][cnt[k]];
+                double coeff = load_as_double(v.in + offs, v.in_dtype);
+                if (order > 0) {
+#pragma unroll
+                    for (int k = 0; k < NAXIS; ++k)
+                        coeff *= w[k][cnt[k]];
+                }
+                t += coeff;
+                int k = NAXIS - 1;
+                for (; k >= 0; --k) {
+                    if (cnt[k] < order) {
+                        cnt[k]++;
+                        break;
+                    }
+                    cnt[k] = 0;
+                }
+                if (k < 0)
+                    break;
+            }
+        } else {
+            t = v.cval;                                    // deform.c:903
+        }
+        store_forward(po, v.out_dtype, t);
+    } else if (!constant) {                                // deform.c:926-996
+        const double grad = load_as_double(po, v.out_dtype);
+#pragma unroll
+        for (int k = 0; k < NAXIS; ++k)
+            cnt[k] = 0;
+        for (;;) {
+            double coeff = grad;
+            if (order > 0) {
+#pragma unroll
+                for (int k = 0; k < NAXIS; ++k)
+                    coeff *= w[k][cnt[k]];
+            }
+            int64_t offs = in_off;
+#pragma unroll
+            for (int k = 0; k < NAXIS; ++k)
+                offs += tap[k][cnt[k]];
+            atomic_accumulate(const_cast<char*>(v.in) + offs, v.in_dtype, coeff);
+            int k = NAXIS - 1;
+            for (; k >= 0; --k) {
+                if (cnt[k] < order) {
+                    cnt[k]++;
+                    break;
+                }
+                cnt[k] = 0;
+            }
+            if (k < 0)
+                break;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
+{
+    const int64_t total = g.nvox * v.nsteps;
+    if (total <= 0)
+        return hipSuccess;
+    const int block = 256;
+    const int64_t nblk = (total + block - 1) / block;
+    if (nblk > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    const dim3 grid((unsigned)nblk);
+    switch (g.naxis) {
+    case 1: hipLaunchKernelGGL(deform_exact_kernel<1>, grid, dim3(block), 0, stream, g, v, gradient); break;
+    case 2: hipLaunchKernelGGL(deform_exact_kernel<2>, grid, dim3(block), 0, stream, g, v, gradient); break;
+    case 3: hipLaunchKernelGGL(deform_exact_kernel<3>, grid, dim3(block), 0, stream, g, v, gradient); break;
+    case 4: hipLaunchKernelGGL(deform_exact_kernel<4>, grid, dim3(block), 0, stream, g, v, gradient); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ed

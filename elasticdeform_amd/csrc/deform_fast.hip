@@ -1,0 +1,419 @@
+// deform_fast.hip -- K1 (forward gather) and K2 (gradient scatter-add), "fast" arithmetic, for
+// float32 / float64 volumes with 1-3 deformed axes and spline orders 0-5.
+//
+// Same per-voxel pipeline as DeformGrid's hot loop (deform.c:649-1001) -- displacement B-spline,
+// optional affine, boundary map, (order+1)^naxis tap gather / scatter -- restructured for CDNA4:
+//
+//  * coordinates stay fp64 end to end (control-point coordinate, displacement, affine, boundary
+//    map, floor, fractional part, basis weights): fp32 coordinates at magnitude 256 already cost
+//    3e-5, fp64 VALU is cheap on MI355X;
+//  * the displacement spline is evaluated SEPARABLY.  Its weights depend only on the output
+//    index along each axis (deform.c:639-647), so for one output row (all deformed indices fixed
+//    except the last) the contraction over the slow axes is done once per row by the wave's 64
+//    lanes in parallel and parked in LDS:  E[h][j] = sum_{l0,l1} w0[l0] w1[l1] D[h,i0,i1,j].
+//    Each voxel then needs only 4 x-taps per component (12 fp64 FMAs in 3-D instead of the
+//    reference's 192 multiply-adds).  The slow-axis weights / mirror-mapped control-point
+//    indices of the block's rows are staged in LDS by the block prologue (the reference's
+//    `dsplvals` table, built per tile instead of per call);
+//  * one wave = one output row segment of 64 consecutive voxels along the fastest deformed axis,
+//    so output stores and the x-taps of the gathers are coalesced;
+//  * taps are accumulated separably (x, then y, then z) in the data's own width: fp32 FMAs for
+//    float32 volumes (6e-7 max abs error vs the fp64 reference on white noise, SURVEY.md section
+//    7), fp64 for float64 volumes;
+//  * K2 uses hardware float atomics (global_atomic_add_f32 / _f64); dX must be zero on entry.
+//
+// Differences from the reference are rounding only (summation order, fp32 tap arithmetic); the
+// parity tests bound them at 1e-5 (float32) / 1e-11 (float64).  Integer and bool volumes never
+// come here: they take the exact kernels (deform_exact.hip).
+#include "ed_device.h"
+#include "ed_params.h"
+
+namespace ed {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kRows = 32;           // output rows per block (8 per wave)
+constexpr int kMaxE = 768;          // naxis * ncp_x doubles of E per wave (LDS: 4 * 6 KiB)
+
+template <typename T>
+__device__ __forceinline__ void atomic_add(T* p, T v)
+{
+    unsafeAtomicAdd(p, v);
+}
+
+// element-unit view of IOView for the typed kernels
+template <int NAXIS>
+struct FastView {
+    int64_t in_stride[NAXIS];
+    int64_t out_stride[NAXIS];
+};
+
+template <typename T, int NAXIS, int ORDER, bool GRAD>
+__global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, const IOView v,
+                                                             const FastView<NAXIS> fv,
+                                                             const int64_t nrows, const int xblocks)
+{
+    constexpr int NS = NAXIS - 1;                  // slow (row) axes
+    constexpr int NSD = NS > 0 ? NS : 1;
+    constexpr int X = NAXIS - 1;                   // fastest deformed axis
+    constexpr int NT = ORDER + 1;
+    __shared__ double s_w[kRows][NSD][4];          // displacement weights of the slow axes per row
+    __shared__ int s_i[kRows][NSD][4];             // mirror-mapped control-point indices
+    __shared__ double s_E[kWaves][kMaxE];          // per-wave row contraction of the grid
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xb = blockIdx.x % xblocks;
+    const int64_t rb = blockIdx.x / xblocks;
+    const int64_t ncpx = g.ncp[X];
+
+    // ---- block prologue: slow-axis displacement tables for this block's rows -----------------
+    if (NS > 0) {
+        for (int t = tid; t < kRows * NS; t += kBlock) {
+            const int rr = t / NS, k = t - rr * NS;
+            int64_t row = rb * kRows + rr;
+            if (row < nrows) {
+                // decompose row -> o_k (last slow axis fastest)
+                int64_t ok = 0;
+                for (int a = NS - 1; a >= 0; --a) {
+                    const int64_t q = row / g.out_len[a];
+                    const int64_t c = row - q * g.out_len[a];
+                    if (a == k)
+                        ok = c;
+                    row = q;
+                }
+                const double cp = control_coordinate(g.ncp[k], ok + g.off[k], g.in_len[k]);
+                const int64_t start = window_start(cp, 3);
+                const bool edge = start < 0 || start + 3 >= g.ncp[k];
+                double w[4];
+                spline_weights(cp, 3, w);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    s_w[rr][k][l] = w[l];
+                    s_i[rr][k][l] = (int)(edge ? mirror_index(start + l, g.ncp[k]) : start + l);
+                }
+            }
+        }
+    }
+
+    // ---- per-lane displacement taps along x (fixed for the whole block) ----------------------
+    const int64_t ox = (int64_t)xb * 64 + lane;
+    const bool xvalid = ox < g.out_len[X];
+    double wx[4];
+    int ix[4];
+    {
+        const double cp = control_coordinate(ncpx, (xvalid ? ox : 0) + g.off[X], g.in_len[X]);
+        const int64_t start = window_start(cp, 3);
+        const bool edge = start < 0 || start + 3 >= ncpx;
+        spline_weights(cp, 3, wx);
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            ix[l] = (int)(edge ? mirror_index(start + l, ncpx) : start + l);
+    }
+    __syncthreads();
+
+    const T* __restrict__ in = (const T*)v.in;
+    T* out = (T*)v.out;
+    const int nE = NAXIS * (int)ncpx;
+
+    for (int rr = wave; rr < kRows; rr += kWaves) {
+        const int64_t row = rb * kRows + rr;
+        if (row >= nrows)
+            break;                                   // wave-uniform
+        // row -> slow output indices
+        int64_t o[NAXIS];
+        {
+            int64_t r = row;
+#pragma unroll
+            for (int a = NS - 1; a >= 0; --a) {
+                const int64_t q = r / g.out_len[a];
+                o[a] = r - q * g.out_len[a];
+                r = q;
+            }
+            o[X] = ox;
+        }
+
+        // ---- E[h][j]: contract the grid over the slow axes, 64 lanes in parallel -------------
+        for (int e = lane; e < nE; e += 64) {
+            const int h = e / (int)ncpx, j = e - h * (int)ncpx;
+            const char* base = g.disp + g.disp_stride[0] * h + g.disp_stride[NAXIS] * j;
+            double acc = 0.0;
+            if (NS == 0) {
+                acc = load_as_double(base, g.disp_dtype);
+            } else {
+                constexpr int NTAP = 1 << (2 * NS);
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) {
+                    int64_t offs = 0;
+                    double wprod = 1.0;
+#pragma unroll
+                    for (int a = 0; a < NS; ++a) {
+                        const int l = (t >> (2 * (NS - 1 - a))) & 3;
+                        offs += g.disp_stride[a + 1] * s_i[rr][a][l];
+                        wprod *= s_w[rr][a][l];
+                    }
+                    acc += load_as_double(base + offs, g.disp_dtype) * wprod;
+                }
+            }
+            s_E[wave][e] = acc;
+        }
+        // same-wave LDS write -> read: DS ops of one wave execute in order; only keep the compiler
+        // from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        if (xvalid) {
+            // ---- displacement, source coordinate, boundary map (fp64) -------------------------
+            double cc[NAXIS];
+            bool constant = false;
+#pragma unroll
+            for (int h = 0; h < NAXIS; ++h) {
+                double d = 0.0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    d += wx[l] * s_E[wave][h * (int)ncpx + ix[l]];
+                double c;
+                if (g.has_affine) {
+                    c = g.affine[h * (NAXIS + 1) + NAXIS];
+#pragma unroll
+                    for (int l = 0; l < NAXIS; ++l)
+                        c += g.affine[h * (NAXIS + 1) + l] * (double)o[l];
+                } else {
+                    c = (double)o[h];
+                }
+                c = map_coordinate(c + (double)g.off[h] + d, g.in_len[h], v.mode);
+                constant = constant || !(c > -1.0);
+                cc[h] = c;
+            }
+
+            // ---- window, tap offsets (elements), weights ------------------------------------
+            int64_t tap[NAXIS][NT];
+            T w[NAXIS][NT];
+            bool xrun = false;       // x taps are consecutive elements in memory
+            if (!constant) {
+#pragma unroll
+                for (int h = 0; h < NAXIS; ++h) {
+                    const int64_t start = window_start(cc[h], ORDER);
+                    const bool edge = start < 0 || start + ORDER >= g.in_len[h];
+#pragma unroll
+                    for (int l = 0; l < NT; ++l)
+                        tap[h][l] = (edge ? mirror_index(start + l, g.in_len[h]) : start + l) *
+                                    fv.in_stride[h];
+                    if (h == X)
+                        xrun = !edge && fv.in_stride[X] == 1;
+                    if (ORDER > 0) {
+                        double wd[NT];
+                        spline_weights(cc[h], ORDER, wd);
+#pragma unroll
+                        for (int l = 0; l < NT; ++l)
+                            w[h][l] = (T)wd[l];
+                    } else {
+                        w[h][0] = (T)1;
+                    }
+                }
+            }
+            (void)xrun;
+
+            int64_t obase = 0;
+#pragma unroll
+            for (int k = 0; k < NAXIS; ++k)
+                obase += fv.out_stride[k] * o[k];
+
+            // ---- steps: the non-deformed axes reuse coordinates and weights (deform.c:828-838)
+            for (int64_t ss = 0; ss < v.nsteps; ++ss) {
+                int64_t in_off = 0, out_off = obase;
+                {
+                    int64_t r = ss;
+                    for (int l = 0; l < v.nstep; ++l) {
+                        const int64_t q = r / v.step_len[l];
+                        const int64_t c = r - q * v.step_len[l];
+                        in_off += v.in_step_stride[l] * c;      // element units (host converted)
+                        out_off += v.out_step_stride[l] * c;
+                        r = q;
+                    }
+                }
+                if (!GRAD) {
+                    T val;
+                    if (constant) {
+                        val = (T)v.cval;
+                    } else {
+                        const T* p = in + in_off;
+                        if constexpr (NAXIS == 1) {
+                            T a0 = 0;
+#pragma unroll
+                            for (int l = 0; l < NT; ++l)
+                                a0 += w[0][l] * p[tap[0][l]];
+                            val = a0;
+                        } else if constexpr (NAXIS == 2) {
+                            T a0 = 0;
+#pragma unroll
+                            for (int l0 = 0; l0 < NT; ++l0) {
+                                const T* p0 = p + tap[0][l0];
+                                T a1 = 0;
+#pragma unroll
+                                for (int l1 = 0; l1 < NT; ++l1)
+                                    a1 += w[X][l1] * p0[tap[X][l1]];
+                                a0 += w[0][l0] * a1;
+                            }
+                            val = a0;
+                        } else {
+                            T a0 = 0;
+#pragma unroll
+                            for (int l0 = 0; l0 < NT; ++l0) {
+                                const T* p0 = p + tap[0][l0];
+                                T a1 = 0;
+#pragma unroll
+                                for (int l1 = 0; l1 < NT; ++l1) {
+                                    const T* p1 = p0 + tap[1][l1];
+                                    T a2 = 0;
+#pragma unroll
+                                    for (int l2 = 0; l2 < NT; ++l2)
+                                        a2 += w[X][l2] * p1[tap[X][l2]];
+                                    a1 += w[1][l1] * a2;
+                                }
+                                a0 += w[0][l0] * a1;
+                            }
+                            val = a0;
+                        }
+                    }
+                    out[out_off] = val;
+                } else if (!constant) {
+                    T* p = const_cast<T*>(in) + in_off;
+                    const T grad = out[out_off];
+                    if constexpr (NAXIS == 1) {
+#pragma unroll
+                        for (int l = 0; l < NT; ++l)
+                            atomic_add(p + tap[0][l], grad * w[0][l]);
+                    } else if constexpr (NAXIS == 2) {
+#pragma unroll
+                        for (int l0 = 0; l0 < NT; ++l0) {
+                            const T g0 = grad * w[0][l0];
+                            T* p0 = p + tap[0][l0];
+#pragma unroll
+                            for (int l1 = 0; l1 < NT; ++l1)
+                                atomic_add(p0 + tap[X][l1], g0 * w[X][l1]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int l0 = 0; l0 < NT; ++l0) {
+                            const T g0 = grad * w[0][l0];
+                            T* p0 = p + tap[0][l0];
+#pragma unroll
+                            for (int l1 = 0; l1 < NT; ++l1) {
+                                const T g1 = g0 * w[1][l1];
+                                T* p1 = p0 + tap[1][l1];
+#pragma unroll
+                                for (int l2 = 0; l2 < NT; ++l2)
+                                    atomic_add(p1 + tap[X][l2], g1 * w[X][l2]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // the next row of this wave overwrites s_E[wave]: all lanes are past their reads here
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T, int NAXIS, int ORDER>
+hipError_t launch_typed(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
+{
+    constexpr int X = NAXIS - 1;
+    FastView<NAXIS> fv;
+    IOView ve = v;     // step strides converted to element units
+    for (int k = 0; k < NAXIS; ++k) {
+        fv.in_stride[k] = v.in_stride[k] / (int64_t)sizeof(T);
+        fv.out_stride[k] = v.out_stride[k] / (int64_t)sizeof(T);
+    }
+    for (int l = 0; l < v.nstep; ++l) {
+        ve.in_step_stride[l] = v.in_step_stride[l] / (int64_t)sizeof(T);
+        ve.out_step_stride[l] = v.out_step_stride[l] / (int64_t)sizeof(T);
+    }
+    int64_t nrows = 1;
+    for (int k = 0; k < NAXIS - 1; ++k)
+        nrows *= g.out_len[k];
+    const int64_t xblocks = (g.out_len[X] + 63) / 64;
+    const int64_t rblocks = (nrows + kRows - 1) / kRows;
+    const int64_t nblk = xblocks * rblocks;
+    if (nblk <= 0)
+        return hipSuccess;
+    if (nblk > 0x7fffffffLL || xblocks > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    if (gradient)
+        hipLaunchKernelGGL((deform_fast_kernel<T, NAXIS, ORDER, true>), dim3((unsigned)nblk),
+                           dim3(kBlock), 0, stream, g, ve, fv, nrows, (int)xblocks);
+    else
+        hipLaunchKernelGGL((deform_fast_kernel<T, NAXIS, ORDER, false>), dim3((unsigned)nblk),
+                           dim3(kBlock), 0, stream, g, ve, fv, nrows, (int)xblocks);
+    return hipGetLastError();
+}
+
+template <typename T, int NAXIS>
+hipError_t launch_order(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
+{
+    switch (v.order) {
+    case 0: return launch_typed<T, NAXIS, 0>(g, v, gradient, stream);
+    case 1: return launch_typed<T, NAXIS, 1>(g, v, gradient, stream);
+    case 2: return launch_typed<T, NAXIS, 2>(g, v, gradient, stream);
+    case 3: return launch_typed<T, NAXIS, 3>(g, v, gradient, stream);
+    case 4: return launch_typed<T, NAXIS, 4>(g, v, gradient, stream);
+    case 5: return launch_typed<T, NAXIS, 5>(g, v, gradient, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T>
+hipError_t launch_axes(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
+{
+    switch (g.naxis) {
+    case 1: return launch_order<T, 1>(g, v, gradient, stream);
+    case 2: return launch_order<T, 2>(g, v, gradient, stream);
+    case 3: return launch_order<T, 3>(g, v, gradient, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
+}  // namespace
+
+bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient)
+{
+    (void)gradient;
+    if (g.naxis < 1 || g.naxis > 3)
+        return false;
+    if (v.in_dtype != v.out_dtype)
+        return false;
+    if (v.in_dtype != EDHIP_F32 && v.in_dtype != EDHIP_F64)
+        return false;
+    const int64_t esz = v.in_dtype == EDHIP_F32 ? 4 : 8;
+    if (((uintptr_t)v.in % esz) || ((uintptr_t)v.out % esz))
+        return false;
+    for (int k = 0; k < g.naxis; ++k)
+        if (v.in_stride[k] % esz || v.out_stride[k] % esz)
+            return false;
+    for (int l = 0; l < v.nstep; ++l)
+        if (v.in_step_stride[l] % esz || v.out_step_stride[l] % esz)
+            return false;
+    if ((int64_t)g.naxis * g.ncp[g.naxis - 1] > kMaxE)
+        return false;
+    for (int k = 0; k < g.naxis; ++k)
+        if (g.ncp[k] > 0x7fffffffLL / 4)
+            return false;
+    return true;
+}
+
+hipError_t launch_deform_fast(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
+{
+    if (!deform_fast_supported(g, v, gradient))
+        return hipErrorNotSupported;
+    if (v.in_dtype == EDHIP_F32)
+        return launch_axes<float>(g, v, gradient, stream);
+    return launch_axes<double>(g, v, gradient, stream);
+}
+
+}  // namespace ed

@@ -1,0 +1,79 @@
+// ed_params.h -- kernel argument blocks (plain structs passed by value) and host-side launchers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "edhip.h"
+
+namespace ed {
+
+constexpr int kMaxAxes = EDHIP_MAX_AXES;   // deformed axes on the GPU
+constexpr int kMaxSteps = EDHIP_MAX_DIMS;  // non-deformed ("step") axes
+
+// geometry shared by every input of one edhip_deform call: deform.c:381-391,439-451,771-776
+struct GridGeom {
+    int naxis;
+    int has_affine;
+    int disp_dtype;
+    int pad_;
+    int64_t in_len[kMaxAxes];     // I_k: deformed extents of inputs[0]          (deform.c:383)
+    int64_t out_len[kMaxAxes];    // O_k: deformed extents of outputs[0]         (deform.c:384)
+    int64_t off[kMaxAxes];        // crop offsets                                (deform.c:439-446)
+    int64_t ncp[kMaxAxes];        // control points per axis                     (deform.c:449-451)
+    const char* disp;             // prefiltered displacement grid
+    int64_t disp_stride[kMaxAxes + 1];   // byte strides, [0] = component axis
+    double affine[kMaxAxes * (kMaxAxes + 1)];   // inverse map, row-major naxis x (naxis+1)
+    int64_t nvox;                 // prod O_k
+};
+
+// one input/output pair: deform.c:399-436,762-838
+struct IOView {
+    const char* in;               // forward: source; gradient: dX (accumulated into)
+    char* out;                    // forward: destination; gradient: dY (read)
+    int in_dtype, out_dtype;
+    int order, mode;
+    double cval;
+    int64_t in_stride[kMaxAxes];  // byte strides of the deformed axes
+    int64_t out_stride[kMaxAxes];
+    int nstep;                    // number of non-deformed axes (ascending axis order)
+    int steps_fastest;            // 1: flatten work as voxel*nsteps+step (step axes innermost in memory)
+    int64_t nsteps;               // product of step extents
+    int64_t step_len[kMaxSteps];
+    int64_t in_step_stride[kMaxSteps];
+    int64_t out_step_stride[kMaxSteps];
+};
+
+// launchers (defined in the .hip files, called from edhip_api.cpp); all enqueue on `stream` and
+// return the hipError_t of the launch.
+hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
+
+// fast path: returns hipErrorNotSupported (without launching) when the case is outside its
+// envelope so that the caller can route it to the exact kernels instead.
+hipError_t launch_deform_fast(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
+bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient);
+
+struct FilterParams {
+    const char* in;
+    char* out;
+    int in_dtype, out_dtype;
+    int npoles;
+    int transpose;
+    double pole[2];
+    double pole_pow[2];      // pole^(len-1), computed on the host with libm pow() like the reference
+    int trunc_branch[2];     // transpose only: (int)ceil(log(1e-15)/log|p|) < len   (deform.c:1119,1134)
+    double gain;
+    int64_t len;             // extent along the filtered axis
+    int64_t in_axis_stride, out_axis_stride;   // bytes
+    int nouter;              // number of other axes
+    int64_t nlines;
+    int64_t outer_len[EDHIP_MAX_DIMS];
+    int64_t in_outer_stride[EDHIP_MAX_DIMS];
+    int64_t out_outer_stride[EDHIP_MAX_DIMS];
+    double* ws;              // fp64 scratch for ws_lines lines, line-interleaved: ws[i * nl + j]
+    int64_t ws_lines;        // lines per chunk
+};
+
+hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream);
+
+}  // namespace ed

@@ -1,0 +1,331 @@
+// edhip_api.hip -- the C ABI of include/edhip.h: argument validation (the checks of
+// Py_DeformGrid_helper, _deform_grid.c:121-255, and Py_SplineFilter1D_grad, :71-81), kernel
+// selection and stream-ordered launches.  No Python, NumPy or torch types.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "ed_params.h"
+#include "edhip.h"
+
+namespace {
+
+int fail(char* err, size_t errlen, int code, const char* fmt, ...)
+{
+    if (err && errlen) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, errlen, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int hip_fail(char* err, size_t errlen, hipError_t e, const char* what)
+{
+    if (e == hipErrorOutOfMemory)
+        return fail(err, errlen, EDHIP_ERR_MEMORY, "%s: out of device memory", what);
+    return fail(err, errlen, EDHIP_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+
+bool dtype_ok(int dt) { return dt >= 0 && dt < EDHIP_NUM_DTYPES; }
+
+int dtype_size(int dt)
+{
+    switch (dt) {
+    case EDHIP_BOOL: case EDHIP_U8: case EDHIP_I8: return 1;
+    case EDHIP_U16: case EDHIP_I16: return 2;
+    case EDHIP_U32: case EDHIP_I32: case EDHIP_F32: return 4;
+    default: return 8;
+    }
+}
+
+int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
+
+}  // namespace
+
+extern "C" {
+
+int edhip_version(void) { return EDHIP_VERSION; }
+
+const char* edhip_status_string(int status)
+{
+    switch (status) {
+    case EDHIP_OK: return "ok";
+    case EDHIP_ERR_INVALID: return "invalid argument";
+    case EDHIP_ERR_DTYPE: return "data type not supported";
+    case EDHIP_ERR_MEMORY: return "out of memory";
+    case EDHIP_ERR_DEVICE: return "HIP runtime error";
+    case EDHIP_ERR_UNSUPPORTED: return "not supported by this build";
+    default: return "unknown status";
+    }
+}
+
+int edhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return -1;
+    return n;
+}
+
+int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
+                 const edhip_array* displacement, const int64_t* output_offset,
+                 const edhip_array* outputs, int naxis, const int32_t* axis, const int32_t* orders,
+                 const int32_t* modes, const double* cvals, const double* affine, uint32_t flags,
+                 void* hip_stream, char* err, size_t errlen)
+{
+    using namespace ed;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (err && errlen)
+        err[0] = 0;
+
+    // ---- the checks of _deform_grid.c:121-255 -------------------------------------------------
+    if (!inputs || !outputs || ninputs <= 0 || ninputs > EDHIP_MAX_INPUTS)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid number of inputs/outputs");
+    if (!axis || !orders || !modes || !cvals || naxis < 1)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis list");
+    if (naxis > kMaxAxes)
+        return fail(err, errlen, EDHIP_ERR_UNSUPPORTED,
+                    "more than %d deformed axes are not supported on the GPU", kMaxAxes);
+    for (int i = 0; i < ninputs; ++i) {
+        const edhip_array& in = inputs[i];
+        const edhip_array& out = outputs[i];
+        if (in.ndim != out.ndim)
+            return fail(err, errlen, EDHIP_ERR_INVALID, "input and output dimensions should match");
+        if (in.ndim < 1 || in.ndim > EDHIP_MAX_DIMS)
+            return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "arrays must have 1..%d dimensions",
+                        EDHIP_MAX_DIMS);
+        if (!dtype_ok(in.dtype) || !dtype_ok(out.dtype))
+            return fail(err, errlen, EDHIP_ERR_DTYPE, "data type not supported");
+        for (int j = 0; j < naxis; ++j) {
+            const int a = axis[i * naxis + j];
+            if (a < 0 || a >= in.ndim)
+                return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis in axis list");
+            if (in.shape[a] != inputs[0].shape[axis[j]])
+                return fail(err, errlen, EDHIP_ERR_INVALID, "all inputs should have the same size");
+            if (out.shape[a] != outputs[0].shape[axis[j]])
+                return fail(err, errlen, EDHIP_ERR_INVALID, "all outputs should have the same size");
+        }
+        if (orders[i] < 0 || orders[i] > 5)
+            return fail(err, errlen, EDHIP_ERR_INVALID, "spline order not supported");
+        if (modes[i] < 0 || modes[i] > 4)
+            return fail(err, errlen, EDHIP_ERR_INVALID, "boundary mode not supported");
+    }
+    if (!displacement || displacement->ndim != naxis + 1 || displacement->shape[0] != naxis)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid displacement shape");
+    if (!dtype_ok(displacement->dtype))
+        return fail(err, errlen, EDHIP_ERR_DTYPE, "data type not supported");
+    for (int k = 0; k <= naxis; ++k)
+        if (displacement->shape[k] <= 0)
+            return fail(err, errlen, EDHIP_ERR_INVALID, "invalid displacement shape");
+
+    // ---- shared geometry ------------------------------------------------------------------------
+    GridGeom g;
+    memset(&g, 0, sizeof(g));
+    g.naxis = naxis;
+    g.has_affine = affine != nullptr;
+    g.disp_dtype = displacement->dtype;
+    g.disp = (const char*)displacement->data;
+    g.nvox = 1;
+    for (int k = 0; k < naxis; ++k) {
+        g.in_len[k] = inputs[0].shape[axis[k]];
+        g.out_len[k] = outputs[0].shape[axis[k]];
+        g.off[k] = output_offset ? output_offset[k] : 0;
+        g.ncp[k] = displacement->shape[k + 1];
+        g.nvox *= g.out_len[k];
+        if (g.out_len[k] > 0 && g.in_len[k] < 2)
+            // the reference divides by (I_k - 1) (deform.c:643,655): undefined there, refused here
+            return fail(err, errlen, EDHIP_ERR_INVALID,
+                        "deformed axes must have at least 2 elements");
+    }
+    for (int k = 0; k <= naxis; ++k)
+        g.disp_stride[k] = displacement->stride_bytes[k];
+    if (affine)
+        for (int k = 0; k < naxis * (naxis + 1); ++k)
+            g.affine[k] = affine[k];
+    if (g.nvox <= 0)
+        return EDHIP_OK;
+
+    // ---- one launch per input/output pair -----------------------------------------------------------
+    for (int i = 0; i < ninputs; ++i) {
+        const edhip_array& in = inputs[i];
+        const edhip_array& out = outputs[i];
+        IOView v;
+        memset(&v, 0, sizeof(v));
+        v.in = (const char*)in.data;
+        v.out = (char*)out.data;
+        v.in_dtype = in.dtype;
+        v.out_dtype = out.dtype;
+        v.order = orders[i];
+        v.mode = modes[i];
+        v.cval = cvals[i];
+        v.nsteps = 1;
+        int64_t min_deform = INT64_MAX, min_step = INT64_MAX;
+        for (int d = 0; d < in.ndim; ++d) {
+            int k = -1;
+            for (int j = 0; j < naxis; ++j)
+                if (axis[i * naxis + j] == d)
+                    k = j;
+            if (k >= 0) {
+                v.in_stride[k] = in.stride_bytes[d];
+                v.out_stride[k] = out.stride_bytes[d];
+                if (out.shape[d] > 1 && iabs64(out.stride_bytes[d]) < min_deform)
+                    min_deform = iabs64(out.stride_bytes[d]);
+            } else {
+                if (in.shape[d] != out.shape[d])
+                    return fail(err, errlen, EDHIP_ERR_INVALID,
+                                "non-deformed axes of input and output must have the same size");
+                v.step_len[v.nstep] = in.shape[d];
+                v.in_step_stride[v.nstep] = in.stride_bytes[d];
+                v.out_step_stride[v.nstep] = out.stride_bytes[d];
+                v.nsteps *= in.shape[d];
+                if (out.shape[d] > 1 && iabs64(out.stride_bytes[d]) < min_step)
+                    min_step = iabs64(out.stride_bytes[d]);
+                v.nstep++;
+            }
+        }
+        v.steps_fastest = v.nstep > 0 && min_step < min_deform;
+        if (v.nsteps <= 0)
+            continue;
+
+        bool use_fast;
+        if (flags & EDHIP_FLAG_EXACT)
+            use_fast = false;
+        else if (flags & EDHIP_FLAG_FAST)
+            use_fast = deform_fast_supported(g, v, gradient);
+        else
+            use_fast = in.dtype == EDHIP_F32 && out.dtype == EDHIP_F32 &&
+                       deform_fast_supported(g, v, gradient);
+        const hipError_t e = use_fast ? launch_deform_fast(g, v, gradient != 0, stream)
+                                      : launch_deform_exact(g, v, gradient != 0, stream);
+        if (e != hipSuccess)
+            return hip_fail(err, errlen, e, "deform kernel launch");
+    }
+    return EDHIP_OK;
+}
+
+int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, int axis, int order,
+                          int transpose, uint32_t flags, void* hip_stream, char* err, size_t errlen)
+{
+    using namespace ed;
+    (void)flags;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (err && errlen)
+        err[0] = 0;
+    if (!input || !output)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "missing array");
+    if (order < 0 || order > 5)                                   // _deform_grid.c:71-74
+        return fail(err, errlen, EDHIP_ERR_INVALID, "spline order not supported");
+    if (input->ndim < 1 || input->ndim > EDHIP_MAX_DIMS || input->ndim != output->ndim)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "input and output dimensions should match");
+    if (axis < 0)
+        axis += input->ndim;                                      // _deform_grid.c:75-77
+    if (axis < 0 || axis >= input->ndim)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis");
+    if (!dtype_ok(input->dtype) || !dtype_ok(output->dtype))
+        return fail(err, errlen, EDHIP_ERR_DTYPE, "data type not supported");
+    for (int d = 0; d < input->ndim; ++d)
+        if (input->shape[d] != output->shape[d])
+            return fail(err, errlen, EDHIP_ERR_INVALID, "input and output shapes should match");
+
+    FilterParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = (const char*)input->data;
+    p.out = (char*)output->data;
+    p.in_dtype = input->dtype;
+    p.out_dtype = output->dtype;
+    p.transpose = transpose != 0;
+    p.len = input->shape[axis];
+    p.in_axis_stride = input->stride_bytes[axis];
+    p.out_axis_stride = output->stride_bytes[axis];
+    p.nlines = 1;
+    for (int d = 0; d < input->ndim; ++d) {
+        if (d == axis)
+            continue;
+        p.outer_len[p.nouter] = input->shape[d];
+        p.in_outer_stride[p.nouter] = input->stride_bytes[d];
+        p.out_outer_stride[p.nouter] = output->stride_bytes[d];
+        p.nlines *= input->shape[d];
+        p.nouter++;
+    }
+    if (p.len <= 0 || p.nlines <= 0)
+        return EDHIP_OK;
+
+    // poles.  transpose: the sqrt() expressions of deform.c:1063-1084; forward: SciPy's correctly
+    // rounded literals (they differ from the expressions by an ulp or so -- see oracle/ed_oracle.c)
+    switch (order) {
+    case 2:
+        p.npoles = 1;
+        p.pole[0] = p.transpose ? std::sqrt(8.0) - 3.0 : -0.171572875253809902396622551580603843;
+        break;
+    case 3:
+        p.npoles = 1;
+        p.pole[0] = p.transpose ? std::sqrt(3.0) - 2.0 : -0.267949192431122706472553658494127633;
+        break;
+    case 4:
+        p.npoles = 2;
+        if (p.transpose) {
+            p.pole[0] = std::sqrt(664.0 - std::sqrt(438976.0)) + std::sqrt(304.0) - 19.0;
+            p.pole[1] = std::sqrt(664.0 + std::sqrt(438976.0)) - std::sqrt(304.0) - 19.0;
+        } else {
+            p.pole[0] = -0.361341225900220177092212841325675255;
+            p.pole[1] = -0.013725429297339121360331226939128204;
+        }
+        break;
+    case 5:
+        p.npoles = 2;
+        if (p.transpose) {
+            p.pole[0] = std::sqrt(67.5 - std::sqrt(4436.25)) + std::sqrt(26.25) - 6.5;
+            p.pole[1] = std::sqrt(67.5 + std::sqrt(4436.25)) - std::sqrt(26.25) - 6.5;
+        } else {
+            p.pole[0] = -0.430575347099973791851434783493520110;
+            p.pole[1] = -0.043096288203264653822712376822550182;
+        }
+        break;
+    default: p.npoles = 0; break;
+    }
+    p.gain = 1.0;
+    for (int h = 0; h < p.npoles; ++h) {
+        p.gain *= (1.0 - p.pole[h]) * (1.0 - 1.0 / p.pole[h]);          // deform.c:1086-1088
+        p.pole_pow[h] = std::pow(p.pole[h], (double)(p.len - 1));       // host libm, like the reference
+        const int max = (int)std::ceil(std::log(1e-15) / std::log(std::fabs(p.pole[h])));
+        p.trunc_branch[h] = max < p.len;                                // deform.c:1119,1134
+    }
+
+    const bool need_ws = p.npoles > 0 && p.len >= 2;
+    if (need_ws) {
+        // bound the fp64 scratch at 256 MiB; chunks of lines reuse it in stream order
+        const int64_t budget = (int64_t)256 << 20;
+        int64_t lines = budget / 8 / p.len;
+        if (lines < 256)
+            lines = 256;
+        lines -= lines % 256;
+        if (lines > p.nlines)
+            lines = p.nlines;
+        p.ws_lines = lines;
+        void* ws = nullptr;
+        hipError_t e = hipMallocAsync(&ws, (size_t)lines * (size_t)p.len * 8, stream);
+        if (e != hipSuccess)
+            return hip_fail(err, errlen, e, "scratch allocation");
+        p.ws = (double*)ws;
+        e = launch_spline_filter(p, stream);
+        const hipError_t e2 = hipFreeAsync(ws, stream);
+        if (e != hipSuccess)
+            return hip_fail(err, errlen, e, "spline filter launch");
+        if (e2 != hipSuccess)
+            return hip_fail(err, errlen, e2, "scratch release");
+    } else {
+        p.ws = nullptr;
+        p.ws_lines = p.nlines;
+        const hipError_t e = launch_spline_filter(p, stream);
+        if (e != hipSuccess)
+            return hip_fail(err, errlen, e, "spline filter launch");
+    }
+    return EDHIP_OK;
+}
+
+}  // extern "C"

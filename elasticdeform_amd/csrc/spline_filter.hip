@@ -1,0 +1,206 @@
+// spline_filter.hip -- K3 (B-spline prefilter, mirror boundary) and K4 (its exact transpose).
+//
+// K3 restates scipy.ndimage.spline_filter1d (third-party; call sites deform_grid.py:160,168,271;
+// algorithm in SURVEY.md Appendix A step 12, pinned bit-for-bit against SciPy 1.15.3 by the
+// oracle tests).  K4 restates NI_SplineFilter1DGrad's per-line recursion, deform.c:1116-1156.
+//
+// Compiled with -ffp-contract=off: every line is filtered in fp64 in the reference's operation
+// order and rounded to the output dtype once, like the reference's double line buffer
+// (deform.c:1106-1162, from_nd_image.c:341-350,422-431).  The result is bit-identical to the CPU
+// path for every dtype.
+//
+// Mapping: one thread per line (a first-order IIR is sequential along the line; all parallelism
+// is across lines).  The fp64 working copy of the lines lives in a line-interleaved scratch
+// buffer ws[i * nlines + line], so that the 64 lanes of a wave, which hold 64 different lines,
+// always touch 64 consecutive doubles -- coalesced whatever the filtered axis is.
+#include "ed_device.h"
+#include "ed_params.h"
+
+namespace ed {
+
+namespace {
+
+struct LineAddr {
+    const char* in;
+    char* out;
+};
+
+__device__ __forceinline__ LineAddr line_address(const FilterParams& p, int64_t line)
+{
+    int64_t in_off = 0, out_off = 0, r = line;
+    for (int d = p.nouter - 1; d >= 0; --d) {
+        const int64_t q = r / p.outer_len[d];
+        const int64_t c = r - q * p.outer_len[d];
+        in_off += c * p.in_outer_stride[d];
+        out_off += c * p.out_outer_stride[d];
+        r = q;
+    }
+    return {p.in + in_off, p.out + out_off};
+}
+
+// forward prefilter of one line (SciPy: gain, then per pole causal init / causal recursion /
+// anti-causal init / anti-causal recursion)
+__global__ __launch_bounds__(256) void prefilter_kernel(const FilterParams p, const int64_t line0,
+                                                        const int64_t nl)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nl)
+        return;
+    const LineAddr a = line_address(p, line0 + j);
+    const int64_t n = p.len;
+    double* ws = p.ws + j;      // element i at ws[i * nl]
+    if (n < 2 || p.npoles == 0) {
+        for (int64_t i = 0; i < n; ++i)
+            store_cast(a.out + i * p.out_axis_stride, p.out_dtype,
+                       load_as_double(a.in + i * p.in_axis_stride, p.in_dtype));
+        return;
+    }
+    for (int64_t i = 0; i < n; ++i)
+        ws[i * nl] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype) * p.gain;
+    for (int h = 0; h < p.npoles; ++h) {
+        const double z = p.pole[h];
+        const double zn1 = p.pole_pow[h];
+        // exact mirror initialisation of the causal filter
+        double c0 = ws[0] + zn1 * ws[(n - 1) * nl];
+        double zi = z;
+        for (int64_t i = 1; i < n - 1; ++i) {
+            c0 += zi * (ws[i * nl] + zn1 * ws[(n - 1 - i) * nl]);
+            zi *= z;
+        }
+        c0 /= 1 - zn1 * zn1;
+        ws[0] = c0;
+        // causal recursion c[i] += z c[i-1]; keep the last two values for the anti-causal init
+        double prev = c0, prev2 = c0;
+        for (int64_t i = 1; i < n; ++i) {
+            const double c = ws[i * nl] + z * prev;
+            ws[i * nl] = c;
+            prev2 = prev;
+            prev = c;
+        }
+        // anti-causal initialisation and recursion c[i] = z (c[i+1] - c[i])
+        double next = (z * prev2 + prev) * z / (z * z - 1);
+        const bool last = h == p.npoles - 1;
+        if (last)
+            store_cast(a.out + (n - 1) * p.out_axis_stride, p.out_dtype, next);
+        else
+            ws[(n - 1) * nl] = next;
+        for (int64_t i = n - 2; i >= 0; --i) {
+            const double c = z * (next - ws[i * nl]);
+            if (last)
+                store_cast(a.out + i * p.out_axis_stride, p.out_dtype, c);
+            else
+                ws[i * nl] = c;
+            next = c;
+        }
+    }
+}
+
+// transpose of the prefilter on one line -- deform.c:1116-1156
+__global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterParams p,
+                                                                  const int64_t line0,
+                                                                  const int64_t nl)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nl)
+        return;
+    const LineAddr a = line_address(p, line0 + j);
+    const int64_t len = p.len;
+    double* ws = p.ws + j;
+    if (len <= 1 || p.npoles == 0) {
+        for (int64_t i = 0; i < len; ++i)
+            store_cast(a.out + i * p.out_axis_stride, p.out_dtype,
+                       load_as_double(a.in + i * p.in_axis_stride, p.in_dtype));
+        return;
+    }
+    for (int64_t i = 0; i < len; ++i)
+        ws[i * nl] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype);
+    for (int h = 0; h < p.npoles; ++h) {
+        const double q = p.pole[h];
+        const bool last = h == p.npoles - 1;
+        // adjoint of the anti-causal recursion, running sum for the adjoint of its initialisation
+        double x0 = ws[0];
+        double sum = q * x0;
+        double prev = -q * x0;
+        ws[0] = prev;
+        for (int64_t ll = 1; ll < len - 1; ++ll) {
+            const double x = ws[ll * nl];
+            sum = q * (sum + x);
+            prev = q * (prev - x);
+            ws[ll * nl] = prev;
+        }
+        sum = (q / (q * q - 1.0)) * (sum + ws[(len - 1) * nl]);
+        double up = ws[(len - 2) * nl] + q * sum;     // ln[len-2] += p*sum
+        ws[(len - 1) * nl] = sum;                     // ln[len-1]  = sum
+        // adjoint of the causal recursion: ln[ll] += p * ln[ll+1], ll = len-2 .. 0
+        double next = sum;
+        for (int64_t ll = len - 2; ll >= 0; --ll) {
+            const double cur = (ll == len - 2 ? up : ws[ll * nl]) + q * next;
+            ws[ll * nl] = cur;
+            next = cur;
+        }
+        // adjoint of the causal initial sum (next == ln[0] here)
+        if (p.trunc_branch[h]) {
+            const double l0 = next;
+            double zn = q;
+            if (last)
+                store_cast(a.out, p.out_dtype, l0 * p.gain);
+            for (int64_t ll = 1; ll < len; ++ll) {
+                const double c = ws[ll * nl] + zn * l0;
+                if (last)
+                    store_cast(a.out + ll * p.out_axis_stride, p.out_dtype, c * p.gain);
+                else
+                    ws[ll * nl] = c;
+                zn *= q;
+            }
+        } else {
+            double zn = q;
+            const double iz = 1.0 / q;
+            double z2n = p.pole_pow[h];
+            const double l0 = next / (1.0 - z2n * z2n);
+            const double tail = ws[(len - 1) * nl] + z2n * l0;
+            z2n *= z2n * iz;
+            if (last) {
+                store_cast(a.out, p.out_dtype, l0 * p.gain);
+                store_cast(a.out + (len - 1) * p.out_axis_stride, p.out_dtype, tail * p.gain);
+            } else {
+                ws[0] = l0;
+                ws[(len - 1) * nl] = tail;
+            }
+            for (int64_t ll = 1; ll <= len - 2; ++ll) {
+                const double c = ws[ll * nl] + (zn + z2n) * l0;
+                if (last)
+                    store_cast(a.out + ll * p.out_axis_stride, p.out_dtype, c * p.gain);
+                else
+                    ws[ll * nl] = c;
+                zn *= q;
+                z2n *= iz;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
+{
+    if (p.nlines <= 0 || p.len <= 0)
+        return hipSuccess;
+    const int block = 256;
+    // p.ws holds p.ws_lines lines; walk the lines in chunks of that size (same stream, so the
+    // chunks reuse the scratch buffer in order)
+    const int64_t chunk = p.ws_lines > 0 ? p.ws_lines : p.nlines;
+    for (int64_t line0 = 0; line0 < p.nlines; line0 += chunk) {
+        const int64_t nl = p.nlines - line0 < chunk ? p.nlines - line0 : chunk;
+        const dim3 grid((unsigned)((nl + block - 1) / block));
+        if (p.transpose)
+            hipLaunchKernelGGL(prefilter_transpose_kernel, grid, dim3(block), 0, stream, p, line0, nl);
+        else
+            hipLaunchKernelGGL(prefilter_kernel, grid, dim3(block), 0, stream, p, line0, nl);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace ed

@@ -1,0 +1,226 @@
+"""
+Public API: ``deform_random_grid``, ``deform_grid``, ``deform_grid_gradient`` -- drop-in for
+``elasticdeform.deform_random_grid / deform_grid / deform_grid_gradient``
+(/root/reference/elasticdeform/deform_grid.py:6-8, :52-53, :182-184): same names, positional
+order, defaults, list-in => list-out, exception classes.
+
+What differs is where the work happens: every array is (moved to) MI355X HBM and the whole
+pipeline -- B-spline prefilter of the inputs and of the displacement grid, the per-voxel
+deformation, and for the gradient the scatter-add plus the transposed prefilter -- runs as
+hand-written HIP kernels behind the C ABI of include/edhip.h, enqueued on the current HIP stream
+with no host synchronisation.
+
+* numpy.ndarray in  -> numpy.ndarray out (one H2D and one D2H copy; the drop-in path)
+* torch.Tensor in   -> torch.Tensor out on the same device (CUDA tensors never touch the host)
+
+There is no CPU fallback: without a GPU or without the built library the call raises.
+"""
+import os
+
+import numpy
+
+from . import _host
+from . import _lib
+
+_ARITHMETIC = {'auto': _lib.FLAG_AUTO, 'exact': _lib.FLAG_EXACT, 'fast': _lib.FLAG_FAST}
+_flags = _ARITHMETIC.get(os.environ.get('EDHIP_ARITHMETIC', 'auto').lower(), _lib.FLAG_AUTO)
+
+
+def set_arithmetic(kind):
+    """Select the kernels' arithmetic: 'auto' (float32 volumes -> fast path, everything else ->
+    exact path), 'exact' (fp64, reference evaluation order, bit-comparable with the reference)
+    or 'fast' (also float64 volumes through the restructured path).  Returns the previous value."""
+    global _flags
+    if kind not in _ARITHMETIC:
+        raise ValueError("arithmetic must be one of %s" % sorted(_ARITHMETIC))
+    prev = [k for k, v in _ARITHMETIC.items() if v == _flags][0]
+    _flags = _ARITHMETIC[kind]
+    return prev
+
+
+def _torch():
+    import torch
+    return torch
+
+
+_TORCH_NAMES = None
+
+
+def _dtype_name(t):
+    """torch dtype -> the NumPy-style name used by the C ABI table."""
+    global _TORCH_NAMES
+    if _TORCH_NAMES is None:
+        torch = _torch()
+        _TORCH_NAMES = {getattr(torch, n): n for n in _lib.DTYPE_CODES if hasattr(torch, n)}
+    name = _TORCH_NAMES.get(t.dtype)
+    if name is None:
+        raise RuntimeError('data type not supported')     # deform.c:744,891 (float16, complex ...)
+    return name
+
+
+def _device_for(arrays):
+    """The GPU every array of this call lives on / is moved to.  Fails loudly without one."""
+    torch = _torch()
+    for a in arrays:
+        if not isinstance(a, numpy.ndarray) and a.is_cuda:
+            return a.device
+    if not torch.cuda.is_available():
+        raise RuntimeError('elasticdeform_amd needs a ROCm GPU (MI355X / gfx950): none is visible '
+                           'and there is no CPU fallback.')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _to_device(x, device):
+    """numpy / torch array -> tensor in HBM on `device`, keeping the logical strides when the
+    bridge allows it (the reference accepts arbitrary strides, _deform_grid.c:12-15)."""
+    torch = _torch()
+    if isinstance(x, numpy.ndarray):
+        if x.dtype.name not in _lib.DTYPE_CODES:
+            raise RuntimeError('data type not supported')
+        if not x.dtype.isnative or not x.flags.aligned or any(s < 0 for s in x.strides) \
+                or not x.flags.writeable:
+            x = numpy.ascontiguousarray(x).astype(x.dtype.newbyteorder('='), copy=True)
+        return torch.from_numpy(x).to(device)
+    x = x.detach()
+    if x.device != device:
+        x = x.to(device)
+    return x
+
+
+def _from_device(t, like):
+    """Give the result back in the caller's array family."""
+    if isinstance(like, numpy.ndarray):
+        return t.cpu().numpy()
+    if like.device != t.device:
+        return t.to(like.device)
+    return t
+
+
+def _desc(t):
+    es = t.element_size()
+    return _lib.describe(t.data_ptr(), _dtype_name(t), tuple(t.shape),
+                         tuple(s * es for s in t.stride()))
+
+
+def _stream(device):
+    return _torch().cuda.current_stream(device).cuda_stream
+
+
+def _filter_axes(x, axes, order, transpose, device):
+    """Chain of 1-D spline filters over `axes`: first pass x -> x_f, the rest in place -- the
+    reference's loop at deform_grid.py:157-162 (forward) / :279-284 (transpose)."""
+    torch = _torch()
+    x_f = torch.empty_like(x)
+    stream = _stream(device)
+    src = x
+    for d in axes:
+        _lib.spline_filter1d(_desc(src), _desc(x_f), d, order, transpose, _flags, stream)
+        src = x_f
+    return x_f
+
+
+def _prefilter_displacement(displacement, device):
+    """Order-3 prefilter of the control grid along every grid axis (deform_grid.py:166-169,
+    :269-272); the output keeps the displacement's dtype like numpy.zeros_like there."""
+    if displacement.ndim < 2:
+        return displacement
+    return _filter_axes(displacement, range(1, displacement.ndim), 3, False, device)
+
+
+def deform_random_grid(X, sigma=25, points=3, order=3, mode='constant', cval=0.0,
+                       crop=None, prefilter=True, axis=None,
+                       affine=None, rotate=None, zoom=None):
+    """
+    Elastic deformation with a random square deformation grid (deform_grid.py:6-49): draws
+    ``numpy.random.randn(ndim, *points) * sigma`` from NumPy's global RNG, exactly like the
+    reference, and calls :func:`deform_grid`.
+    """
+    Xs = _host.normalize_inputs(X)
+    axis, deform_shape = _host.normalize_axis_list(axis, Xs)
+    if not isinstance(points, (list, tuple)):
+        points = [points] * len(deform_shape)
+    displacement = numpy.random.randn(len(deform_shape), *points) * sigma
+    return deform_grid(X, displacement, order, mode, cval, crop, prefilter, axis,
+                       affine, rotate, zoom)
+
+
+def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, prefilter=True,
+                axis=None, affine=None, rotate=None, zoom=None):
+    """
+    Elastic deformation with a deformation grid (deform_grid.py:52-179).
+
+    X : array or list of arrays (numpy.ndarray or torch.Tensor); displacement : array of shape
+    (naxis, n_0, ..., n_{naxis-1}); order 0..5, mode in {nearest, wrap, reflect, mirror,
+    constant}, cval, crop (slices over the deformed axes), prefilter, axis, affine
+    (naxis x naxis+1), rotate / zoom (2-D only) -- all with the reference's meaning, and order /
+    mode / cval / axis may be per-input lists.  Returns the deformed array, or a list for a list.
+    """
+    Xs = _host.normalize_inputs(X)
+    plan = _host.Plan(Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
+
+    torch = _torch()
+    device = _device_for(list(Xs) + [displacement])
+    with torch.cuda.device(device):
+        Xd = [_to_device(x, device) for x in Xs]
+        dd = _to_device(displacement, device)
+
+        # prefilter the inputs along their deformed axes (deform_grid.py:155-164) ...
+        Xf = [(_filter_axes(x, plan.axis[i], int(plan.order[i]), False, device)
+               if prefilter and plan.order[i] > 1 else x) for i, x in enumerate(Xd)]
+        # ... and always the displacement (deform_grid.py:166-169)
+        df = _prefilter_displacement(dd, device)
+
+        # every output element is written by the kernel (value or cval), so no zero fill is needed
+        outs = [torch.empty(tuple(int(s) for s in shape), dtype=x.dtype, device=device)
+                for shape, x in zip(plan.output_shapes, Xd)]
+
+        _lib.deform(False, [_desc(x) for x in Xf], _desc(df), plan.output_offset,
+                    [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
+                    plan.inverse_affine, _flags, _stream(device))
+        res = [_from_device(o, x) for o, x in zip(outs, Xs)]
+    return res if isinstance(X, list) else res[0]
+
+
+def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, crop=None,
+                         prefilter=True, axis=None, X_shape=None,
+                         affine=None, rotate=None, zoom=None):
+    """
+    Gradient of :func:`deform_grid` with respect to its input (deform_grid.py:182-291): the exact
+    adjoint, interpolation and prefilter included.  ``X_shape`` (tuple, or list of tuples) is
+    required when ``crop`` is used.
+    """
+    dYs = _host.normalize_inputs(dY)
+
+    if isinstance(X_shape, tuple):
+        X_shape = [X_shape]
+    elif X_shape is None:
+        if crop is not None:
+            raise ValueError("X_shape is required if the crop parameter is given.")
+        X_shape = [tuple(dy.shape) for dy in dYs]
+
+    torch = _torch()
+    device = _device_for(list(dYs) + [displacement])
+    with torch.cuda.device(device):
+        dYd = [_to_device(dy, device) for dy in dYs]
+        # gradient accumulators start at zero (deform_grid.py:243)
+        dXs = [torch.zeros(tuple(int(v) for v in s), dtype=dy.dtype, device=device)
+               for s, dy in zip(X_shape, dYd)]
+
+        plan = _host.Plan(dXs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
+        if [tuple(s) for s in plan.output_shapes] != [tuple(dy.shape) for dy in dYs]:
+            raise ValueError("X_shape does not match output shape and cropping. "
+                             "Expected output shape is %s, but %s given."
+                             % (str(plan.output_shapes), str([tuple(dy.shape) for dy in dYs])))
+
+        dd = _to_device(displacement, device)
+        df = _prefilter_displacement(dd, device)
+
+        _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
+                    [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
+                    plan.inverse_affine, _flags, _stream(device))
+
+        # gradient of the prefilter: its transpose along each deformed axis (deform_grid.py:276-286)
+        dXf = [(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device)
+                if prefilter and plan.order[i] > 1 else x) for i, x in enumerate(dXs)]
+        res = [_from_device(x, dy) for x, dy in zip(dXf, dYs)]
+    return res if isinstance(dY, list) else res[0]

@@ -1,0 +1,59 @@
+"""
+PyTorch wrapper: ``elasticdeform_amd.torch.deform_grid(X, displacement, *args, **kwargs)`` --
+drop-in for ``elasticdeform.torch.deform_grid`` (/root/reference/elasticdeform/torch.py:33-66).
+
+Same autograd contract as the reference's ``ElasticDeform`` Function (torch.py:5-29): gradients
+flow to the inputs ``X`` only (the displacement gets none), a list / tuple of inputs gives a
+tuple of outputs.  The difference is the one this build exists for: the reference copies every
+tensor to the host, runs one CPU thread and copies back (torch.py:13-16,25-29); here CUDA tensors
+stay in HBM and forward / backward are HIP kernels enqueued on the current stream.
+"""
+from __future__ import absolute_import
+
+import torch
+
+# the package re-exports the functions, and `deform_grid` the function shadows the submodule
+from . import deform_grid as _deform_grid_fn
+from . import deform_grid_gradient as _deform_grid_gradient_fn
+
+
+class ElasticDeform(torch.autograd.Function):
+    """forward: deform_grid; backward: deform_grid_gradient (torch.py:5-29)."""
+
+    @staticmethod
+    def forward(ctx, displacement, deform_args, deform_kwargs, *xs):
+        ctx.save_for_backward(displacement)
+        ctx.deform_args = deform_args
+        ctx.deform_kwargs = deform_kwargs
+        ctx.x_shapes = [tuple(x.shape) for x in xs]
+        ys = _deform_grid_fn([x.detach() for x in xs], displacement.detach(),
+                             *deform_args, **deform_kwargs)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        displacement, = ctx.saved_tensors
+        dxs = _deform_grid_gradient_fn([dy.detach() for dy in dys], displacement.detach(),
+                                       *ctx.deform_args, X_shape=ctx.x_shapes,
+                                       **ctx.deform_kwargs)
+        return (None, None, None) + tuple(dxs)
+
+
+def deform_grid(X, displacement, *args, **kwargs):
+    """
+    Elastic deformation with a deformation grid, wrapped for PyTorch with a custom gradient.
+
+    X : torch.Tensor or list / tuple of torch.Tensors; displacement : tensor or array of control
+    point displacements; remaining arguments as for ``elasticdeform_amd.deform_grid``.
+    Returns a tensor, or a tuple of tensors for a list / tuple input (torch.py:56-66).
+    """
+    if not isinstance(X, (list, tuple)):
+        X_list = [X]
+    else:
+        X_list = X
+    displacement = torch.as_tensor(displacement)
+    y = ElasticDeform.apply(displacement, args, kwargs, *X_list)
+    if isinstance(X, (list, tuple)):
+        return y
+    else:
+        return y[0]

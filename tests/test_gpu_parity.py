@@ -1,0 +1,267 @@
+"""
+GPU parity tests (run with `-m gpu` on the MI355X box).  Every check goes through the product path
+-- elasticdeform_amd's Python API -> ctypes -> the C ABI of include/edhip.h -> HIP kernels -- and
+compares with (a) the committed golden vectors (outputs of the real reference) and (b) the CPU
+oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): float32 within 1e-5; float64 / integer / bool / order-0
+results on the exact path are compared for bit equality; float gradients (atomics reorder the
+additions) within 1e-5 (f32) / 1e-12 relative (f64).
+"""
+import numpy as np
+import pytest
+
+import cases as C
+from oracle import ed_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import elasticdeform_amd as ed  # noqa: E402
+
+F32_TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _aslist(v):
+    return list(v) if isinstance(v, (list, tuple)) else [v]
+
+
+def _pick(case, arrs):
+    if not case["pick"]:
+        return arrs
+    return [a[p] for a, p in zip(arrs, case["pick"]())]
+
+
+def _check(got, want, exact_floats):
+    assert got.dtype == want.dtype and got.shape == want.shape
+    if want.dtype == np.float32 and not exact_floats:
+        np.testing.assert_allclose(got, want, **F32_TOL)
+    else:
+        np.testing.assert_array_equal(got, want)
+
+
+SMALL = [c for c in C.all_cases() if not c["big"]]
+BIG = [c for c in C.all_cases() if c["big"]]
+
+
+@pytest.fixture(autouse=True)
+def _auto_arithmetic():
+    prev = ed.set_arithmetic("auto")
+    yield
+    ed.set_arithmetic(prev)
+
+
+@pytest.mark.parametrize("case", SMALL, ids=lambda c: c["name"])
+def test_forward_and_gradient_vs_golden(case, golden):
+    """Default arithmetic: f32 -> fast kernels (1e-5), everything else -> exact kernels (==)."""
+    X, disp, kw = case["make"]()
+    out = ed.deform_grid(X, disp, **kw)
+    assert isinstance(out, list) == isinstance(X, list)
+    for g, w in zip(_pick(case, _aslist(out)), golden.outputs(case, "out")):
+        _check(g, w, exact_floats=False)
+    if case["grad"]:
+        dY = C.seeded_dY(case, out)
+        grad = ed.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
+        for g, w in zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad")):
+            assert g.dtype == w.dtype and g.shape == w.shape
+            if w.dtype == np.float32:
+                np.testing.assert_allclose(g, w, **F32_TOL)
+            else:
+                np.testing.assert_allclose(g, w, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("case", [c for c in SMALL if c["name"].endswith("_f32")],
+                         ids=lambda c: c["name"])
+def test_float32_exact_arithmetic_is_bit_equal(case, golden):
+    """EDHIP_FLAG_EXACT: the fp64 reference-order kernels reproduce float32 outputs bit for bit."""
+    ed.set_arithmetic("exact")
+    X, disp, kw = case["make"]()
+    out = ed.deform_grid(X, disp, **kw)
+    for g, w in zip(_aslist(out), golden.outputs(case, "out")):
+        np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize("case", [c for c in SMALL if c["name"].endswith("_f64")
+                                  or c["name"].startswith(("E_", "L1d", "A2d_s25"))][::3],
+                         ids=lambda c: c["name"])
+def test_float64_fast_arithmetic_close(case, golden):
+    """EDHIP_FLAG_FAST on float64 volumes: restructured sums, still fp64 -> 1e-11."""
+    ed.set_arithmetic("fast")
+    X, disp, kw = case["make"]()
+    out = ed.deform_grid(X, disp, **kw)
+    for g, w in zip(_aslist(out), golden.outputs(case, "out")):
+        np.testing.assert_allclose(g, w, rtol=1e-11, atol=1e-11)
+    if case["grad"]:
+        dY = C.seeded_dY(case, out)
+        grad = ed.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
+        for g, w in zip(_aslist(grad), golden.outputs(case, "grad")):
+            np.testing.assert_allclose(g, w, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("case", BIG, ids=lambda c: c["name"])
+def test_baseline_configs_vs_golden(case, golden):
+    """BASELINE.json cfg2 (256^3 f32 order 3 mirror; three 24^3 crops x two sigmas), cfg3 (128^3
+    forward + gradient), cfg4 (3x256^3 image order 3 + 256^3 int32 labels order 0, axis, crop
+    64^3, 3x4 affine).  Label volume: bit-exact."""
+    X, disp, kw = case["make"]()
+    out = ed.deform_grid(X, disp, **kw)
+    for g, w in zip(_pick(case, _aslist(out)), golden.outputs(case, "out")):
+        _check(g, w, exact_floats=False)
+    if case["grad"]:
+        dY = C.seeded_dY(case, out)
+        grad = ed.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
+        for g, w in zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad")):
+            np.testing.assert_allclose(g, w, **F32_TOL)
+
+
+def test_cfg1_readme_example(golden):
+    case = [c for c in C.all_cases() if c["name"] == "cfg1_readme"][0]
+    X, disp, kw = case["make"]()
+    out = ed.deform_grid(X, disp, **kw)
+    np.testing.assert_allclose(_pick(case, [out])[0], golden.outputs(case, "out")[0], **F32_TOL)
+    # the whole image against the oracle, both arithmetic modes
+    want = orc.deform_grid(X, disp, **kw)
+    np.testing.assert_allclose(out, want, **F32_TOL)
+    ed.set_arithmetic("exact")
+    np.testing.assert_array_equal(ed.deform_grid(X, disp, **kw), want)
+
+
+# ---- fresh seeds against the oracle: shapes that are ragged w.r.t. the 64-wide tiles -----------
+
+@pytest.mark.parametrize("shape,points", [((67, 131), (3, 5)), ((5, 300), (1, 4)),
+                                          ((19, 33, 70), (3, 2, 5)), ((2, 2, 2), (2, 2, 2)),
+                                          ((130,), (6,)), ((6, 5, 7, 9), (2, 2, 3, 2))])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16])
+def test_ragged_shapes_vs_oracle(shape, points, dtype):
+    rng = np.random.default_rng(hash((shape, points)) % 2**32)
+    for order in (0, 1, 3, 5):
+        for mode in ("mirror", "constant", "wrap"):
+            X = (rng.random(shape) * 100).astype(dtype)
+            disp = rng.standard_normal((len(shape),) + points) * 2.5
+            kw = dict(order=order, mode=mode, cval=-1.5)
+            want = orc.deform_grid(X, disp, **kw)
+            got = ed.deform_grid(X, disp, **kw)
+            if dtype == np.float32:
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6 * 100)  # data in [0, 100)
+            else:
+                np.testing.assert_array_equal(got, want)
+            if np.dtype(dtype).kind == "f":
+                dY = rng.random(want.shape).astype(dtype)
+                gw = orc.deform_grid_gradient(dY, disp, **kw)
+                gg = ed.deform_grid_gradient(dY, disp, **kw)
+                tol = dict(rtol=1e-5, atol=1e-5) if dtype == np.float32 else \
+                    dict(rtol=1e-12, atol=1e-12)
+                np.testing.assert_allclose(gg, gw, **tol)
+
+
+def test_integer_gradient_is_bit_exact():
+    """*(T*)p += (T)t accumulates in the array dtype (deform.c:309-312): integer atomics are
+    associative, so even the scatter-add is bit-reproducible for integer gradients."""
+    rng = np.random.default_rng(77)
+    for dtype in (np.int32, np.int64, np.int16, np.uint8):
+        dY = (rng.random((21, 35)) * 90).astype(dtype)
+        disp = rng.standard_normal((2, 3, 3)) * 2
+        for order in (0, 1, 3):
+            want = orc.deform_grid_gradient(dY, disp, order=order, mode="mirror", prefilter=False)
+            got = ed.deform_grid_gradient(dY, disp, order=order, mode="mirror", prefilter=False)
+            np.testing.assert_array_equal(got, want)
+
+
+def test_strided_and_fortran_inputs():
+    rng = np.random.default_rng(8)
+    big = rng.random((40, 50, 6))
+    X = big[::2, 5:45, 1]                    # non-contiguous view, positive strides
+    F = np.asfortranarray(rng.random((20, 40)))
+    R = rng.random((20, 40))[::-1]           # negative stride (bridged by a copy)
+    disp = rng.standard_normal((2, 3, 3)) * 3
+    for arr in (X, F, R):
+        want = orc.deform_grid(arr, disp, order=3, mode="reflect", prefilter=False)
+        got = ed.deform_grid(arr, disp, order=3, mode="reflect", prefilter=False)
+        np.testing.assert_array_equal(got, want)
+    # torch views with arbitrary strides stay on the device and are read in place
+    t = torch.from_numpy(big).cuda()
+    view = t[::2, 5:45, 1]
+    got = ed.deform_grid(view, torch.from_numpy(disp).cuda(), order=3, mode="reflect",
+                         prefilter=False)
+    assert got.is_cuda
+    np.testing.assert_array_equal(got.cpu().numpy(),
+                                  orc.deform_grid(X, disp, order=3, mode="reflect",
+                                                  prefilter=False))
+
+
+def test_prefilter_kernels_vs_scipy_and_reference_transpose(golden):
+    import scipy.ndimage
+    from elasticdeform_amd import deform_grid as _  # noqa: F401  (function; module below)
+    import importlib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    f = golden.filters()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for n in (1, 2, 3, 5, 8, 30, 40, 100):
+        x = f["x_n%d" % n]
+        xd = torch.from_numpy(x).cuda()
+        for order in range(6):
+            if order > 1:
+                got = dgm._filter_axes(xd, [1], order, False, dev).cpu().numpy()
+                np.testing.assert_array_equal(got, f["fwd_o%d_n%d" % (order, n)])
+                np.testing.assert_array_equal(
+                    got, scipy.ndimage.spline_filter1d(x, order=order, axis=1))
+            got = dgm._filter_axes(xd, [1], order, True, dev).cpu().numpy()
+            np.testing.assert_array_equal(got, f["tr_o%d_n%d" % (order, n)])
+    for dt in ("float32", "int16", "uint8"):
+        a = torch.from_numpy(f["xd_%s" % dt]).cuda()
+        np.testing.assert_array_equal(dgm._filter_axes(a, [1], 3, False, dev).cpu().numpy(),
+                                      f["fwd_o3_%s" % dt])
+        np.testing.assert_array_equal(dgm._filter_axes(a, [1], 3, True, dev).cpu().numpy(),
+                                      f["tr_o3_%s" % dt])
+    # a larger, multi-axis, in-place chain like deform_grid.py:157-162 does
+    x = np.random.default_rng(3).random((33, 70, 129))
+    want = x
+    for d in range(3):
+        want = scipy.ndimage.spline_filter1d(want, order=3, axis=d)
+    got = dgm._filter_axes(torch.from_numpy(x).cuda(), [0, 1, 2], 3, False, dev).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+# ---- size-independent properties at BASELINE.json's full sizes ---------------------------------
+
+def test_cfg2_full_size_properties():
+    """256^3 float32, order 3, mirror (the benchmark workload), data resident on the GPU:
+    crop identity (README.md:113: full[crop] == cropped), linearity, adjointness of the gradient,
+    and an oracle spot check on a slab."""
+    X, disp, kw = C.cfg2_inputs(5.0)
+    Xd = torch.from_numpy(X).cuda()
+    dd = torch.from_numpy(disp).cuda()
+    full = ed.deform_grid(Xd, dd, **kw)
+    assert full.is_cuda and full.shape == Xd.shape and full.dtype == torch.float32
+    crop = (slice(37, 101), slice(200, 256), slice(0, 256))
+    part = ed.deform_grid(Xd, dd, crop=crop, **kw)
+    assert torch.equal(full[crop], part)
+    # linearity in X
+    Z = torch.from_numpy(np.random.default_rng(9).random(X.shape, dtype=np.float32)).cuda()
+    lin = ed.deform_grid(2.0 * Xd - 0.5 * Z, dd, **kw)
+    ref = 2.0 * full - 0.5 * ed.deform_grid(Z, dd, **kw)
+    assert float((lin - ref).abs().max()) < 2e-5
+    # <dY, f(X)> == <f^T(dY), X>   (fp64 accumulation of the dot products)
+    dY = torch.from_numpy(np.random.default_rng(10).random(X.shape, dtype=np.float32)).cuda()
+    dX = ed.deform_grid_gradient(dY, dd, **kw)
+    lhs = float((dY.double() * full.double()).sum())
+    rhs = float((dX.double() * Xd.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * abs(lhs)
+    # oracle on a thin slab of the same volume
+    slab = (slice(120, 124), slice(0, 256), slice(0, 256))
+    want = orc.deform_grid(X, disp, crop=slab, **kw)
+    np.testing.assert_allclose(full[slab].cpu().numpy(), want, **F32_TOL)
+
+
+def test_empty_and_degenerate_inputs():
+    disp = np.zeros((2, 3, 3))
+    X = np.random.default_rng(1).random((9, 11))
+    # zero displacement, order 1: identity
+    np.testing.assert_array_equal(ed.deform_grid(X, disp, order=1, prefilter=False), X)
+    # step axis of extent zero -> empty output, no launch
+    E = np.zeros((0, 9, 11))
+    out = ed.deform_grid(E, disp, axis=(1, 2))
+    assert out.shape == (0, 9, 11)
+    # float16 is rejected exactly like the reference does (deform.c:744,891)
+    with pytest.raises(RuntimeError, match="data type not supported"):
+        ed.deform_grid(X.astype(np.float16), disp)
