@@ -40,13 +40,24 @@ __device__ __forceinline__ double load_as_double(const char* p, int dt)
 // conversion goes through a signed 32-bit (8/16-bit targets) or signed 64-bit (32/64-bit targets)
 // truncating convert and is then narrowed, so out-of-range values of the narrow types wrap
 // instead of saturating (matters for integer images pushed through the prefilter).
-__device__ __forceinline__ int32_t trunc_i32(double t) { return (int32_t)t; }
-__device__ __forceinline__ int64_t trunc_i64(double t) { return (int64_t)t; }
+__device__ __forceinline__ int32_t trunc_i32(double t)
+{
+    // cvttsd2si r32: out-of-range and NaN give the "integer indefinite" 0x80000000
+    return (t >= -2147483648.0 && t < 2147483648.0) ? (int32_t)t : (int32_t)0x80000000;
+}
+__device__ __forceinline__ int64_t trunc_i64(double t)
+{
+    // cvttsd2si r64: out-of-range and NaN give 0x8000000000000000
+    return (t >= -9223372036854775808.0 && t < 9223372036854775808.0)
+               ? (int64_t)t
+               : (int64_t)0x8000000000000000ull;
+}
 __device__ __forceinline__ uint64_t trunc_u64(double t)
 {
-    // gcc: values below 2^63 use the signed convert, the rest subtract 2^63 first
-    return t < 9223372036854775808.0 ? (uint64_t)(int64_t)t
-                                     : (uint64_t)(int64_t)(t - 9223372036854775808.0) ^ 0x8000000000000000ull;
+    // gcc: values below 2^63 use the signed convert, the rest subtract 2^63 first and flip bit 63
+    return t < 9223372036854775808.0
+               ? (uint64_t)trunc_i64(t)
+               : (uint64_t)trunc_i64(t - 9223372036854775808.0) ^ 0x8000000000000000ull;
 }
 
 // plain C cast store: the spline filters' line-buffer write-back (from_nd_image.c:422-431) and

@@ -53,6 +53,10 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
 hipError_t launch_deform_fast(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
 bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient);
 
+// LDS-tiled forward kernel (3 deformed axes, order >= 2): the benchmark's hot kernel.
+hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
+bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient);
+
 struct FilterParams {
     const char* in;
     char* out;

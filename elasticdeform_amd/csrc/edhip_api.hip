@@ -200,8 +200,13 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         else
             use_fast = in.dtype == EDHIP_F32 && out.dtype == EDHIP_F32 &&
                        deform_fast_supported(g, v, gradient);
-        const hipError_t e = use_fast ? launch_deform_fast(g, v, gradient != 0, stream)
-                                      : launch_deform_exact(g, v, gradient != 0, stream);
+        hipError_t e;
+        if (!use_fast)
+            e = launch_deform_exact(g, v, gradient != 0, stream);
+        else if (deform_tile_supported(g, v, gradient != 0))
+            e = launch_deform_tile(g, v, gradient != 0, stream);
+        else
+            e = launch_deform_fast(g, v, gradient != 0, stream);
         if (e != hipSuccess)
             return hip_fail(err, errlen, e, "deform kernel launch");
     }
