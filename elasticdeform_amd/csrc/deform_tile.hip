@@ -1,35 +1,45 @@
-// deform_tile.hip -- K1 forward, LDS-tiled: the hot kernel of the benchmark workload
-// (3 deformed axes, float32 / float64 volumes, spline order 2-5).
+// deform_tile.hip -- K1 (forward gather) and K2 (gradient scatter-add), LDS-tiled: the hot kernels
+// of the benchmark workload (3 deformed axes, float32 / float64 volumes, spline order 2-5).
 //
-// Per-voxel pipeline of DeformGrid's forward branch (deform.c:649-924), organised per OUTPUT TILE:
+// Per-voxel pipeline of DeformGrid's hot loop (deform.c:649-1001), organised per OUTPUT TILE:
 //
-//   tile     8 x 8 x 8 output voxels per 256-thread workgroup (4 waves x 2 z-slices each; a lane
-//            owns one (y, x) column of the tile), cubic so that the source bounding box stays
-//            small under shear (long-x tiles overfetch 6x, cubes 3.5x)
-//   phase A  displacement at every voxel (deform.c:650-758), fp64, evaluated separably through
-//            LDS by the whole workgroup: the control grid D is parked in LDS, contracted over z
-//            for the tile's 8 slices (P), then over y for the 64 rows (Q); a voxel is left with 4
-//            x-taps per component (12 fp64 FMAs instead of the reference's 192 multiply-adds).
-//            The per-axis weights / mirror-mapped control indices of the tile's 8+8+8 output
-//            indices are the block prologue's LDS table (the reference's `dsplvals`,
-//            deform.c:639-647).  Then affine, + offset, boundary map, floor -- all fp64 -- and the
-//            fractional offsets are handed to fp32 (float32 volumes) for the basis weights.
-//   phase B  bounding box of all tap windows of the tile, in UNMAPPED tap-index space
-//            (wave min/max reduce -> one LDS atomic per wave).
-//   phase C  the source box is staged from HBM/L2 into LDS once (it overlays D/P/Q, which are dead
-//            by then), rows coalesced along the fastest axis; every box index goes through the
-//            mirror map here, which is exactly what the reference does with the taps of a window
-//            that sticks out (deform.c:791-813) -- so the gather needs no edge handling at all.
-//            float32: a second copy shifted by one element makes every x-run of taps aligned
-//            ds_read_b64 pairs instead of single ds_read_b32.
-//   phase D  (order+1)^3 tap gather from LDS, accumulated separably (x, y, z) in the data's width.
+//   strip    a 256-thread workgroup (4 waves) owns a strip of up to 8 tiles along x; a tile is
+//            8 x 8 x 8 output voxels (cubic, so the source bounding box stays small under shear:
+//            SURVEY.md section 7 -- long-x tiles overfetch 6x, cubes 3.5x); a lane owns one (y, x)
+//            column of the tile and two of its z-slices.
+//   prologue (once per strip) displacement spline, separable, fp64, through LDS (deform.c:639-758):
+//            per-axis cubic weights + mirror-mapped control indices of the strip's 8 + 8 + 64
+//            output indices (the reference's `dsplvals` table, built per strip); the control grid
+//            D parked in LDS as doubles; contracted over z for the 8 slices (P), then over y for
+//            the 64 rows (Q).  Q stays resident for the whole strip, so a voxel is left with 4
+//            x-taps per component: 12 fp64 FMAs instead of the reference's 192 multiply-adds.
+//   phase A  per tile: displacement, affine, + offset, boundary map, floor -- all fp64 -- then the
+//            fractional offsets are handed to the data's width for the basis weights.
+//   phase B  bounding box of all tap windows of the tile in UNMAPPED tap-index space (wave
+//            min/max reduce, one LDS atomic per wave).
+//   K1 C/D   the source box is staged from HBM/L2 into LDS once (it overlays D/P, dead by then),
+//            rows coalesced along the fastest axis; every box index goes through the mirror map
+//            here, which is what the reference does with the taps of a window that sticks out
+//            (deform.c:791-813) -- the gather needs no edge handling.  float32: a second copy
+//            shifted by one element makes every x-run of taps aligned ds_read_b64 pairs.  Then the
+//            (order+1)^3 tap gather from LDS, accumulated separably (x, y, z) in the data's width.
+//   K2 C/D   (float32) the box is an accumulator: taps are scattered with INTEGER LDS atomics
+//            (ds_add_u32 sustains ~5 cycles per wave instruction on MI355X, ds_add_f32 ~195 --
+//            profiles/r01_ubench_lds.txt) in a per-tile fixed-point scale derived from max|dY| of
+//            the tile, which cannot overflow and rounds each contribution to 2^-22 of that
+//            maximum -- the same order as the float32 rounding of the reference's own `+=`
+//            (deform.c:309-312).  The box is then flushed with one float atomic per touched
+//            source element (mirror-mapped; dX must be zero on entry): ~3.5 global atomics per
+//            voxel instead of 64.
 //   spill    a tile whose box exceeds the LDS budget (strong folding, 'wrap' seams) is appended to
-//            a worklist and finished by deform_tile3_spill_kernel straight from global memory with
-//            per-tap mirror mapping; the hot kernel carries no fallback code.
+//            a worklist and finished by the spill kernels straight from global memory with
+//            per-tap mirror mapping; the hot kernels carry no fallback code.
 //
 // HBM traffic: each source voxel is fetched ~3.5x per launch but from L2 / Infinity Cache
-// (neighbouring tiles overlap; tiles are dealt to the 8 XCDs in contiguous chunks so that the
+// (neighbouring tiles overlap; strips are dealt to the 8 XCDs in contiguous chunks so that the
 // overlap stays inside one L2); algorithmic bytes are 4 read + 4 written per voxel (float32).
+#include <cstdlib>
+
 #include "ed_device.h"
 #include "ed_params.h"
 
@@ -38,17 +48,22 @@ namespace ed {
 namespace {
 
 constexpr int kT = 8;                 // tile edge
+constexpr int kStrip = 8;             // tiles per strip (along x)
 constexpr int kBlock = 256;
-constexpr int kTabBytes = 3 * kT * 48;             // 1152
-constexpr int kRedInts = 8;
-constexpr int kHeadBytes = kTabBytes + kRedInts * 4;   // 1184, multiple of 16
 
 struct AxTab {
     double w[4];
     int idx[4];
 };
 static_assert(sizeof(AxTab) == 48, "AxTab layout");
-static_assert(kHeadBytes % 16 == 0, "LDS carve alignment");
+
+// LDS carve (bytes)
+constexpr int kOffTabZY = 0;                              // [2][8] AxTab
+constexpr int kOffTabX = 2 * kT * 48;                     // [kStrip][8] AxTab
+constexpr int kOffRed = kOffTabX + kStrip * kT * 48;      // int[2][8]: lo[3], hi[3], -, -
+constexpr int kOffSum = kOffRed + 64;                     // float[2][4]: per-wave sum |dY| (K2)
+constexpr int kOffQ = kOffSum + 32;                       // 3936
+static_assert(kOffQ % 16 == 0, "LDS carve alignment");
 
 __device__ __forceinline__ int mirror_i32(int idx, int len)
 {
@@ -139,68 +154,68 @@ struct TileGeom {
     int in_len[3];        // I_k (the tile kernels require extents < 2^30)
     int out_len[3];
     int tiles[3];         // number of tiles per axis
-    int ntiles;
+    int strips_x;         // strips per tile row
+    int nstrips;
+    int lg_nyx, lg_nx;    // log2 of ncp_y*ncp_x and ncp_x padded to powers of two
+    int box_cap;          // elements per LDS copy
+    int off_ov;           // LDS byte offset of the overlay region (box | D, P)
     int64_t in_stride[3];    // element strides
     int64_t out_stride[3];
-    int box_cap;          // elements per LDS copy
-    int overlay_bytes;    // size of the D/P/Q | box overlay region
     int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
+    int dbg;              // ablation switches for profiling (EDHIP_TILE_DBG), 0 in production
 };
 
-__device__ __forceinline__ void tile_origin(const TileGeom& tg, int t, int* o0)
+struct StripPos {
+    int tz, ty, tx0, ntile;   // tile coordinates of the strip and number of tiles in it
+};
+
+__device__ __forceinline__ bool strip_position(const TileGeom& tg, StripPos& sp)
 {
-    const int tx = t % tg.tiles[2];
-    t /= tg.tiles[2];
-    const int ty = t % tg.tiles[1];
-    const int tz = t / tg.tiles[1];
-    o0[0] = tz * kT;
-    o0[1] = ty * kT;
-    o0[2] = tx * kT;
+    // strips are dealt to the XCDs in contiguous chunks (block b runs on XCD b % 8): neighbouring
+    // strips, whose source boxes overlap, share an L2
+    const int b = blockIdx.x;
+    const int per = (tg.nstrips + 7) >> 3;
+    int s = (b & 7) * per + (b >> 3);
+    if (s >= tg.nstrips)
+        return false;
+    const int sx = s % tg.strips_x;
+    s /= tg.strips_x;
+    sp.ty = s % tg.tiles[1];
+    sp.tz = s / tg.tiles[1];
+    sp.tx0 = sx * kStrip;
+    sp.ntile = min(kStrip, tg.tiles[2] - sp.tx0);
+    return true;
 }
 
-template <typename T, int ORDER, bool PAIR>
-__global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridGeom g,
-                                                                     const IOView v,
-                                                                     const TileGeom tg)
+// Strip prologue: tables, D -> LDS, P, Q.  Ends with a barrier; afterwards only tabx and Q are
+// needed (D / P may be overwritten).
+__device__ __forceinline__ void strip_prologue(const GridGeom& g, const TileGeom& tg,
+                                               const StripPos& sp, char* smem)
 {
-    constexpr int NT = ORDER + 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    AxTab* tab = reinterpret_cast<AxTab*>(smem);                      // [3][8]
-    int* sred = reinterpret_cast<int*>(smem + kTabBytes);              // lo[3], hi[3]
-    char* overlay = smem + kHeadBytes;
-    // phase A view of the overlay
-    const int ncpz = (int)g.ncp[0], ncpy = (int)g.ncp[1], ncpx = (int)g.ncp[2];
-    const int nyx = ncpy * ncpx;
-    double* sD = reinterpret_cast<double*>(overlay);         // [3][ncpz][nyx]
-    double* sP = sD + 3 * ncpz * nyx;                         // [8][3][nyx]
-    double* sQ = sP + kT * 3 * nyx;                           // [8][8][3][ncpx]
-    // phase C/D view
-    T* box0 = reinterpret_cast<T*>(overlay);
-    T* box1 = box0 + tg.box_cap + 8;      // +8 elements: the two copies sit on disjoint LDS banks
-
+    AxTab* tabzy = reinterpret_cast<AxTab*>(smem + kOffTabZY);
+    AxTab* tabx = reinterpret_cast<AxTab*>(smem + kOffTabX);
+    int* sred = reinterpret_cast<int*>(smem + kOffRed);
+    double* sQ = reinterpret_cast<double*>(smem + kOffQ);
+    const int ncpz = (int)g.ncp[0], ncpx = (int)g.ncp[2];
+    const int nyx = (int)g.ncp[1] * ncpx;
+    const int lgp = tg.lg_nyx, lgx = tg.lg_nx;
+    double* sD = reinterpret_cast<double*>(smem + tg.off_ov);      // [3][ncpz][1 << lgp]
+    double* sP = sD + ((3 * ncpz) << lgp);                           // [8][3][1 << lgp]
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int yy = lane >> 3, xx = lane & 7;
 
-    // tiles are dealt to the XCDs in contiguous chunks (block b runs on XCD b % 8): neighbouring
-    // tiles, whose source boxes overlap, share an L2
-    int tile;
-    {
-        const int b = blockIdx.x;
-        const int per = (tg.ntiles + 7) >> 3;
-        tile = (b & 7) * per + (b >> 3);
-        if (tile >= tg.ntiles)
-            return;
-    }
-    int o0[3];
-    tile_origin(tg, tile, o0);
-
-    // ---- block prologue: per-axis displacement weights / control indices (deform.c:639-690),
-    //      control grid -> LDS as doubles ----------------------------------------------------------
-    if (tid < 3 * kT) {
-        const int a = tid >> 3, i = tid & 7;
-        int oi = o0[a] + i;
+    // per-axis cubic weights / control indices (deform.c:639-690): 8 z, 8 y, up to 64 x entries
+    if (tid < 2 * kT + kStrip * kT) {
+        int a, oi;
+        AxTab* dst;
+        if (tid < 2 * kT) {
+            a = tid >> 3;
+            oi = (a == 0 ? sp.tz : sp.ty) * kT + (tid & 7);
+            dst = tabzy + tid;
+        } else {
+            a = 2;
+            oi = sp.tx0 * kT + (tid - 2 * kT);
+            dst = tabx + (tid - 2 * kT);
+        }
         if (oi >= tg.out_len[a])
             oi = tg.out_len[a] - 1;
         const double cp = control_coordinate(g.ncp[a], (int64_t)oi + g.off[a], g.in_len[a]);
@@ -210,96 +225,159 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
         spline_weights(cp, 3, w);
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            tab[tid].w[l] = w[l];
-            tab[tid].idx[l] = (int)(edge ? mirror_index(start + l, g.ncp[a]) : start + l);
+            dst->w[l] = w[l];
+            dst->idx[l] = (int)(edge ? mirror_index(start + l, g.ncp[a]) : start + l);
         }
     }
-    if (tid < 3) {
-        sred[tid] = 0x7fffffff;
-        sred[3 + tid] = (int)0x80000000;
+    if (tid < 16) {
+        const int k = tid & 7;
+        sred[tid] = k < 3 ? 0x7fffffff : (int)0x80000000;
     }
-    for (int e = tid; e < 3 * ncpz * nyx; e += kBlock) {
-        int r = e;
-        const int j2 = r % ncpx;
-        r /= ncpx;
-        const int j1 = r % ncpy;
-        r /= ncpy;
-        const int j0 = r % ncpz;
-        const int h = r / ncpz;
-        sD[e] = load_as_double(g.disp + g.disp_stride[0] * h + g.disp_stride[1] * j0 +
-                                   g.disp_stride[2] * j1 + g.disp_stride[3] * j2,
-                               g.disp_dtype);
+    // control grid -> LDS (doubles), rows padded to 1 << lgp
+    for (int e = tid; e < ((3 * ncpz) << lgp); e += kBlock) {
+        const int j = e & ((1 << lgp) - 1), r = e >> lgp;
+        if (j < nyx) {
+            const int j1 = j / ncpx, j2 = j - j1 * ncpx;
+            const int h = r / ncpz, j0 = r - h * ncpz;
+            sD[e] = load_as_double(g.disp + g.disp_stride[0] * h + g.disp_stride[1] * j0 +
+                                       g.disp_stride[2] * j1 + g.disp_stride[3] * j2,
+                                   g.disp_dtype);
+        }
     }
     __syncthreads();
+    // P[zi][h][j] = sum_l wz[zi][l] * D[h][iz[zi][l]][j]
+    for (int e = tid; e < ((kT * 3) << lgp); e += kBlock) {
+        const int j = e & ((1 << lgp) - 1), r = e >> lgp;
+        if (j < nyx) {
+            const int zi = r / 3, h = r - zi * 3;
+            const AxTab& tz_ = tabzy[zi];
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                acc += tz_.w[l] * sD[((h * ncpz + tz_.idx[l]) << lgp) + j];
+            sP[e] = acc;
+        }
+    }
+    __syncthreads();
+    // Q[zi][y][h][j2] = sum_l wy[y][l] * P[zi][h][iy[y][l]][j2]
+    for (int q = tid; q < ((kT * kT * 3) << lgx); q += kBlock) {
+        const int j2 = q & ((1 << lgx) - 1), r = q >> lgx;
+        if (j2 < ncpx) {
+            const int zy = r / 3, h = r - zy * 3;
+            const int y = zy & 7, zi = zy >> 3;
+            const AxTab& ty_ = tabzy[kT + y];
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                acc += ty_.w[l] * sP[((zi * 3 + h) << lgp) + ty_.idx[l] * ncpx + j2];
+            sQ[q] = acc;
+        }
+    }
+    __syncthreads();
+}
 
-    // ---- phase A.1: P[zi][h][j] = sum_l wz[zi][l] * D[h][iz[zi][l]][j] ----------------------------
-    for (int e = tid; e < kT * 3 * nyx; e += kBlock) {
-        const int zi = e / (3 * nyx), r = e - zi * 3 * nyx;
-        const int h = r / nyx, j = r - h * nyx;
-        const AxTab& tz_ = tab[zi];
-        double acc = 0.0;
+// Phase A for one voxel: displacement from Q, affine, boundary map, window start, fraction.
+template <typename T, int ORDER>
+__device__ __forceinline__ bool voxel_coords(const GridGeom& g, int mode, const double* sQ, int lgx,
+                                             const AxTab& tx_, int zi, int yy, const int* o,
+                                             int* start, T* frac)
+{
+    bool cst = false;
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const double* qrow = sQ + (((zi * kT + yy) * 3 + h) << lgx);
+        double d = 0.0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
-            acc += tz_.w[l] * sD[(h * ncpz + tz_.idx[l]) * nyx + j];
-        sP[e] = acc;
-    }
-    __syncthreads();
-    // ---- phase A.2: Q[zi][y][h][j2] = sum_l wy[y][l] * P[zi][h][iy[y][l]][j2] -----------------------
-    for (int q = tid; q < kT * kT * 3 * ncpx; q += kBlock) {
-        int r = q;
-        const int j2 = r % ncpx;
-        r /= ncpx;
-        const int h = r % 3;
-        r /= 3;
-        const int y = r & 7, zi = r >> 3;
-        const AxTab& ty_ = tab[kT + y];
-        double acc = 0.0;
+            d += tx_.w[l] * qrow[tx_.idx[l]];
+        double c;
+        if (g.has_affine) {
+            c = g.affine[h * 4 + 3];
 #pragma unroll
-        for (int l = 0; l < 4; ++l)
-            acc += ty_.w[l] * sP[(zi * 3 + h) * nyx + ty_.idx[l] * ncpx + j2];
-        sQ[q] = acc;
+            for (int l = 0; l < 3; ++l)
+                c += g.affine[h * 4 + l] * (double)o[l];
+        } else {
+            c = (double)o[h];
+        }
+        c = map_coordinate(c + (double)g.off[h] + d, g.in_len[h], mode);
+        const bool bad = !(c > -1.0);
+        cst = cst || bad;
+        const double fl = floor((ORDER & 1) ? c : c + 0.5);
+        start[h] = bad ? 0 : (int)fl - ORDER / 2;
+        frac[h] = (T)(c - fl);
     }
-    __syncthreads();
+    return cst;
+}
 
-    // ---- phase A.3: coordinates of this thread's two voxels --------------------------------------
-    int start[2][3];
-    T frac[2][3];
-    bool valid[2], constant[2];
-    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-    int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-    {
-        const AxTab& tx_ = tab[2 * kT + xx];
+__device__ __forceinline__ void step_offsets(const IOView& v, int64_t ss, int64_t& in_off,
+                                             int64_t& out_off)
+{
+    in_off = 0;
+    out_off = 0;
+    int64_t r = ss;
+    for (int l = 0; l < v.nstep; ++l) {
+        const int64_t q = r / v.step_len[l];
+        const int64_t c = r - q * v.step_len[l];
+        in_off += v.in_step_stride[l] * c;
+        out_off += v.out_step_stride[l] * c;
+        r = q;
+    }
+}
+
+// ================================================================================================
+// K1: forward
+// ================================================================================================
+template <typename T, int ORDER, bool PAIR>
+__global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridGeom g,
+                                                                     const IOView v,
+                                                                     const TileGeom tg)
+{
+    constexpr int NT = ORDER + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StripPos sp;
+    if (!strip_position(tg, sp))
+        return;
+    strip_prologue(g, tg, sp, smem);
+
+    const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
+    int* sred = reinterpret_cast<int*>(smem + kOffRed);
+    const double* sQ = reinterpret_cast<const double*>(smem + kOffQ);
+    T* box0 = reinterpret_cast<T*>(smem + tg.off_ov);
+    T* box1 = box0 + tg.box_cap + 8;      // +8 elements: the two copies sit on disjoint LDS banks
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int yy = lane >> 3, xx = lane & 7;
+    const T* __restrict__ in = reinterpret_cast<const T*>(v.in);
+    T* out = reinterpret_cast<T*>(v.out);
+
+    for (int ti = 0; ti < sp.ntile; ++ti) {
+        const int o0[3] = {sp.tz * kT, sp.ty * kT, (sp.tx0 + ti) * kT};
+        int* red = sred + (ti & 1) * 8;
+
+        // ---- phase A: coordinates of this thread's two voxels ----------------------------------
+        int start[2][3];
+        T frac[2][3];
+        bool valid[2], constant[2];
+        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int zi = wave + 4 * i;
             const int o[3] = {o0[0] + zi, o0[1] + yy, o0[2] + xx};
             valid[i] = o[0] < tg.out_len[0] && o[1] < tg.out_len[1] && o[2] < tg.out_len[2];
-            bool cst = false;
+            if (tg.dbg & 4) {
+                constant[i] = false;
 #pragma unroll
-            for (int h = 0; h < 3; ++h) {
-                const double* qrow = sQ + ((zi * kT + yy) * 3 + h) * ncpx;
-                double d = 0.0;
-#pragma unroll
-                for (int l = 0; l < 4; ++l)
-                    d += tx_.w[l] * qrow[tx_.idx[l]];
-                double c;
-                if (g.has_affine) {
-                    c = g.affine[h * 4 + 3];
-#pragma unroll
-                    for (int l = 0; l < 3; ++l)
-                        c += g.affine[h * 4 + l] * (double)o[l];
-                } else {
-                    c = (double)o[h];
+                for (int h = 0; h < 3; ++h) {
+                    start[i][h] = min(max(o[h] - 1, 0), tg.in_len[h] - 4);
+                    frac[i][h] = (T)0.5;
                 }
-                c = map_coordinate(c + (double)g.off[h] + d, g.in_len[h], v.mode);
-                const bool bad = !(c > -1.0);
-                cst = cst || bad;
-                const double fl = floor((ORDER & 1) ? c : c + 0.5);
-                start[i][h] = bad ? 0 : (int)fl - ORDER / 2;
-                frac[i][h] = (T)(c - fl);
-            }
-            constant[i] = cst;
-            if (valid[i] && !cst) {
+            } else
+            constant[i] = voxel_coords<T, ORDER>(g, v.mode, sQ, tg.lg_nx, tabx[ti * kT + xx], zi, yy,
+                                                 o, start[i], frac[i]);
+            if (valid[i] && !constant[i]) {
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
                     lo[h] = min(lo[h], start[i][h]);
@@ -307,161 +385,355 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                 }
             }
         }
-    }
-
-    // ---- phase B: bounding box of the tile's tap windows ------------------------------------------
+        // ---- phase B: bounding box of the tile's tap windows -----------------------------------
 #pragma unroll
-    for (int h = 0; h < 3; ++h) {
-        const int l = wave_min(lo[h]);
-        const int u = wave_max(hi[h]);
-        if (lane == 0) {
-            atomicMin(&sred[h], l);
-            atomicMax(&sred[3 + h], u);
-        }
-    }
-    __syncthreads();      // also: every read of Q is done, the overlay may become the box
-    const int b0[3] = {sred[0], sred[1], sred[2]};
-    const int ext[3] = {sred[3] - sred[0] + 1, sred[4] - sred[1] + 1, sred[5] - sred[2] + 1};
-    const bool any = sred[3] >= sred[0];
-    // row pitch: PAIR (ds_read_b64): 16 * odd puts 4 consecutive rows on 4 disjoint bank groups;
-    // b32 / f64 reads: 8 or 24 (mod 32)
-    int pitch;
-    if (PAIR)
-        pitch = ext[2] <= 16 ? 16 : (ext[2] <= 48 ? 48 : 0);
-    else
-        pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 56 ? 56 : 0));
-    const int by = ext[1];
-    const int nrows = ext[0] * by;
-    const bool fits = any && pitch > 0 && (int64_t)nrows * pitch <= tg.box_cap;
-    if (any && !fits) {
-        // hand the whole tile to the spill kernel
-        if (tid == 0) {
-            const int slot = atomicAdd(&tg.spill[0], 1);
-            tg.spill[1 + slot] = tile;
-        }
-        return;
-    }
-    const bool x_inside = b0[2] >= 0 && b0[2] + ext[2] <= tg.in_len[2];
-
-    const T* __restrict__ in = reinterpret_cast<const T*>(v.in);
-    T* out = reinterpret_cast<T*>(v.out);
-
-    for (int64_t ss = 0; ss < v.nsteps; ++ss) {
-        int64_t in_off = 0, out_off = 0;
-        {
-            int64_t r = ss;
-            for (int l = 0; l < v.nstep; ++l) {
-                const int64_t q = r / v.step_len[l];
-                const int64_t c = r - q * v.step_len[l];
-                in_off += v.in_step_stride[l] * c;
-                out_off += v.out_step_stride[l] * c;
-                r = q;
+        for (int h = 0; h < 3; ++h) {
+            const int l = wave_min(lo[h]);
+            const int u = wave_max(hi[h]);
+            if (lane == 0) {
+                atomicMin(&red[h], l);
+                atomicMax(&red[3 + h], u);
             }
         }
-        const T* src = in + in_off;
-
-        if (any) {
-            // ---- phase C: stage the source box (mirror-mapped) into LDS ---------------------------
-            if (ss > 0)
-                __syncthreads();     // previous step's gathers are done with the box
-            const int sub = tid & 7;
-            for (int r = tid >> 3; r < nrows; r += kBlock / 8) {
-                const int zr = r / by, yr = r - zr * by;
-                const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
-                const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
-                const T* rowp = src + (int64_t)zs * tg.in_stride[0] + (int64_t)ys * tg.in_stride[1];
-                T* d0 = box0 + r * pitch;
-                T* d1 = box1 + r * pitch;
-                for (int xi = sub; xi < ext[2]; xi += 8) {
-                    const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
-                    const T val = rowp[(int64_t)xs * tg.in_stride[2]];
-                    d0[xi] = val;
-                    if (PAIR && xi > 0)
-                        d1[xi - 1] = val;
-                }
+        __syncthreads();   // B1: box known; every gather of the previous tile is done
+        const int b0[3] = {red[0], red[1], red[2]};
+        const int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
+        const bool any = red[3] >= red[0];
+        if (tid < 6)       // re-arm the other buffer for the next tile
+            sred[((ti + 1) & 1) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
+        // row pitch: PAIR (ds_read_b64): 16 * odd puts 4 consecutive rows on 4 disjoint bank
+        // groups; b32 / f64 reads: 8 or 24 (mod 32)
+        int pitch;
+        if (PAIR)
+            pitch = ext[2] <= 16 ? 16 : (ext[2] <= 48 ? 48 : 0);
+        else
+            pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 56 ? 56 : 0));
+        const int by = ext[1];
+        const int nrows = ext[0] * by;
+        const bool fits = pitch > 0 && (int64_t)nrows * pitch <= tg.box_cap;
+        if (any && !fits) {
+            if (tid == 0) {    // hand the whole tile to the spill kernel
+                const int slot = atomicAdd(&tg.spill[0], 1);
+                tg.spill[1 + slot] = (sp.tz * tg.tiles[1] + sp.ty) * tg.tiles[2] + sp.tx0 + ti;
             }
-            __syncthreads();
+            continue;
         }
+        const bool x_inside = b0[2] >= 0 && b0[2] + ext[2] <= tg.in_len[2];
+        const float inv_by = 1.0f / (float)by;
 
-        // ---- phase D: gather ------------------------------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (!valid[i])
-                continue;
-            T val;
-            if (constant[i]) {
-                val = (T)v.cval;
-            } else {
-                T w0[NT], w1[NT], w2[NT];
-                weights_from_frac<T, ORDER>(frac[i][0], w0);
-                weights_from_frac<T, ORDER>(frac[i][1], w1);
-                weights_from_frac<T, ORDER>(frac[i][2], w2);
-                const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1],
-                          rx = start[i][2] - b0[2];
-                const int rowbase = (rz * by + ry) * pitch;
-                T a0 = 0;
-                if (PAIR) {
-                    // consecutive x-taps as aligned 8-byte reads from the copy whose shift matches
-                    // the parity of rx
-                    const T* bp = (rx & 1) ? box1 + rowbase + rx - 1 : box0 + rowbase + rx;
-#pragma unroll
-                    for (int l0 = 0; l0 < NT; ++l0) {
-                        T a1 = 0;
-#pragma unroll
-                        for (int l1 = 0; l1 < NT; ++l1) {
-                            const T* rp = bp + (l0 * by + l1) * pitch;
-                            T a2 = 0;
-#pragma unroll
-                            for (int l2 = 0; l2 < NT; l2 += 2) {
-                                const float2 pr = *reinterpret_cast<const float2*>(rp + l2);
-                                a2 += w2[l2] * pr.x;
-                                a2 += w2[l2 + 1] * pr.y;
-                            }
-                            a1 += w1[l1] * a2;
-                        }
-                        a0 += w0[l0] * a1;
+        for (int64_t ss = 0; ss < v.nsteps; ++ss) {
+            int64_t in_off, out_off;
+            step_offsets(v, ss, in_off, out_off);
+            const T* src = in + in_off;
+
+            if (any) {
+                // ---- phase C: stage the source box (mirror-mapped) into LDS ----------------------
+                if (ss > 0)
+                    __syncthreads();     // previous step's gathers are done with the box
+                const int sub = tid & 7;
+                for (int r = tid >> 3; r < nrows; r += kBlock / 8) {
+                    const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                    const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
+                    const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
+                    const T* rowp = src + (int64_t)zs * tg.in_stride[0] +
+                                    (int64_t)ys * tg.in_stride[1];
+                    T* d0 = box0 + r * pitch;
+                    T* d1 = box1 + r * pitch;
+                    for (int xi = sub; xi < ext[2]; xi += 8) {
+                        const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
+                        const T val = (tg.dbg & 1) ? (T)xs : rowp[(int64_t)xs * tg.in_stride[2]];
+                        d0[xi] = val;
+                        if (PAIR && xi > 0)
+                            d1[xi - 1] = val;
                     }
+                }
+                __syncthreads();         // B2
+            }
+
+            // ---- phase D: gather -------------------------------------------------------------------
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!valid[i])
+                    continue;
+                T val;
+                if (constant[i]) {
+                    val = (T)v.cval;
+                } else if (tg.dbg & 2) {
+                    val = frac[i][0] + frac[i][1] + frac[i][2] + (T)start[i][0];
                 } else {
-                    const T* bp = box0 + rowbase + rx;
+                    T w0[NT], w1[NT], w2[NT];
+                    weights_from_frac<T, ORDER>(frac[i][0], w0);
+                    weights_from_frac<T, ORDER>(frac[i][1], w1);
+                    weights_from_frac<T, ORDER>(frac[i][2], w2);
+                    const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1],
+                              rx = start[i][2] - b0[2];
+                    const int rowbase = (rz * by + ry) * pitch;
+                    T a0 = 0;
+                    if (PAIR) {
+                        // consecutive x-taps as aligned 8-byte reads from the copy whose shift
+                        // matches the parity of rx
+                        const T* bp = (rx & 1) ? box1 + rowbase + rx - 1 : box0 + rowbase + rx;
 #pragma unroll
-                    for (int l0 = 0; l0 < NT; ++l0) {
-                        T a1 = 0;
+                        for (int l0 = 0; l0 < NT; ++l0) {
+                            T a1 = 0;
 #pragma unroll
-                        for (int l1 = 0; l1 < NT; ++l1) {
-                            const T* rp = bp + (l0 * by + l1) * pitch;
-                            T a2 = 0;
+                            for (int l1 = 0; l1 < NT; ++l1) {
+                                const T* rp = bp + (l0 * by + l1) * pitch;
+                                T a2 = 0;
 #pragma unroll
-                            for (int l2 = 0; l2 < NT; ++l2)
-                                a2 += w2[l2] * rp[l2];
-                            a1 += w1[l1] * a2;
+                                for (int l2 = 0; l2 < NT; l2 += 2) {
+                                    const float2 pr = *reinterpret_cast<const float2*>(rp + l2);
+                                    a2 += w2[l2] * pr.x;
+                                    a2 += w2[l2 + 1] * pr.y;
+                                }
+                                a1 += w1[l1] * a2;
+                            }
+                            a0 += w0[l0] * a1;
                         }
-                        a0 += w0[l0] * a1;
+                    } else {
+                        const T* bp = box0 + rowbase + rx;
+#pragma unroll
+                        for (int l0 = 0; l0 < NT; ++l0) {
+                            T a1 = 0;
+#pragma unroll
+                            for (int l1 = 0; l1 < NT; ++l1) {
+                                const T* rp = bp + (l0 * by + l1) * pitch;
+                                T a2 = 0;
+#pragma unroll
+                                for (int l2 = 0; l2 < NT; ++l2)
+                                    a2 += w2[l2] * rp[l2];
+                                a1 += w1[l1] * a2;
+                            }
+                            a0 += w0[l0] * a1;
+                        }
                     }
+                    val = a0;
                 }
-                val = a0;
+                const int oz = o0[0] + wave + 4 * i, oy = o0[1] + yy, ox = o0[2] + xx;
+                out[out_off + (int64_t)oz * tg.out_stride[0] + (int64_t)oy * tg.out_stride[1] +
+                    (int64_t)ox * tg.out_stride[2]] = val;
             }
-            const int oz = o0[0] + wave + 4 * i, oy = o0[1] + yy, ox = o0[2] + xx;
-            out[out_off + (int64_t)oz * tg.out_stride[0] + (int64_t)oy * tg.out_stride[1] +
-                (int64_t)ox * tg.out_stride[2]] = val;
         }
     }
 }
 
-// Tiles that did not fit in LDS: one thread per voxel, taps straight from global memory with the
-// per-tap mirror map of deform.c:791-813; displacement by the direct 64-tap sum (deform.c:693-758).
-template <typename T, int ORDER>
+// ================================================================================================
+// K2: gradient (float32): integer LDS accumulation per tile, float atomics to flush
+// ================================================================================================
+template <int ORDER>
+__global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const GridGeom g,
+                                                                      const IOView v,
+                                                                      const TileGeom tg)
+{
+    constexpr int NT = ORDER + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StripPos sp;
+    if (!strip_position(tg, sp))
+        return;
+    strip_prologue(g, tg, sp, smem);
+
+    const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
+    int* sred = reinterpret_cast<int*>(smem + kOffRed);
+    const double* sQ = reinterpret_cast<const double*>(smem + kOffQ);
+    int* box = reinterpret_cast<int*>(smem + tg.off_ov);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int yy = lane >> 3, xx = lane & 7;
+    float* dx = reinterpret_cast<float*>(const_cast<char*>(v.in));      // accumulated into
+    const float* __restrict__ dy = reinterpret_cast<const float*>(v.out);
+    int phase = 0;      // parity of the gmax slot
+
+    for (int ti = 0; ti < sp.ntile; ++ti) {
+        const int o0[3] = {sp.tz * kT, sp.ty * kT, (sp.tx0 + ti) * kT};
+        int* red = sred + (ti & 1) * 8;
+
+        int start[2][3];
+        float frac[2][3];
+        bool active[2];
+        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+        int64_t ooff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int zi = wave + 4 * i;
+            const int o[3] = {o0[0] + zi, o0[1] + yy, o0[2] + xx};
+            const bool valid = o[0] < tg.out_len[0] && o[1] < tg.out_len[1] && o[2] < tg.out_len[2];
+            const bool cst = voxel_coords<float, ORDER>(g, v.mode, sQ, tg.lg_nx, tabx[ti * kT + xx],
+                                                        zi, yy, o, start[i], frac[i]);
+            active[i] = valid && !cst;       // constant-mapped voxels contribute nothing (:928)
+            ooff[i] = (int64_t)o[0] * tg.out_stride[0] + (int64_t)o[1] * tg.out_stride[1] +
+                      (int64_t)o[2] * tg.out_stride[2];
+            if (active[i]) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    lo[h] = min(lo[h], start[i][h]);
+                    hi[h] = max(hi[h], start[i][h] + ORDER);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const int l = wave_min(lo[h]);
+            const int u = wave_max(hi[h]);
+            if (lane == 0) {
+                atomicMin(&red[h], l);
+                atomicMax(&red[3 + h], u);
+            }
+        }
+        __syncthreads();   // B1: box known; the previous tile's flush is done
+        const int b0[3] = {red[0], red[1], red[2]};
+        const int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
+        const bool any = red[3] >= red[0];
+        if (tid < 6)
+            sred[((ti + 1) & 1) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
+        if (!any)
+            continue;      // nothing to scatter (uniform)
+        const int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 56 ? 56 : 0));
+        const int by = ext[1];
+        const int nrows = ext[0] * by;
+        const int nbox = nrows * pitch;
+        const bool fits = pitch > 0 && nbox <= tg.box_cap;
+        if (!fits) {
+            if (tid == 0) {
+                const int slot = atomicAdd(&tg.spill[0], 1);
+                tg.spill[1 + slot] = (sp.tz * tg.tiles[1] + sp.ty) * tg.tiles[2] + sp.tx0 + ti;
+            }
+            continue;
+        }
+        const bool x_inside = b0[2] >= 0 && b0[2] + ext[2] <= tg.in_len[2];
+        const float inv_by = 1.0f / (float)by;
+
+        for (int64_t ss = 0; ss < v.nsteps; ++ss, ++phase) {
+            int64_t in_off, out_off;
+            step_offsets(v, ss, in_off, out_off);
+            if (ss > 0)
+                __syncthreads();         // previous step's flush is done with the box
+            // zero the accumulators; tile maximum of |dY|
+            for (int e = tid * 4; e < nbox; e += kBlock * 4)
+                *reinterpret_cast<int4*>(box + e) = make_int4(0, 0, 0, 0);
+            float gval[2];
+            float gm = 0.f;
+            float* dst = dx + in_off;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                gval[i] = active[i] ? dy[out_off + ooff[i]] : 0.f;
+                if ((__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000) {
+                    // inf / NaN gradient: no fixed-point scale exists -- this voxel scatters its
+                    // taps with float atomics straight to global memory (rare, rolled loops)
+                    float w0[NT], w1[NT], w2[NT];
+                    weights_from_frac<float, ORDER>(frac[i][0], w0);
+                    weights_from_frac<float, ORDER>(frac[i][1], w1);
+                    weights_from_frac<float, ORDER>(frac[i][2], w2);
+#pragma unroll 1
+                    for (int t = 0; t < NT * NT * NT; ++t) {
+                        const int l0 = t / (NT * NT), l1 = (t / NT) % NT, l2 = t % NT;
+                        const int zs = mirror_i32(start[i][0] + l0, tg.in_len[0]);
+                        const int ys = mirror_i32(start[i][1] + l1, tg.in_len[1]);
+                        const int xs = mirror_i32(start[i][2] + l2, tg.in_len[2]);
+                        float wp = w0[0], wq = w1[0], wr = w2[0];
+#pragma unroll
+                        for (int l = 1; l < NT; ++l) {
+                            wp = l0 == l ? w0[l] : wp;
+                            wq = l1 == l ? w1[l] : wq;
+                            wr = l2 == l ? w2[l] : wr;
+                        }
+                        unsafeAtomicAdd(dst + (int64_t)zs * tg.in_stride[0] + (int64_t)ys * tg.in_stride[1] +
+                                            (int64_t)xs * tg.in_stride[2],
+                                        gval[i] * wp * wq * wr);
+                    }
+                    gval[i] = 0.f;
+                }
+                gm += fabsf(gval[i]);
+            }
+            // sum of |dY| over the tile: wave reduce, one slot per wave, combined after the barrier
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+                gm += __shfl_xor(gm, m, 64);
+            float* gsum = reinterpret_cast<float*>(smem + kOffSum) + (phase & 1) * 4;
+            if (lane == 0)
+                gsum[wave] = gm;
+            __syncthreads();             // B2: box zeroed, sum known
+            const float gtot = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
+            if (gtot == 0.f)
+                continue;                // all-zero gradient tile (uniform)
+            // fixed-point scale.  Rigorous bound on what can land in one accumulator:
+            //   |sum| <= max tap weight * sum over the tile's voxels of |dY|   (+ 1/2 per rounding)
+            // so scale = (2^31 - 2^10) / (wmax * sum|dY|) cannot overflow an int32; for white-noise
+            // dY that is a resolution of ~3e-8 of max|dY| per contribution -- the level of the
+            // float32 rounding in the reference's own `+=` (deform.c:309-312).
+            constexpr float kWmax = ORDER == 2 ? 0.4219f : (ORDER == 3 ? 0.2963f
+                                    : (ORDER == 4 ? 0.2150f : 0.1664f));
+            const float scale = (2147483648.0f - 1024.0f) / (kWmax * 1.001f * gtot);
+            const float inv_scale = 1.0f / scale;
+
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!active[i] || gval[i] == 0.f)
+                    continue;
+                float w0[NT], w1[NT], w2[NT];
+                weights_from_frac<float, ORDER>(frac[i][0], w0);
+                weights_from_frac<float, ORDER>(frac[i][1], w1);
+                weights_from_frac<float, ORDER>(frac[i][2], w2);
+                const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1],
+                          rx = start[i][2] - b0[2];
+                int* bp = box + (rz * by + ry) * pitch + rx;
+                const float gs = gval[i] * scale;
+#pragma unroll
+                for (int l0 = 0; l0 < NT; ++l0) {
+                    const float g0 = gs * w0[l0];
+#pragma unroll
+                    for (int l1 = 0; l1 < NT; ++l1) {
+                        const float g1 = g0 * w1[l1];
+                        int* rp = bp + (l0 * by + l1) * pitch;
+#pragma unroll
+                        for (int l2 = 0; l2 < NT; ++l2)
+                            atomicAdd(rp + l2, __float2int_rn(g1 * w2[l2]));
+                    }
+                }
+            }
+            __syncthreads();             // B3: all contributions are in
+            // flush: one float atomic per touched source element, mirror-mapped (deform.c:791-813)
+            const int sub = tid & 7;
+            for (int r = tid >> 3; r < nrows; r += kBlock / 8) {
+                const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
+                const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
+                float* rowp = dst + (int64_t)zs * tg.in_stride[0] + (int64_t)ys * tg.in_stride[1];
+                const int* brow = box + r * pitch;
+                for (int xi = sub; xi < ext[2]; xi += 8) {
+                    const int acc = brow[xi];
+                    if (acc != 0) {
+                        const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
+                        unsafeAtomicAdd(rowp + (int64_t)xs * tg.in_stride[2], (float)acc * inv_scale);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// spill kernels: tiles that did not fit in LDS, one thread per voxel, straight from global memory;
+// displacement by the direct 64-tap sum (deform.c:693-758), taps with the per-tap mirror map
+// ================================================================================================
+template <typename T, int ORDER, bool GRAD>
 __global__ __launch_bounds__(kBlock) void deform_tile3_spill_kernel(const GridGeom g, const IOView v,
                                                                     const TileGeom tg)
 {
     constexpr int NT = ORDER + 1;
     const int nspill = tg.spill[0];
-    const T* __restrict__ in = reinterpret_cast<const T*>(v.in);
-    T* out = reinterpret_cast<T*>(v.out);
+    T* inp = reinterpret_cast<T*>(const_cast<char*>(v.in));
+    T* outp = reinterpret_cast<T*>(v.out);
     for (int s = blockIdx.x; s < nspill; s += gridDim.x) {
-        int o0[3];
-        tile_origin(tg, tg.spill[1 + s], o0);
+        int t = tg.spill[1 + s];
+        const int tx = t % tg.tiles[2];
+        t /= tg.tiles[2];
+        const int ty = t % tg.tiles[1];
+        const int tz = t / tg.tiles[1];
         for (int vox = threadIdx.x; vox < kT * kT * kT; vox += kBlock) {
-            const int o[3] = {o0[0] + (vox >> 6), o0[1] + ((vox >> 3) & 7), o0[2] + (vox & 7)};
+            const int o[3] = {tz * kT + (vox >> 6), ty * kT + ((vox >> 3) & 7), tx * kT + (vox & 7)};
             if (o[0] >= tg.out_len[0] || o[1] >= tg.out_len[1] || o[2] >= tg.out_len[2])
                 continue;
             double dw[3][4];
@@ -483,8 +755,8 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_spill_kernel(const GridGe
             for (int h = 0; h < 3; ++h) {
                 const char* base = g.disp + g.disp_stride[0] * h;
                 double d = 0.0;
-                for (int t = 0; t < 64; ++t) {
-                    const int l0 = t >> 4, l1 = (t >> 2) & 3, l2 = t & 3;
+                for (int t2 = 0; t2 < 64; ++t2) {
+                    const int l0 = t2 >> 4, l1 = (t2 >> 2) & 3, l2 = t2 & 3;
                     d += load_as_double(base + dtap[0][l0] + dtap[1][l1] + dtap[2][l2], g.disp_dtype) *
                          dw[0][l0] * dw[1][l1] * dw[2][l2];
                 }
@@ -507,89 +779,116 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_spill_kernel(const GridGe
             const int64_t obase = (int64_t)o[0] * tg.out_stride[0] + (int64_t)o[1] * tg.out_stride[1] +
                                   (int64_t)o[2] * tg.out_stride[2];
             for (int64_t ss = 0; ss < v.nsteps; ++ss) {
-                int64_t in_off = 0, out_off = 0, r = ss;
-                for (int l = 0; l < v.nstep; ++l) {
-                    const int64_t q = r / v.step_len[l];
-                    const int64_t c = r - q * v.step_len[l];
-                    in_off += v.in_step_stride[l] * c;
-                    out_off += v.out_step_stride[l] * c;
-                    r = q;
-                }
-                T val;
-                if (cst) {
-                    val = (T)v.cval;
-                } else {
-                    const T* src = in + in_off;
-                    T a0 = 0;
+                int64_t in_off, out_off;
+                step_offsets(v, ss, in_off, out_off);
+                T* src = inp + in_off;
+                if (!GRAD) {
+                    T val;
+                    if (cst) {
+                        val = (T)v.cval;
+                    } else {
+                        T a0 = 0;
+                        for (int l0 = 0; l0 < NT; ++l0) {
+                            const T* p0 = src + (int64_t)mirror_i32(start[0] + l0, tg.in_len[0]) * tg.in_stride[0];
+                            T a1 = 0;
+                            for (int l1 = 0; l1 < NT; ++l1) {
+                                const T* p1 = p0 + (int64_t)mirror_i32(start[1] + l1, tg.in_len[1]) * tg.in_stride[1];
+                                T a2 = 0;
+#pragma unroll
+                                for (int l2 = 0; l2 < NT; ++l2)
+                                    a2 += w[2][l2] * p1[(int64_t)mirror_i32(start[2] + l2, tg.in_len[2]) * tg.in_stride[2]];
+                                a1 += w[1][l1] * a2;
+                            }
+                            a0 += w[0][l0] * a1;
+                        }
+                        val = a0;
+                    }
+                    outp[out_off + obase] = val;
+                } else if (!cst) {
+                    const T grad = outp[out_off + obase];
                     for (int l0 = 0; l0 < NT; ++l0) {
-                        const T* p0 = src + (int64_t)mirror_i32(start[0] + l0, tg.in_len[0]) * tg.in_stride[0];
-                        T a1 = 0;
+                        T* p0 = src + (int64_t)mirror_i32(start[0] + l0, tg.in_len[0]) * tg.in_stride[0];
+                        const T g0 = grad * w[0][l0];
                         for (int l1 = 0; l1 < NT; ++l1) {
-                            const T* p1 = p0 + (int64_t)mirror_i32(start[1] + l1, tg.in_len[1]) * tg.in_stride[1];
-                            T a2 = 0;
+                            T* p1 = p0 + (int64_t)mirror_i32(start[1] + l1, tg.in_len[1]) * tg.in_stride[1];
+                            const T g1 = g0 * w[1][l1];
 #pragma unroll
                             for (int l2 = 0; l2 < NT; ++l2)
-                                a2 += w[2][l2] * p1[(int64_t)mirror_i32(start[2] + l2, tg.in_len[2]) * tg.in_stride[2]];
-                            a1 += w[1][l1] * a2;
+                                unsafeAtomicAdd(p1 + (int64_t)mirror_i32(start[2] + l2, tg.in_len[2]) * tg.in_stride[2],
+                                                g1 * w[2][l2]);
                         }
-                        a0 += w[0][l0] * a1;
                     }
-                    val = a0;
                 }
-                out[out_off + obase] = val;
             }
         }
     }
 }
 
-inline size_t dpq_bytes(const GridGeom& g)
+// ---- host side -------------------------------------------------------------------------------------
+
+inline int ceil_log2(int64_t n)
 {
-    const size_t nyx = (size_t)g.ncp[1] * g.ncp[2];
-    return 8 * (3 * (size_t)g.ncp[0] * nyx + kT * 3 * nyx + (size_t)kT * kT * 3 * g.ncp[2]);
+    int l = 0;
+    while (((int64_t)1 << l) < n)
+        ++l;
+    return l;
 }
 
-template <bool PAIR, typename T>
-constexpr int box_cap()
+inline size_t dp_bytes(const GridGeom& g)
 {
-    return PAIR ? 4096 : (sizeof(T) == 4 ? 6144 : 4096);
+    const int lgp = ceil_log2(g.ncp[1] * g.ncp[2]);
+    return 8 * (((size_t)3 * g.ncp[0] + kT * 3) << lgp);
 }
-template <bool PAIR, typename T>
-constexpr size_t box_bytes()
-{
-    return (PAIR ? 2 * (size_t)box_cap<PAIR, T>() + 8 : (size_t)box_cap<PAIR, T>()) * sizeof(T);
-}
+inline size_t q_bytes(const GridGeom& g) { return 8 * ((size_t)(kT * kT * 3) << ceil_log2(g.ncp[2])); }
 
-template <typename T, int ORDER, bool PAIR>
+template <typename T, int ORDER, bool PAIR, bool GRAD>
 hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
 {
     TileGeom tg;
     IOView ve = v;
-    int64_t ntiles = 1;
     for (int k = 0; k < 3; ++k) {
         tg.in_len[k] = (int)g.in_len[k];
         tg.out_len[k] = (int)g.out_len[k];
         tg.tiles[k] = (int)((g.out_len[k] + kT - 1) / kT);
         tg.in_stride[k] = v.in_stride[k] / (int64_t)sizeof(T);
         tg.out_stride[k] = v.out_stride[k] / (int64_t)sizeof(T);
-        ntiles *= tg.tiles[k];
     }
     for (int l = 0; l < v.nstep; ++l) {
         ve.in_step_stride[l] = v.in_step_stride[l] / (int64_t)sizeof(T);
         ve.out_step_stride[l] = v.out_step_stride[l] / (int64_t)sizeof(T);
     }
-    if (ntiles <= 0)
+    tg.strips_x = (tg.tiles[2] + kStrip - 1) / kStrip;
+    const int64_t nstrips = (int64_t)tg.tiles[0] * tg.tiles[1] * tg.strips_x;
+    const int64_t ntiles = (int64_t)tg.tiles[0] * tg.tiles[1] * tg.tiles[2];
+    if (nstrips <= 0)
         return hipSuccess;
     if (ntiles > 0x3fffffffLL)
         return hipErrorInvalidValue;
-    tg.ntiles = (int)ntiles;
-    tg.box_cap = box_cap<PAIR, T>();
-    size_t overlay = box_bytes<PAIR, T>();
-    if (dpq_bytes(g) > overlay)
-        overlay = dpq_bytes(g);
+    tg.nstrips = (int)nstrips;
+    tg.lg_nyx = ceil_log2(g.ncp[1] * g.ncp[2]);
+    tg.lg_nx = ceil_log2(g.ncp[2]);
+    // LDS: head | Q | overlay (box | D, P).  K1 float32 odd orders: two shifted copies of 4096
+    // elements; otherwise one copy (6144 x 4 bytes or 4096 x 8 bytes)
+    size_t box;
+    if (GRAD) {
+        tg.box_cap = 6144;
+        box = 6144 * 4;
+    } else if (PAIR) {
+        tg.box_cap = 4096;
+        box = (2 * 4096 + 8) * sizeof(T);
+    } else {
+        tg.box_cap = sizeof(T) == 4 ? 6144 : 4096;
+        box = (size_t)tg.box_cap * sizeof(T);
+    }
+    size_t overlay = box > dp_bytes(g) ? box : dp_bytes(g);
     overlay = (overlay + 15) & ~(size_t)15;
-    tg.overlay_bytes = (int)overlay;
-    const size_t lds = kHeadBytes + overlay;
+    tg.off_ov = (int)(kOffQ + ((q_bytes(g) + 15) & ~(size_t)15));
+    const size_t lds = tg.off_ov + overlay;
 
+    {
+        const char* dbg = getenv("EDHIP_TILE_DBG");
+        tg.dbg = dbg ? atoi(dbg) : 0;
+    }
     // spill worklist: stream-ordered scratch, counter zeroed on the stream
     void* spill = nullptr;
     hipError_t e = hipMallocAsync(&spill, sizeof(int) * ((size_t)ntiles + 1), stream);
@@ -598,15 +897,19 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     tg.spill = (int*)spill;
     e = hipMemsetAsync(spill, 0, sizeof(int), stream);
     if (e == hipSuccess) {
-        const unsigned nblk = (unsigned)(((ntiles + 7) / 8) * 8);
-        hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR>), dim3(nblk), dim3(kBlock), lds,
-                           stream, g, ve, tg);
+        const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
+        if (GRAD)
+            hipLaunchKernelGGL((deform_tile3_grad_kernel<ORDER>), dim3(nblk), dim3(kBlock), lds,
+                               stream, g, ve, tg);
+        else
+            hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR>), dim3(nblk), dim3(kBlock),
+                               lds, stream, g, ve, tg);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
         const unsigned nsp = (unsigned)(ntiles < 2048 ? ntiles : 2048);
-        hipLaunchKernelGGL((deform_tile3_spill_kernel<T, ORDER>), dim3(nsp), dim3(kBlock), 0, stream,
-                           g, ve, tg);
+        hipLaunchKernelGGL((deform_tile3_spill_kernel<T, ORDER, GRAD>), dim3(nsp), dim3(kBlock), 0,
+                           stream, g, ve, tg);
         e = hipGetLastError();
     }
     const hipError_t e2 = hipFreeAsync(spill, stream);
@@ -617,15 +920,17 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
 
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
 {
-    if (gradient || g.naxis != 3 || v.order < 2)
+    if (g.naxis != 3 || v.order < 2)
+        return false;
+    if (gradient && v.in_dtype != EDHIP_F32)
         return false;
     if (!deform_fast_supported(g, v, gradient))
         return false;
     for (int k = 0; k < 3; ++k)
-        if (g.in_len[k] >= 0x3fffffff || g.out_len[k] >= 0x3fffffff || g.ncp[k] > 4096)
+        if (g.in_len[k] >= 0x3fffffff || g.out_len[k] >= 0x3fffffff || g.ncp[k] > 1024)
             return false;
-    // D + P + Q live in the LDS region that later holds the source box; keep the block <= 48 KiB
-    if (dpq_bytes(g) > (size_t)47 * 1024)
+    // head + Q + max(box, D + P) must stay within a 64 KiB block
+    if (kOffQ + q_bytes(g) + 16 + (dp_bytes(g) > 32800 ? dp_bytes(g) : 32800) > (size_t)64 * 1024)
         return false;
     return true;
 }
@@ -634,20 +939,29 @@ hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, 
 {
     if (!deform_tile_supported(g, v, gradient))
         return hipErrorNotSupported;
+    if (gradient) {
+        switch (v.order) {
+        case 2: return launch_tile<float, 2, false, true>(g, v, stream);
+        case 3: return launch_tile<float, 3, false, true>(g, v, stream);
+        case 4: return launch_tile<float, 4, false, true>(g, v, stream);
+        case 5: return launch_tile<float, 5, false, true>(g, v, stream);
+        default: return hipErrorNotSupported;
+        }
+    }
     if (v.in_dtype == EDHIP_F32) {
         switch (v.order) {
-        case 2: return launch_tile<float, 2, false>(g, v, stream);
-        case 3: return launch_tile<float, 3, true>(g, v, stream);
-        case 4: return launch_tile<float, 4, false>(g, v, stream);
-        case 5: return launch_tile<float, 5, true>(g, v, stream);
+        case 2: return launch_tile<float, 2, false, false>(g, v, stream);
+        case 3: return launch_tile<float, 3, true, false>(g, v, stream);
+        case 4: return launch_tile<float, 4, false, false>(g, v, stream);
+        case 5: return launch_tile<float, 5, true, false>(g, v, stream);
         default: return hipErrorNotSupported;
         }
     }
     switch (v.order) {
-    case 2: return launch_tile<double, 2, false>(g, v, stream);
-    case 3: return launch_tile<double, 3, false>(g, v, stream);
-    case 4: return launch_tile<double, 4, false>(g, v, stream);
-    case 5: return launch_tile<double, 5, false>(g, v, stream);
+    case 2: return launch_tile<double, 2, false, false>(g, v, stream);
+    case 3: return launch_tile<double, 3, false, false>(g, v, stream);
+    case 4: return launch_tile<double, 4, false, false>(g, v, stream);
+    case 5: return launch_tile<double, 5, false, false>(g, v, stream);
     default: return hipErrorNotSupported;
     }
 }
