@@ -81,19 +81,108 @@ __device__ __forceinline__ int mirror_i32(int idx, int len)
     return idx;
 }
 
+// Wave-wide min / max / sum without touching LDS: four DPP steps fold each row of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row
+// results meet in scalar registers.  All 64 lanes must be active.
+#define ED_DPP_STEP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
 __device__ __forceinline__ int wave_min(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = min(v, __shfl_xor(v, m, 64));
-    return v;
+    v = min(v, ED_DPP_STEP(v, 0xB1));
+    v = min(v, ED_DPP_STEP(v, 0x4E));
+    v = min(v, ED_DPP_STEP(v, 0x141));
+    v = min(v, ED_DPP_STEP(v, 0x140));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = max(v, __shfl_xor(v, m, 64));
-    return v;
+    v = max(v, ED_DPP_STEP(v, 0xB1));
+    v = max(v, ED_DPP_STEP(v, 0x4E));
+    v = max(v, ED_DPP_STEP(v, 0x141));
+    v = max(v, ED_DPP_STEP(v, 0x140));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ float wave_sum(float f)
+{
+    f += __int_as_float(ED_DPP_STEP(__float_as_int(f), 0xB1));
+    f += __int_as_float(ED_DPP_STEP(__float_as_int(f), 0x4E));
+    f += __int_as_float(ED_DPP_STEP(__float_as_int(f), 0x141));
+    f += __int_as_float(ED_DPP_STEP(__float_as_int(f), 0x140));
+    const int v = __float_as_int(f);
+    return (__int_as_float(__builtin_amdgcn_readlane(v, 0)) +
+            __int_as_float(__builtin_amdgcn_readlane(v, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(v, 32)) +
+            __int_as_float(__builtin_amdgcn_readlane(v, 48)));
+}
+
+// Boundary map of a real coordinate for the fast kernels: the same piecewise map as deform.c:47-128
+// (legacy SciPy semantics, same branch structure) with the trunc-divisions `(npy_intp)(c / period)`
+// replaced by floor(c * (1 / period)) -- equal as real functions (every argument is positive
+// there), different only in the last ulp of the product, which the fast path does not promise.
+__device__ __forceinline__ double map_coordinate_fast(double c, int len, int mode, double period,
+                                                      double inv_period)
+{
+    const double last = (double)(len - 1);
+    if (c < 0) {
+        switch (mode) {
+        case EDHIP_MODE_MIRROR:
+            if (len <= 1) {
+                c = 0;
+            } else {
+                c = period * floor(-c * inv_period) + c;
+                c = c <= -last ? c + period : -c;
+            }
+            break;
+        case EDHIP_MODE_REFLECT:
+            if (len <= 1) {
+                c = 0;
+            } else {
+                if (c < -period)
+                    c = period * floor(-c * inv_period) + c;
+                c = c < (double)(-len) ? c + period : -c - 1;
+            }
+            break;
+        case EDHIP_MODE_WRAP:
+            if (len <= 1)
+                c = 0;
+            else
+                c += period * (floor(-c * inv_period) + 1);
+            break;
+        case EDHIP_MODE_NEAREST: c = 0; break;
+        default: c = -1; break;   // constant
+        }
+    } else if (c > last) {
+        switch (mode) {
+        case EDHIP_MODE_MIRROR:
+            if (len <= 1) {
+                c = 0;
+            } else {
+                c -= period * floor(c * inv_period);
+                if (c >= (double)len)
+                    c = period - c;
+            }
+            break;
+        case EDHIP_MODE_REFLECT:
+            if (len <= 1) {
+                c = 0;
+            } else {
+                c -= period * floor(c * inv_period);
+                if (c >= (double)len)
+                    c = period - c - 1;
+            }
+            break;
+        case EDHIP_MODE_WRAP:
+            if (len <= 1)
+                c = 0;
+            else
+                c -= period * floor(c * inv_period);
+            break;
+        case EDHIP_MODE_NEAREST: c = last; break;
+        default: c = -1; break;   // constant
+        }
+    }
+    return c;
 }
 
 // B-spline basis weights from the fractional offset, in the data's own width.  Same closed forms
@@ -159,8 +248,14 @@ struct TileGeom {
     int lg_nyx, lg_nx;    // log2 of ncp_y*ncp_x and ncp_x padded to powers of two
     int box_cap;          // elements per LDS copy
     int off_ov;           // LDS byte offset of the overlay region (box | D, P)
-    int64_t in_stride[3];    // element strides
-    int64_t out_stride[3];
+    int in_stride[3];     // element strides (the tile kernels require < 2^31 elements per volume)
+    int out_stride[3];
+    int mode;             // boundary mode of this input
+    int has_affine;
+    int off[3];           // crop offsets
+    double period[3];     // boundary-map period of each axis for `mode`, and its reciprocal
+    double inv_period[3];
+    double affine[12];    // inverse map, 3 x 4
     int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
     int dbg;              // ablation switches for profiling (EDHIP_TILE_DBG), 0 in production
 };
@@ -278,28 +373,28 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const TileGeom
 
 // Phase A for one voxel: displacement from Q, affine, boundary map, window start, fraction.
 template <typename T, int ORDER>
-__device__ __forceinline__ bool voxel_coords(const GridGeom& g, int mode, const double* sQ, int lgx,
-                                             const AxTab& tx_, int zi, int yy, const int* o,
-                                             int* start, T* frac)
+__device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const double* sQ, const AxTab& tx_,
+                                             int zi, int yy, const int* o, int* start, T* frac)
 {
     bool cst = false;
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
-        const double* qrow = sQ + (((zi * kT + yy) * 3 + h) << lgx);
+        const double* qrow = sQ + (((zi * kT + yy) * 3 + h) << tg.lg_nx);
         double d = 0.0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
             d += tx_.w[l] * qrow[tx_.idx[l]];
         double c;
-        if (g.has_affine) {
-            c = g.affine[h * 4 + 3];
+        if (tg.has_affine) {
+            c = tg.affine[h * 4 + 3];
 #pragma unroll
             for (int l = 0; l < 3; ++l)
-                c += g.affine[h * 4 + l] * (double)o[l];
+                c += tg.affine[h * 4 + l] * (double)o[l];
         } else {
             c = (double)o[h];
         }
-        c = map_coordinate(c + (double)g.off[h] + d, g.in_len[h], mode);
+        c = map_coordinate_fast(c + (double)tg.off[h] + d, tg.in_len[h], tg.mode, tg.period[h],
+                                tg.inv_period[h]);
         const bool bad = !(c > -1.0);
         cst = cst || bad;
         const double fl = floor((ORDER & 1) ? c : c + 0.5);
@@ -375,8 +470,8 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
                     frac[i][h] = (T)0.5;
                 }
             } else
-            constant[i] = voxel_coords<T, ORDER>(g, v.mode, sQ, tg.lg_nx, tabx[ti * kT + xx], zi, yy,
-                                                 o, start[i], frac[i]);
+            constant[i] = voxel_coords<T, ORDER>(tg, sQ, tabx[ti * kT + xx], zi, yy, o, start[i],
+                                                 frac[i]);
             if (valid[i] && !constant[i]) {
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
@@ -435,13 +530,12 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
                     const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                     const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
                     const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
-                    const T* rowp = src + (int64_t)zs * tg.in_stride[0] +
-                                    (int64_t)ys * tg.in_stride[1];
+                    const T* rowp = src + (zs * tg.in_stride[0] + ys * tg.in_stride[1]);
                     T* d0 = box0 + r * pitch;
                     T* d1 = box1 + r * pitch;
                     for (int xi = sub; xi < ext[2]; xi += 8) {
                         const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
-                        const T val = (tg.dbg & 1) ? (T)xs : rowp[(int64_t)xs * tg.in_stride[2]];
+                        const T val = (tg.dbg & 1) ? (T)xs : rowp[xs * tg.in_stride[2]];
                         d0[xi] = val;
                         if (PAIR && xi > 0)
                             d1[xi - 1] = val;
@@ -510,8 +604,8 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
                     val = a0;
                 }
                 const int oz = o0[0] + wave + 4 * i, oy = o0[1] + yy, ox = o0[2] + xx;
-                out[out_off + (int64_t)oz * tg.out_stride[0] + (int64_t)oy * tg.out_stride[1] +
-                    (int64_t)ox * tg.out_stride[2]] = val;
+                out[out_off + (oz * tg.out_stride[0] + oy * tg.out_stride[1] + ox * tg.out_stride[2])] =
+                    val;
             }
         }
     }
@@ -554,17 +648,16 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
         bool active[2];
         int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
         int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-        int64_t ooff[2];
+        int ooff[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int zi = wave + 4 * i;
             const int o[3] = {o0[0] + zi, o0[1] + yy, o0[2] + xx};
             const bool valid = o[0] < tg.out_len[0] && o[1] < tg.out_len[1] && o[2] < tg.out_len[2];
-            const bool cst = voxel_coords<float, ORDER>(g, v.mode, sQ, tg.lg_nx, tabx[ti * kT + xx],
-                                                        zi, yy, o, start[i], frac[i]);
+            const bool cst = voxel_coords<float, ORDER>(tg, sQ, tabx[ti * kT + xx], zi, yy, o,
+                                                        start[i], frac[i]);
             active[i] = valid && !cst;       // constant-mapped voxels contribute nothing (:928)
-            ooff[i] = (int64_t)o[0] * tg.out_stride[0] + (int64_t)o[1] * tg.out_stride[1] +
-                      (int64_t)o[2] * tg.out_stride[2];
+            ooff[i] = o[0] * tg.out_stride[0] + o[1] * tg.out_stride[1] + o[2] * tg.out_stride[2];
             if (active[i]) {
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
@@ -639,8 +732,8 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
                             wq = l1 == l ? w1[l] : wq;
                             wr = l2 == l ? w2[l] : wr;
                         }
-                        unsafeAtomicAdd(dst + (int64_t)zs * tg.in_stride[0] + (int64_t)ys * tg.in_stride[1] +
-                                            (int64_t)xs * tg.in_stride[2],
+                        unsafeAtomicAdd(dst + (zs * tg.in_stride[0] + ys * tg.in_stride[1] +
+                                               xs * tg.in_stride[2]),
                                         gval[i] * wp * wq * wr);
                     }
                     gval[i] = 0.f;
@@ -648,9 +741,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
                 gm += fabsf(gval[i]);
             }
             // sum of |dY| over the tile: wave reduce, one slot per wave, combined after the barrier
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1)
-                gm += __shfl_xor(gm, m, 64);
+            gm = wave_sum(gm);
             float* gsum = reinterpret_cast<float*>(smem + kOffSum) + (phase & 1) * 4;
             if (lane == 0)
                 gsum[wave] = gm;
@@ -700,13 +791,13 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
                 const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                 const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
                 const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
-                float* rowp = dst + (int64_t)zs * tg.in_stride[0] + (int64_t)ys * tg.in_stride[1];
+                float* rowp = dst + (zs * tg.in_stride[0] + ys * tg.in_stride[1]);
                 const int* brow = box + r * pitch;
                 for (int xi = sub; xi < ext[2]; xi += 8) {
                     const int acc = brow[xi];
                     if (acc != 0) {
                         const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
-                        unsafeAtomicAdd(rowp + (int64_t)xs * tg.in_stride[2], (float)acc * inv_scale);
+                        unsafeAtomicAdd(rowp + xs * tg.in_stride[2], (float)acc * inv_scale);
                     }
                 }
             }
@@ -769,7 +860,8 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_spill_kernel(const GridGe
                 } else {
                     c = (double)o[h];
                 }
-                c = map_coordinate(c + (double)g.off[h] + d, g.in_len[h], v.mode);
+                c = map_coordinate_fast(c + (double)g.off[h] + d, tg.in_len[h], tg.mode, tg.period[h],
+                                        tg.inv_period[h]);
                 const bool bad = !(c > -1.0);
                 cst = cst || bad;
                 const double fl = floor((ORDER & 1) ? c : c + 0.5);
@@ -850,9 +942,19 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         tg.in_len[k] = (int)g.in_len[k];
         tg.out_len[k] = (int)g.out_len[k];
         tg.tiles[k] = (int)((g.out_len[k] + kT - 1) / kT);
-        tg.in_stride[k] = v.in_stride[k] / (int64_t)sizeof(T);
-        tg.out_stride[k] = v.out_stride[k] / (int64_t)sizeof(T);
+        tg.in_stride[k] = (int)(v.in_stride[k] / (int64_t)sizeof(T));
+        tg.out_stride[k] = (int)(v.out_stride[k] / (int64_t)sizeof(T));
+        tg.off[k] = (int)g.off[k];
+        // boundary-map period of the axis (deform.c:56,65,75 / :94,104,114)
+        const double len = (double)g.in_len[k];
+        tg.period[k] = v.mode == EDHIP_MODE_MIRROR ? 2 * len - 2
+                       : (v.mode == EDHIP_MODE_REFLECT ? 2 * len : len - 1);
+        tg.inv_period[k] = tg.period[k] > 0 ? 1.0 / tg.period[k] : 0.0;
     }
+    tg.mode = v.mode;
+    tg.has_affine = g.has_affine;
+    for (int k = 0; k < 12; ++k)
+        tg.affine[k] = g.affine[k];
     for (int l = 0; l < v.nstep; ++l) {
         ve.in_step_stride[l] = v.in_step_stride[l] / (int64_t)sizeof(T);
         ve.out_step_stride[l] = v.out_step_stride[l] / (int64_t)sizeof(T);
@@ -926,9 +1028,17 @@ bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
         return false;
     if (!deform_fast_supported(g, v, gradient))
         return false;
-    for (int k = 0; k < 3; ++k)
+    const int64_t esz = v.in_dtype == EDHIP_F32 ? 4 : 8;
+    int64_t in_span = 0, out_span = 0;
+    for (int k = 0; k < 3; ++k) {
         if (g.in_len[k] >= 0x3fffffff || g.out_len[k] >= 0x3fffffff || g.ncp[k] > 1024)
             return false;
+        const int64_t si = v.in_stride[k] / esz, so = v.out_stride[k] / esz;
+        in_span += (si < 0 ? -si : si) * (g.in_len[k] - 1);
+        out_span += (so < 0 ? -so : so) * (g.out_len[k] - 1);
+    }
+    if (in_span >= 0x7fffffffLL || out_span >= 0x7fffffffLL)   // 32-bit element offsets inside a volume
+        return false;
     // head + Q + max(box, D + P) must stay within a 64 KiB block
     if (kOffQ + q_bytes(g) + 16 + (dp_bytes(g) > 32800 ? dp_bytes(g) : 32800) > (size_t)64 * 1024)
         return false;

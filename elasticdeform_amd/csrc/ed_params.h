@@ -80,4 +80,10 @@ struct FilterParams {
 
 hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream);
 
+// fast path (orders 2/3, float32/float64, lines >= 64 samples, no scratch); hipErrorNotSupported
+// (nothing launched) when the case is outside its envelope
+hipError_t launch_spline_filter_fast(const FilterParams& p, int order, int ndim, int axis,
+                                     const int64_t* shape, const int64_t* in_stride_bytes,
+                                     const int64_t* out_stride_bytes, hipStream_t stream);
+
 }  // namespace ed

@@ -217,7 +217,6 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
                           int transpose, uint32_t flags, void* hip_stream, char* err, size_t errlen)
 {
     using namespace ed;
-    (void)flags;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (err && errlen)
         err[0] = 0;
@@ -299,6 +298,21 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
         p.pole_pow[h] = std::pow(p.pole[h], (double)(p.len - 1));       // host libm, like the reference
         const int max = (int)std::ceil(std::log(1e-15) / std::log(std::fabs(p.pole[h])));
         p.trunc_branch[h] = max < p.len;                                // deform.c:1119,1134
+    }
+
+    // fast path: float32 by default, float64 on request; same operator, no scratch, ~1e-16 relative
+    // to the sequential recursion (see spline_fast.hip)
+    const bool want_fast = !(flags & EDHIP_FLAG_EXACT) &&
+                           (input->dtype == EDHIP_F32 || (flags & EDHIP_FLAG_FAST));
+    if (want_fast && p.npoles == 1) {
+        const hipError_t e = launch_spline_filter_fast(p, order, input->ndim, axis, input->shape,
+                                                       input->stride_bytes, output->stride_bytes,
+                                                       stream);
+        if (e == hipSuccess)
+            return EDHIP_OK;
+        if (e != hipErrorNotSupported)
+            return hip_fail(err, errlen, e, "spline filter launch");
+        (void)hipGetLastError();
     }
 
     const bool need_ws = p.npoles > 0 && p.len >= 2;

@@ -107,16 +107,22 @@ def _stream(device):
 
 
 def _filter_axes(x, axes, order, transpose, device):
-    """Chain of 1-D spline filters over `axes`: first pass x -> x_f, the rest in place -- the
-    reference's loop at deform_grid.py:157-162 (forward) / :279-284 (transpose)."""
+    """Chain of 1-D spline filters over `axes` -- the reference's loop at deform_grid.py:157-162
+    (forward) / :279-284 (transpose).  The reference filters x -> x_f and then x_f in place; here
+    the passes ping-pong between two buffers (the caller's x is never written), which lets the
+    kernels split long lines across lanes; the values are the same."""
     torch = _torch()
-    x_f = torch.empty_like(x)
+    axes = list(axes)
+    if not axes:
+        return x
     stream = _stream(device)
+    bufs = [torch.empty_like(x), torch.empty_like(x) if len(axes) > 1 else None]
     src = x
-    for d in axes:
-        _lib.spline_filter1d(_desc(src), _desc(x_f), d, order, transpose, _flags, stream)
-        src = x_f
-    return x_f
+    for i, d in enumerate(axes):
+        dst = bufs[i & 1]
+        _lib.spline_filter1d(_desc(src), _desc(dst), d, order, transpose, _flags, stream)
+        src = dst
+    return src
 
 
 def _prefilter_displacement(displacement, device):

@@ -275,3 +275,48 @@ def test_empty_and_degenerate_inputs():
     # float16 is rejected exactly like the reference does (deform.c:744,891)
     with pytest.raises(RuntimeError, match="data type not supported"):
         ed.deform_grid(X.astype(np.float16), disp)
+
+
+def test_fast_prefilter_kernels():
+    """K3 / K4 fast path (float32 by default, float64 with arithmetic 'fast'): block-recompute IIR,
+    lines split into segments, contiguous axis through LDS tiles, in place.  Against SciPy
+    (forward) and the oracle's restatement of NI_SplineFilter1DGrad (transpose)."""
+    import importlib
+    import ctypes
+    import scipy.ndimage
+    from elasticdeform_amd import _lib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(21)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for shape in ((64,), (70, 3, 97), (129, 200), (5, 64, 7), (3, 100, 65), (300, 70)):
+        for order in (2, 3):
+            for dtype, flag, tol in ((np.float32, _lib.FLAG_AUTO, 2e-6), (np.float64, _lib.FLAG_FAST, 1e-13)):
+                x = rng.standard_normal(shape).astype(dtype)
+                xd = torch.from_numpy(x).to(dev)
+                for axis in range(len(shape)):
+                    if shape[axis] < 64:
+                        continue
+                    want = scipy.ndimage.spline_filter1d(x.astype(np.float64), order=order, axis=axis)
+                    wt = np.zeros(shape)
+                    orc.spline_filter1d_grad(x.astype(np.float64), wt, axis, order)
+                    for transpose, w in ((0, want), (1, wt)):
+                        scale = np.abs(w).max()
+                        # out of place (segmented)
+                        out = torch.empty_like(xd)
+                        _lib.spline_filter1d(dgm._desc(xd), dgm._desc(out), axis, order, transpose,
+                                             flag, stream)
+                        np.testing.assert_allclose(out.cpu().numpy(), w, rtol=0, atol=tol * scale)
+                        # in place (one segment per line)
+                        buf = xd.clone()
+                        _lib.spline_filter1d(dgm._desc(buf), dgm._desc(buf), axis, order, transpose,
+                                             flag, stream)
+                        np.testing.assert_allclose(buf.cpu().numpy(), w, rtol=0, atol=tol * scale)
+                # a non-contiguous view (channels-last style): strided everywhere
+                if len(shape) == 2 and shape[0] >= 64:
+                    v = xd.t()
+                    out = torch.empty_like(v)
+                    _lib.spline_filter1d(dgm._desc(v), dgm._desc(out), 1, order, 0, flag, stream)
+                    want = scipy.ndimage.spline_filter1d(x.T.astype(np.float64), order=order, axis=1)
+                    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0,
+                                               atol=tol * np.abs(want).max())
