@@ -239,20 +239,34 @@ __global__ __launch_bounds__(64 * contig_waves<T>()) void prefilter_fast_contig_
     const double z = p.z, h0 = p.h0;
     const bool tr = p.transpose != 0;
     const int nl = (int)((p.nlines - line0) < 64 ? (p.nlines - line0) : 64);   // lines in this group
-    const bool mine = lane < nl;
 
-    // line bases of this lane's own line (for nothing but bookkeeping) and of every line r of the
-    // group (recomputed by all lanes when loading row r: cheap, wave-uniform)
+    // lane r holds the base offsets of line r of the group; the row loops fetch them with readlane
+    int64_t my_in, my_out;
+    line_offsets(p, line0 + (lane < nl ? lane : nl - 1), my_in, my_out);
+    const T* in_base = reinterpret_cast<const T*>(p.in);
+    T* out_base = reinterpret_cast<T*>(p.out);
+    auto row_offset = [&](int64_t v, int r) -> int64_t {
+        const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffff), r);
+        const int hi = __builtin_amdgcn_readlane((int)(v >> 32), r);
+        return ((int64_t)hi << 32) | (uint32_t)lo;
+    };
     auto load_tile = [&](int64_t j0, int count) {
         // rows r = 0..nl-1, columns j0 .. j0 + count - 1 (count <= 64): lane <-> column
-        for (int r = 0; r < nl; ++r) {
-            int64_t in_off, out_off;
-            line_offsets(p, line0 + r, in_off, out_off);
-            const T* src = reinterpret_cast<const T*>(p.in) + in_off;
-            if (lane < count) {
-                const int64_t i = ext_index(j0 + lane, n, tr);
-                tl[r * kPitch + lane] = i >= 0 ? src[i * p.in_axis_stride] : (T)0;
+        const int64_t i = lane < count ? ext_index(j0 + lane, n, tr) : -1;
+        const int64_t col = i * p.in_axis_stride;
+        // all row loads of a batch are issued before the first LDS write (fixed trip counts so
+        // that the loops unroll; rows beyond nl re-read the last line, harmlessly)
+#pragma unroll 1
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            T v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t off = row_offset(my_in, r0 + r);
+                v[r] = i >= 0 ? in_base[off + col] : (T)0;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tl[(r0 + r) * kPitch + lane] = v[r];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -325,16 +339,17 @@ __global__ __launch_bounds__(64 * contig_waves<T>()) void prefilter_fast_contig_
         wave_sync();
         // store rows: two lines per instruction, 32 contiguous outputs each
         const int half = lane >> 5, col = lane & 31;
-        for (int r = half; r < nl; r += 2) {
-            int64_t in_off, out_off;
-            line_offsets(p, line0 + r, in_off, out_off);
-            T* dst = reinterpret_cast<T*>(p.out) + out_off;
-            if (b + col < n)
-                dst[(b + col) * p.out_axis_stride] = tl[r * kPitch + col];
+#pragma unroll 8
+        for (int r0 = 0; r0 < 64; r0 += 2) {
+            // rows r0 (lanes 0-31) and r0 + 1 (lanes 32-63)
+            const int64_t o0 = row_offset(my_out, r0);
+            const int64_t o1 = row_offset(my_out, r0 + 1);
+            const int r = r0 + half;
+            if (r < nl && b + col < n)
+                out_base[(half ? o1 : o0) + (b + col) * p.out_axis_stride] = tl[r * kPitch + col];
         }
         wave_sync();
     }
-    (void)mine;
 }
 
 }  // namespace
