@@ -55,6 +55,11 @@ struct AxTab {
     double w[4];
     int idx[4];
 };
+
+// 16 bytes at 4-byte alignment: compiles to one global_load_dwordx4 (unaligned access is on)
+struct __attribute__((packed, aligned(4))) F4u {
+    float x, y, z, w;
+};
 static_assert(sizeof(AxTab) == 48, "AxTab layout");
 
 // LDS carve (bytes)
@@ -67,13 +72,19 @@ static_assert(kOffQ % 16 == 0, "LDS carve alignment");
 
 __device__ __forceinline__ int mirror_i32(int idx, int len)
 {
+    if ((unsigned)idx < (unsigned)len)
+        return idx;                       // in range: the common case
     if (len <= 1)
         return 0;
+    if (idx < 0 && idx > -len)
+        return -idx;                      // one reflection at the low end
+    if (idx >= len && idx <= 2 * len - 2)
+        return 2 * len - 2 - idx;         // one reflection at the high end
     const int period = 2 * len - 2;
     if (idx < 0) {
         idx = period * (-idx / period) + idx;
         idx = idx <= 1 - len ? idx + period : -idx;
-    } else if (idx >= len) {
+    } else {
         idx -= period * (idx / period);
         if (idx >= len)
             idx = period - idx;
@@ -376,30 +387,41 @@ template <typename T, int ORDER>
 __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const double* sQ, const AxTab& tx_,
                                              int zi, int yy, const int* o, int* start, T* frac)
 {
-    bool cst = false;
+    double c[3];
+    bool oob = false;
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
         const double* qrow = sQ + (((zi * kT + yy) * 3 + h) << tg.lg_nx);
         double d = 0.0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
-            d += tx_.w[l] * qrow[tx_.idx[l]];
-        double c;
+            d = fma(tx_.w[l], qrow[tx_.idx[l]], d);
+        double b;
         if (tg.has_affine) {
-            c = tg.affine[h * 4 + 3];
+            b = tg.affine[h * 4 + 3];
 #pragma unroll
             for (int l = 0; l < 3; ++l)
-                c += tg.affine[h * 4 + l] * (double)o[l];
+                b = fma(tg.affine[h * 4 + l], (double)o[l], b);
         } else {
-            c = (double)o[h];
+            b = (double)o[h];
         }
-        c = map_coordinate_fast(c + (double)tg.off[h] + d, tg.in_len[h], tg.mode, tg.period[h],
-                                tg.inv_period[h]);
-        const bool bad = !(c > -1.0);
-        cst = cst || bad;
-        const double fl = floor((ORDER & 1) ? c : c + 0.5);
-        start[h] = bad ? 0 : (int)fl - ORDER / 2;
-        frac[h] = (T)(c - fl);
+        c[h] = b + (double)tg.off[h] + d;
+        oob = oob || c[h] < 0.0 || c[h] > (double)(tg.in_len[h] - 1);
+    }
+    bool cst = false;
+    if (oob) {
+        // one divergent region for all three axes: only lanes whose source point left the array
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            c[h] = map_coordinate_fast(c[h], tg.in_len[h], tg.mode, tg.period[h], tg.inv_period[h]);
+            cst = cst || !(c[h] > -1.0);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const double fl = floor((ORDER & 1) ? c[h] : c[h] + 0.5);
+        start[h] = cst ? 0 : (int)fl - ORDER / 2;
+        frac[h] = (T)(c[h] - fl);
     }
     return cst;
 }
@@ -446,6 +468,8 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
     const int yy = lane >> 3, xx = lane & 7;
     const T* __restrict__ in = reinterpret_cast<const T*>(v.in);
     T* out = reinterpret_cast<T*>(v.out);
+    if (tg.dbg & 16)
+        return;
 
     for (int ti = 0; ti < sp.ntile; ++ti) {
         const int o0[3] = {sp.tz * kT, sp.ty * kT, (sp.tx0 + ti) * kT};
@@ -514,6 +538,9 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
             continue;
         }
         const bool x_inside = b0[2] >= 0 && b0[2] + ext[2] <= tg.in_len[2];
+        // the whole padded row (and its one-element shift) lies inside the line: vector staging
+        const bool wide = tg.in_stride[2] == 1 && b0[2] >= 0 && b0[2] + pitch + 1 <= tg.in_len[2] &&
+                          !(tg.dbg & 1);
         const float inv_by = 1.0f / (float)by;
 
         for (int64_t ss = 0; ss < v.nsteps; ++ss) {
@@ -521,10 +548,35 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
             step_offsets(v, ss, in_off, out_off);
             const T* src = in + in_off;
 
-            if (any) {
+            if (any && !(tg.dbg & 32)) {
                 // ---- phase C: stage the source box (mirror-mapped) into LDS ----------------------
                 if (ss > 0)
                     __syncthreads();     // previous step's gathers are done with the box
+                if (sizeof(T) == 4 && wide) {
+                    // interior tile, unit x-stride: 16-byte chunks.  A thread moves chunk q of row
+                    // r (4 / 12 chunks per row, consecutive lanes -> consecutive chunks: global
+                    // reads are 64-byte runs, LDS writes conflict-free b128); the shifted copy is a
+                    // second, 4-byte-offset load of the same run.
+                    const int cpr = pitch >> 2;
+                    const int total = nrows * cpr;
+                    for (int idx = tid; idx < total; idx += kBlock) {
+                        const int r = cpr == 4 ? idx >> 2 : idx / 12;
+                        const int q = idx - r * cpr;
+                        const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                        const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
+                        const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
+                        const float* rowp = reinterpret_cast<const float*>(src) +
+                                            (zs * tg.in_stride[0] + ys * tg.in_stride[1] + b0[2] + 4 * q);
+                        const F4u v0 = *reinterpret_cast<const F4u*>(rowp);
+                        float* d0 = reinterpret_cast<float*>(box0) + r * pitch + 4 * q;
+                        *reinterpret_cast<float4*>(d0) = make_float4(v0.x, v0.y, v0.z, v0.w);
+                        if (PAIR) {
+                            const F4u v1 = *reinterpret_cast<const F4u*>(rowp + 1);
+                            float* d1 = reinterpret_cast<float*>(box1) + r * pitch + 4 * q;
+                            *reinterpret_cast<float4*>(d1) = make_float4(v1.x, v1.y, v1.z, v1.w);
+                        }
+                    }
+                } else {
                 const int sub = tid & 7;
                 for (int r = tid >> 3; r < nrows; r += kBlock / 8) {
                     const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
@@ -540,6 +592,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
                         if (PAIR && xi > 0)
                             d1[xi - 1] = val;
                     }
+                }
                 }
                 __syncthreads();         // B2
             }
@@ -577,12 +630,12 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
 #pragma unroll
                                 for (int l2 = 0; l2 < NT; l2 += 2) {
                                     const float2 pr = *reinterpret_cast<const float2*>(rp + l2);
-                                    a2 += w2[l2] * pr.x;
-                                    a2 += w2[l2 + 1] * pr.y;
+                                    a2 = fmaf(w2[l2], pr.x, a2);
+                                    a2 = fmaf(w2[l2 + 1], pr.y, a2);
                                 }
-                                a1 += w1[l1] * a2;
+                                a1 = fmaf(w1[l1], a2, a1);
                             }
-                            a0 += w0[l0] * a1;
+                            a0 = fmaf(w0[l0], a1, a0);
                         }
                     } else {
                         const T* bp = box0 + rowbase + rx;

@@ -1,0 +1,138 @@
+"""
+CPU tests of the host layer (elasticdeform_amd/_host.py): what the reference's Python helpers hand
+to the C entry point (deform_grid.py:295-454) and how they fail.  No GPU, no library call.
+Expected values come from the oracle's independent restatement (oracle/ed_oracle.py) and, in the
+build container, from the real reference.
+"""
+import numpy as np
+import pytest
+
+from elasticdeform_amd import _host
+from oracle import ed_oracle as orc
+from oracle import ref_loader
+
+
+def _plan(Xs, disp, order=3, mode="constant", cval=0.0, crop=None, axis=None, affine=None,
+          rotate=None, zoom=None):
+    return _host.Plan(Xs, disp, order, mode, cval, crop, axis, affine, rotate, zoom)
+
+
+def test_plan_matches_oracle_restatement():
+    rng = np.random.default_rng(0)
+    X = rng.random((3, 22, 26))
+    Y = rng.random((22, 26))
+    disp = rng.standard_normal((2, 3, 3))
+    crop = (slice(3, 19), slice(None, 21))
+    for affine in (None, np.eye(3), np.eye(2, 3) + rng.standard_normal((2, 3)) * 0.1):
+        for rotate in (None, -30, 0, 25.5):
+            for zoom in (None, 0.5, 1.0, 1.5):
+                p = _plan([X, Y], disp, [3, 0], ["mirror", "nearest"], [0.0, 2.0], crop,
+                          [(1, 2), (0, 1)], affine, rotate, zoom)
+                axis, out_shapes, offset, orders, modes, cvals, inv = orc.prepare(
+                    [X, Y], disp, [3, 0], ["mirror", "nearest"], [0.0, 2.0], crop,
+                    [(1, 2), (0, 1)], affine, rotate, zoom)
+                assert p.axis == axis and [tuple(s) for s in p.output_shapes] == out_shapes
+                np.testing.assert_array_equal(p.output_offset, offset)
+                assert p.output_offset.dtype == np.int64
+                np.testing.assert_array_equal(p.order, orders)
+                np.testing.assert_array_equal(p.mode, modes)
+                np.testing.assert_array_equal(p.cval, cvals)
+                if inv is None:
+                    assert p.inverse_affine is None
+                else:
+                    # bit-equal: the factors are multiplied in the reference's order
+                    np.testing.assert_array_equal(p.inverse_affine, inv)
+                    assert p.inverse_affine.shape == (2, 3)
+
+
+def test_crop_offset_is_none_without_positive_start():
+    X = np.zeros((10, 12))
+    disp = np.zeros((2, 3, 3))
+    p = _plan([X], disp, crop=(slice(0, 5), slice(None, 7)))
+    assert p.output_offset is None and p.output_shapes == [[5, 7]]
+    p = _plan([X], disp, crop=(slice(0, 5), slice(2, 7)))
+    np.testing.assert_array_equal(p.output_offset, [0, 2])
+
+
+def test_axis_forms():
+    X = np.zeros((4, 5, 6))
+    disp1 = np.zeros((1, 3))
+    assert _plan([X], disp1, axis=1).axis == [(1,)]
+    assert _plan([X], np.zeros((2, 3, 3)), axis=(0, 2)).axis == [(0, 2)]
+    assert _plan([X, X], np.zeros((3, 2, 2, 2))).axis == [(0, 1, 2), (0, 1, 2)]
+
+
+def test_failure_behaviour_matches_the_reference():
+    X = np.zeros((10, 12))
+    disp = np.zeros((2, 3, 3))
+    with pytest.raises(Exception, match="numpy.ndarray or a list"):
+        _host.normalize_inputs((X,))                      # tuple is not accepted (deform_grid.py:301)
+    with pytest.raises(AssertionError):
+        _host.normalize_inputs([])
+    with pytest.raises(AssertionError):
+        _plan([X], disp, order=6)
+    with pytest.raises(AssertionError):
+        _plan([X], disp, order=[3, 3])
+    with pytest.raises(RuntimeError, match="boundary mode not supported"):
+        _plan([X], disp, mode="periodic")
+    with pytest.raises(AssertionError):
+        _plan([X], np.zeros((3, 3, 3)))                   # first dim must equal naxis
+    with pytest.raises(AssertionError):
+        _plan([X], np.zeros((2, 3)))                      # ndim must be naxis + 1
+    with pytest.raises(AssertionError):
+        _plan([X], disp, axis=(1, 0))                     # sorted and unique
+    with pytest.raises(AssertionError):
+        _plan([X], disp, axis=(0, 2))                     # out of range
+    with pytest.raises(AssertionError):
+        _plan([X, np.zeros((10, 13))], disp)              # equal deformed shapes
+    with pytest.raises(Exception, match="Crop must be a slice"):
+        _plan([X], disp, crop=(slice(0, 5), 3))
+    with pytest.raises(AssertionError):
+        _plan([X], disp, crop=(slice(0, 5, 2), slice(None)))
+    with pytest.raises(AssertionError):
+        _plan([X], disp, crop=(slice(0, 11), slice(None)))
+    with pytest.raises(AssertionError):
+        _plan([X], disp, affine=np.eye(4))
+    with pytest.raises(AssertionError, match="only implemented for 2D"):
+        _plan([np.zeros((4, 5, 6))], np.zeros((3, 2, 2, 2)), rotate=10)
+    # a homogeneous 4x4 in 3-D trips the reference's hard-coded [0, 0, 1] check
+    with pytest.raises(ValueError):
+        _plan([np.zeros((4, 5, 6))], np.zeros((3, 2, 2, 2)), affine=np.eye(4))
+
+
+def test_public_api_fails_loudly_without_gpu_or_library():
+    import torch
+    import elasticdeform_amd as ed
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ed.deform_grid(np.zeros((8, 8)), np.zeros((2, 3, 3)))
+    # argument errors still surface first, exactly like the reference
+    with pytest.raises(AssertionError):
+        ed.deform_grid(np.zeros((8, 8)), np.zeros((2, 3, 3)), order=7)
+    with pytest.raises(ValueError, match="X_shape is required"):
+        ed.deform_grid_gradient(np.zeros((4, 4)), np.zeros((2, 3, 3)), crop=(slice(0, 4),) * 2)
+
+
+@pytest.mark.skipif(ref_loader.load_reference() is None,
+                    reason="real reference only exists in the build container")
+def test_plan_matches_live_reference_helpers():
+    import importlib
+    ref = ref_loader.load_reference()
+    dg = importlib.import_module(ref.__name__ + ".deform_grid")
+    rng = np.random.default_rng(1)
+    X = rng.random((20, 30))
+    for rotate, zoom in ((None, None), (17.0, None), (None, 0.7), (-33, 1.3)):
+        for affine in (None, np.eye(2, 3) + rng.standard_normal((2, 3)) * 0.1):
+            crop = (slice(2, 18), slice(5, 25))
+            p = _plan([X], np.zeros((2, 3, 3)), crop=crop, affine=affine, rotate=rotate, zoom=zoom)
+            Xs = dg._normalize_inputs(X)
+            axis, ds = dg._normalize_axis_list(None, Xs)
+            shapes, off = dg._compute_output_shapes(Xs, axis, ds, crop)
+            inv = dg._compute_inverse_affine(dg._normalize_affine(affine, axis))
+            inv = dg._apply_rotation_and_zoom(rotate, zoom, inv, [shapes[0][d] for d in axis[0]])
+            np.testing.assert_array_equal(p.output_offset, off)
+            if inv is None:
+                assert p.inverse_affine is None
+            else:
+                np.testing.assert_array_equal(p.inverse_affine, inv)

@@ -1,0 +1,92 @@
+"""
+CPU tests of the C-ABI shared library: it loads, exports every symbol include/edhip.h declares,
+and its argument validation (the checks of _deform_grid.c:121-255) answers with the right status
+codes -- all before any HIP call, so no GPU is needed.  No compute is launched here.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from elasticdeform_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH),
+                                reason="libedhip.so not built (run __graft_entry__.build())")
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "edhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(edhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree():
+    names = _declared_functions()
+    assert set(names) == set(_lib.EXPORTS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+    lib = _lib.load()
+    assert lib.edhip_version() == 100
+    assert lib.edhip_status_string(2) == b"data type not supported"
+
+
+def _desc(shape, dtype="float32", ptr=0x1000):
+    a = np.empty(shape, dtype=dtype)
+    return _lib.describe(ptr, a.dtype.name, a.shape, a.strides)
+
+
+def _call(ins, disp, outs, axis, orders=None, modes=None, cvals=None, off=None, aff=None, grad=False):
+    n = len(ins)
+    _lib.deform(grad, ins, disp, off, outs, axis, orders or [3] * n, modes or [4] * n,
+                cvals or [0.0] * n, aff, _lib.FLAG_AUTO, 0)
+
+
+def test_validation_errors_map_to_reference_exceptions():
+    d2 = _desc((2, 3, 3), "float64")
+    x = _desc((8, 9))
+    # input / output rank mismatch (_deform_grid.c:137-140)
+    with pytest.raises(RuntimeError, match="dimensions should match"):
+        _call([x], d2, [_desc((8, 9, 1))], [(0, 1)])
+    # axis out of range (:161-165)
+    with pytest.raises(RuntimeError, match="invalid axis"):
+        _call([x], d2, [x], [(0, 2)])
+    # inputs of different deformed size (:166-169)
+    with pytest.raises(RuntimeError, match="same size"):
+        _call([x, _desc((8, 10))], d2, [x, _desc((8, 10))], [(0, 1), (0, 1)])
+    # displacement shape (:178-183)
+    with pytest.raises(RuntimeError, match="invalid displacement shape"):
+        _call([x], _desc((3, 3, 3), "float64"), [x], [(0, 1)])
+    with pytest.raises(RuntimeError, match="invalid displacement shape"):
+        _call([x], _desc((2, 3), "float64"), [x], [(0, 1)])
+    # spline order / mode ranges
+    with pytest.raises(RuntimeError, match="spline order"):
+        _call([x], d2, [x], [(0, 1)], orders=[6])
+    with pytest.raises(RuntimeError, match="boundary mode"):
+        _call([x], d2, [x], [(0, 1)], modes=[9])
+    # unsupported dtypes never reach the library: the descriptor builder refuses them with the
+    # reference's message (deform.c:744,891)
+    with pytest.raises(RuntimeError, match="data type not supported"):
+        _lib.describe(0x1000, "float16", (4, 4), (8, 2))
+    with pytest.raises(RuntimeError, match="data type not supported"):
+        _lib.describe(0x1000, "complex64", (4, 4), (32, 8))
+
+
+def test_filter_validation():
+    x = _desc((8, 9))
+    with pytest.raises(RuntimeError, match="spline order not supported"):
+        _lib.spline_filter1d(x, x, 0, 6, False, 0, 0)
+    with pytest.raises(RuntimeError, match="invalid axis"):
+        _lib.spline_filter1d(x, x, 2, 3, False, 0, 0)
+    with pytest.raises(RuntimeError, match="shapes should match"):
+        _lib.spline_filter1d(x, _desc((8, 10)), 0, 3, False, 0, 0)
+
+
+def test_empty_work_is_ok_without_a_gpu():
+    # zero output voxels: validated, nothing launched, EDHIP_OK
+    d2 = _desc((2, 3, 3), "float64")
+    _call([_desc((8, 9))], d2, [_desc((0, 9))], [(0, 1)])
