@@ -67,8 +67,26 @@ constexpr int kOffTabZY = 0;                              // [2][8] AxTab
 constexpr int kOffTabX = 2 * kT * 48;                     // [kStrip][8] AxTab
 constexpr int kOffRed = kOffTabX + kStrip * kT * 48;      // int[2][8]: lo[3], hi[3], -, -
 constexpr int kOffSum = kOffRed + 64;                     // float[2][4]: per-wave sum |dY| (K2)
-constexpr int kOffQ = kOffSum + 32;                       // 3936
+constexpr int kOffHot = kOffSum + 32;                     // HotParams (uniform values kept out of SGPRs)
+constexpr int kOffQ = kOffHot + 512;
 static_assert(kOffQ % 16 == 0, "LDS carve alignment");
+
+// Uniform per-call values the per-voxel code needs.  Kept in LDS and fetched with broadcast reads:
+// as kernel arguments they would be hoisted into ~100 scalar registers, live across the whole tile
+// loop, and the spill reloads (v_readlane) were a third of the kernel's VALU work.
+struct HotParams {
+    double offd[3];        // crop offset per axis
+    double last[3];        // I_k - 1
+    double period[3];      // boundary-map period for the input's mode, and its reciprocal
+    double inv_period[3];
+    double affine[12];     // inverse map, 3 x 4
+    long long step_len[8];
+    long long in_step_stride[8];
+    long long out_step_stride[8];
+    int nstep;
+    int pad_;
+};
+static_assert(sizeof(HotParams) <= 512, "HotParams must fit its LDS slot");
 
 __device__ __forceinline__ int mirror_i32(int idx, int len)
 {
@@ -295,8 +313,8 @@ __device__ __forceinline__ bool strip_position(const TileGeom& tg, StripPos& sp)
 
 // Strip prologue: tables, D -> LDS, P, Q.  Ends with a barrier; afterwards only tabx and Q are
 // needed (D / P may be overwritten).
-__device__ __forceinline__ void strip_prologue(const GridGeom& g, const TileGeom& tg,
-                                               const StripPos& sp, char* smem)
+__device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& vstep,
+                                               const TileGeom& tg, const StripPos& sp, char* smem)
 {
     AxTab* tabzy = reinterpret_cast<AxTab*>(smem + kOffTabZY);
     AxTab* tabx = reinterpret_cast<AxTab*>(smem + kOffTabX);
@@ -338,6 +356,24 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const TileGeom
     if (tid < 16) {
         const int k = tid & 7;
         sred[tid] = k < 3 ? 0x7fffffff : (int)0x80000000;
+    }
+    if (tid >= 128 && tid < 128 + 12) {
+        HotParams* hp = reinterpret_cast<HotParams*>(smem + kOffHot);
+        const int k = tid - 128;
+        hp->affine[k] = tg.affine[k];
+        if (k < 3) {
+            hp->offd[k] = (double)tg.off[k];
+            hp->last[k] = (double)(tg.in_len[k] - 1);
+            hp->period[k] = tg.period[k];
+            hp->inv_period[k] = tg.inv_period[k];
+        }
+        if (k < 8) {
+            hp->step_len[k] = vstep.step_len[k];
+            hp->in_step_stride[k] = vstep.in_step_stride[k];
+            hp->out_step_stride[k] = vstep.out_step_stride[k];
+        }
+        if (k == 0)
+            hp->nstep = vstep.nstep;
     }
     // control grid -> LDS (doubles), rows padded to 1 << lgp
     for (int e = tid; e < ((3 * ncpz) << lgp); e += kBlock) {
@@ -384,8 +420,9 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const TileGeom
 
 // Phase A for one voxel: displacement from Q, affine, boundary map, window start, fraction.
 template <typename T, int ORDER>
-__device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const double* sQ, const AxTab& tx_,
-                                             int zi, int yy, const int* o, int* start, T* frac)
+__device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const HotParams* hp, const double* sQ,
+                                             const AxTab& tx_, int zi, int yy, const int* o,
+                                             int* start, T* frac)
 {
     double c[3];
     bool oob = false;
@@ -398,22 +435,23 @@ __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const double* s
             d = fma(tx_.w[l], qrow[tx_.idx[l]], d);
         double b;
         if (tg.has_affine) {
-            b = tg.affine[h * 4 + 3];
+            b = hp->affine[h * 4 + 3];
 #pragma unroll
             for (int l = 0; l < 3; ++l)
-                b = fma(tg.affine[h * 4 + l], (double)o[l], b);
+                b = fma(hp->affine[h * 4 + l], (double)o[l], b);
         } else {
             b = (double)o[h];
         }
-        c[h] = b + (double)tg.off[h] + d;
-        oob = oob || c[h] < 0.0 || c[h] > (double)(tg.in_len[h] - 1);
+        c[h] = b + hp->offd[h] + d;
+        oob = oob || c[h] < 0.0 || c[h] > hp->last[h];
     }
     bool cst = false;
     if (oob) {
         // one divergent region for all three axes: only lanes whose source point left the array
 #pragma unroll
         for (int h = 0; h < 3; ++h) {
-            c[h] = map_coordinate_fast(c[h], tg.in_len[h], tg.mode, tg.period[h], tg.inv_period[h]);
+            c[h] = map_coordinate_fast(c[h], (int)hp->last[h] + 1, tg.mode, hp->period[h],
+                                       hp->inv_period[h]);
             cst = cst || !(c[h] > -1.0);
         }
     }
@@ -424,6 +462,23 @@ __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const double* s
         frac[h] = (T)(c[h] - fl);
     }
     return cst;
+}
+
+__device__ __forceinline__ void step_offsets(const HotParams* hp, int64_t ss, int64_t& in_off,
+                                             int64_t& out_off)
+{
+    in_off = 0;
+    out_off = 0;
+    int64_t r = ss;
+    const int nstep = hp->nstep;
+    for (int l = 0; l < nstep; ++l) {
+        const int64_t len = hp->step_len[l];
+        const int64_t q = r / len;
+        const int64_t c = r - q * len;
+        in_off += hp->in_step_stride[l] * c;
+        out_off += hp->out_step_stride[l] * c;
+        r = q;
+    }
 }
 
 __device__ __forceinline__ void step_offsets(const IOView& v, int64_t ss, int64_t& in_off,
@@ -454,11 +509,12 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
     StripPos sp;
     if (!strip_position(tg, sp))
         return;
-    strip_prologue(g, tg, sp, smem);
+    strip_prologue(g, v, tg, sp, smem);
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
     const double* sQ = reinterpret_cast<const double*>(smem + kOffQ);
+    const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
     T* box0 = reinterpret_cast<T*>(smem + tg.off_ov);
     T* box1 = box0 + tg.box_cap + 8;      // +8 elements: the two copies sit on disjoint LDS banks
 
@@ -494,7 +550,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
                     frac[i][h] = (T)0.5;
                 }
             } else
-            constant[i] = voxel_coords<T, ORDER>(tg, sQ, tabx[ti * kT + xx], zi, yy, o, start[i],
+            constant[i] = voxel_coords<T, ORDER>(tg, hp, sQ, tabx[ti * kT + xx], zi, yy, o, start[i],
                                                  frac[i]);
             if (valid[i] && !constant[i]) {
 #pragma unroll
@@ -545,7 +601,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
 
         for (int64_t ss = 0; ss < v.nsteps; ++ss) {
             int64_t in_off, out_off;
-            step_offsets(v, ss, in_off, out_off);
+            step_offsets(hp, ss, in_off, out_off);
             const T* src = in + in_off;
 
             if (any && !(tg.dbg & 32)) {
@@ -667,7 +723,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
 // ================================================================================================
 // K2: gradient (float32): integer LDS accumulation per tile, float atomics to flush
 // ================================================================================================
-template <int ORDER>
+template <int ORDER, int TX>
 __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const GridGeom g,
                                                                       const IOView v,
                                                                       const TileGeom tg)
@@ -677,37 +733,42 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
     StripPos sp;
     if (!strip_position(tg, sp))
         return;
-    strip_prologue(g, tg, sp, smem);
+    strip_prologue(g, v, tg, sp, smem);
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
     const double* sQ = reinterpret_cast<const double*>(smem + kOffQ);
+    const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
     int* box = reinterpret_cast<int*>(smem + tg.off_ov);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int yy = lane >> 3, xx = lane & 7;
+    // a tile is 8 (z) x 8 (y) x TX (x) voxels; a thread owns column (yy, xx) and NV z-slices
+    constexpr int NV = TX / 4;
+    constexpr int ZSTEP = 8 / NV;
+    const int xx = tid % TX, yy = (tid / TX) & 7, zq = tid / (TX * 8);
+    const int ntile = (sp.ntile * kT + TX - 1) / TX;
     float* dx = reinterpret_cast<float*>(const_cast<char*>(v.in));      // accumulated into
     const float* __restrict__ dy = reinterpret_cast<const float*>(v.out);
     int phase = 0;      // parity of the gmax slot
 
-    for (int ti = 0; ti < sp.ntile; ++ti) {
-        const int o0[3] = {sp.tz * kT, sp.ty * kT, (sp.tx0 + ti) * kT};
+    for (int ti = 0; ti < ntile; ++ti) {
+        const int o0[3] = {sp.tz * kT, sp.ty * kT, sp.tx0 * kT + ti * TX};
         int* red = sred + (ti & 1) * 8;
 
-        int start[2][3];
-        float frac[2][3];
-        bool active[2];
+        int start[NV][3];
+        float frac[NV][3];
+        bool active[NV];
         int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
         int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-        int ooff[2];
+        int ooff[NV];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int zi = wave + 4 * i;
+        for (int i = 0; i < NV; ++i) {
+            const int zi = zq + ZSTEP * i;
             const int o[3] = {o0[0] + zi, o0[1] + yy, o0[2] + xx};
             const bool valid = o[0] < tg.out_len[0] && o[1] < tg.out_len[1] && o[2] < tg.out_len[2];
-            const bool cst = voxel_coords<float, ORDER>(tg, sQ, tabx[ti * kT + xx], zi, yy, o,
+            const bool cst = voxel_coords<float, ORDER>(tg, hp, sQ, tabx[ti * TX + xx], zi, yy, o,
                                                         start[i], frac[i]);
             active[i] = valid && !cst;       // constant-mapped voxels contribute nothing (:928)
             ooff[i] = o[0] * tg.out_stride[0] + o[1] * tg.out_stride[1] + o[2] * tg.out_stride[2];
@@ -736,15 +797,16 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
             sred[((ti + 1) & 1) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
         if (!any)
             continue;      // nothing to scatter (uniform)
-        const int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 56 ? 56 : 0));
+        const int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
         const int by = ext[1];
         const int nrows = ext[0] * by;
         const int nbox = nrows * pitch;
         const bool fits = pitch > 0 && nbox <= tg.box_cap;
         if (!fits) {
-            if (tid == 0) {
+            if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < tg.tiles[2]) {
                 const int slot = atomicAdd(&tg.spill[0], 1);
-                tg.spill[1 + slot] = (sp.tz * tg.tiles[1] + sp.ty) * tg.tiles[2] + sp.tx0 + ti;
+                tg.spill[1 + slot] = (sp.tz * tg.tiles[1] + sp.ty) * tg.tiles[2] + sp.tx0 +
+                                     ti * (TX / kT) + tid;
             }
             continue;
         }
@@ -753,17 +815,17 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
 
         for (int64_t ss = 0; ss < v.nsteps; ++ss, ++phase) {
             int64_t in_off, out_off;
-            step_offsets(v, ss, in_off, out_off);
+            step_offsets(hp, ss, in_off, out_off);
             if (ss > 0)
                 __syncthreads();         // previous step's flush is done with the box
             // zero the accumulators; tile maximum of |dY|
             for (int e = tid * 4; e < nbox; e += kBlock * 4)
                 *reinterpret_cast<int4*>(box + e) = make_int4(0, 0, 0, 0);
-            float gval[2];
+            float gval[NV];
             float gm = 0.f;
             float* dst = dx + in_off;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 gval[i] = active[i] ? dy[out_off + ooff[i]] : 0.f;
                 if ((__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000) {
                     // inf / NaN gradient: no fixed-point scale exists -- this voxel scatters its
@@ -812,18 +874,34 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
             const float scale = (2147483648.0f - 1024.0f) / (kWmax * 1.001f * gtot);
             const float inv_scale = 1.0f / scale;
 
+            // one voxel at a time (rolled: four unrolled 64-tap scatters do not fit the register
+            // budget); the voxel's state is picked out of the register arrays by select chains
+#pragma unroll 1
+            for (int i = 0; i < NV; ++i) {
+                int st0 = start[0][0], st1 = start[0][1], st2 = start[0][2];
+                float f0 = frac[0][0], f1 = frac[0][1], f2 = frac[0][2], gv = gval[0];
+                bool act = active[0];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (!active[i] || gval[i] == 0.f)
+                for (int k = 1; k < NV; ++k) {
+                    const bool sel = i == k;
+                    st0 = sel ? start[k][0] : st0;
+                    st1 = sel ? start[k][1] : st1;
+                    st2 = sel ? start[k][2] : st2;
+                    f0 = sel ? frac[k][0] : f0;
+                    f1 = sel ? frac[k][1] : f1;
+                    f2 = sel ? frac[k][2] : f2;
+                    gv = sel ? gval[k] : gv;
+                    act = sel ? active[k] : act;
+                }
+                if (!act || gv == 0.f || (tg.dbg & 128))
                     continue;
                 float w0[NT], w1[NT], w2[NT];
-                weights_from_frac<float, ORDER>(frac[i][0], w0);
-                weights_from_frac<float, ORDER>(frac[i][1], w1);
-                weights_from_frac<float, ORDER>(frac[i][2], w2);
-                const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1],
-                          rx = start[i][2] - b0[2];
+                weights_from_frac<float, ORDER>(f0, w0);
+                weights_from_frac<float, ORDER>(f1, w1);
+                weights_from_frac<float, ORDER>(f2, w2);
+                const int rz = st0 - b0[0], ry = st1 - b0[1], rx = st2 - b0[2];
                 int* bp = box + (rz * by + ry) * pitch + rx;
-                const float gs = gval[i] * scale;
+                const float gs = gv * scale;
 #pragma unroll
                 for (int l0 = 0; l0 < NT; ++l0) {
                     const float g0 = gs * w0[l0];
@@ -839,19 +917,20 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
             }
             __syncthreads();             // B3: all contributions are in
             // flush: one float atomic per touched source element, mirror-mapped (deform.c:791-813)
-            const int sub = tid & 7;
-            for (int r = tid >> 3; r < nrows; r += kBlock / 8) {
-                const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
-                const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
-                const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
-                float* rowp = dst + (zs * tg.in_stride[0] + ys * tg.in_stride[1]);
-                const int* brow = box + r * pitch;
-                for (int xi = sub; xi < ext[2]; xi += 8) {
-                    const int acc = brow[xi];
-                    if (acc != 0) {
-                        const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
-                        unsafeAtomicAdd(rowp + xs * tg.in_stride[2], (float)acc * inv_scale);
-                    }
+            // consecutive lanes walk consecutive elements of the padded rows: a row's touched
+            // elements are one contiguous run of float atomics
+            const float inv_pitch = 1.0f / (float)pitch;
+            for (int e = tid; e < ((tg.dbg & 64) ? 0 : nbox); e += kBlock) {
+                const int acc = box[e];
+                if (acc != 0) {
+                    const int r = (int)(((float)e + 0.5f) * inv_pitch), xi = e - r * pitch;
+                    const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                    const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
+                    const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
+                    const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
+                    unsafeAtomicAdd(dst + (zs * tg.in_stride[0] + ys * tg.in_stride[1] +
+                                           xs * tg.in_stride[2]),
+                                    (float)acc * inv_scale);
                 }
             }
         }
@@ -1026,8 +1105,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     // elements; otherwise one copy (6144 x 4 bytes or 4096 x 8 bytes)
     size_t box;
     if (GRAD) {
-        tg.box_cap = 6144;
-        box = 6144 * 4;
+        tg.box_cap = 8192;
+        box = 8192 * 4;
     } else if (PAIR) {
         tg.box_cap = 4096;
         box = (2 * 4096 + 8) * sizeof(T);
@@ -1054,7 +1133,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
         if (GRAD)
-            hipLaunchKernelGGL((deform_tile3_grad_kernel<ORDER>), dim3(nblk), dim3(kBlock), lds,
+            hipLaunchKernelGGL((deform_tile3_grad_kernel<ORDER, 16>), dim3(nblk), dim3(kBlock), lds,
                                stream, g, ve, tg);
         else
             hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR>), dim3(nblk), dim3(kBlock),
