@@ -42,6 +42,7 @@
 
 #include "ed_device.h"
 #include "ed_params.h"
+#include "ed_workspace.h"
 
 namespace ed {
 
@@ -286,6 +287,8 @@ struct TileGeom {
     double inv_period[3];
     double affine[12];    // inverse map, 3 x 4
     int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
+    const double* q_global;   // [O_z][O_y][3][1 << lg_nx]: displacement contracted over z and y
+    const AxTab* xt_global;   // [O_x]: cubic weights / control indices along x
     int dbg;              // ablation switches for profiling (EDHIP_TILE_DBG), 0 in production
 };
 
@@ -311,37 +314,24 @@ __device__ __forceinline__ bool strip_position(const TileGeom& tg, StripPos& sp)
     return true;
 }
 
-// Strip prologue: tables, D -> LDS, P, Q.  Ends with a barrier; afterwards only tabx and Q are
-// needed (D / P may be overwritten).
-__device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& vstep,
-                                               const TileGeom& tg, const StripPos& sp, char* smem)
+// Per-call tables (one small launch before the tile kernel).  The displacement spline is
+// separable and its weights depend only on the output index along each axis (deform.c:639-647):
+//   XT[ox]            = cubic weights + mirror-mapped control indices along x   (the reference's
+//                       `dsplvals` rows, for one axis)
+//   Q[oz][oy][h][j2]  = sum_{l0,l1} wz[oz][l0] wy[oy][l1] D[h, iz[l0], iy[l1], j2]
+// so that a voxel is left with 4 x-taps per component (12 fp64 FMAs instead of the reference's 192
+// multiply-adds, deform.c:693-758).  One block per output z: P = D contracted over z in LDS, then
+// every output y of that slice.
+__global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, const TileGeom tg)
 {
-    AxTab* tabzy = reinterpret_cast<AxTab*>(smem + kOffTabZY);
-    AxTab* tabx = reinterpret_cast<AxTab*>(smem + kOffTabX);
-    int* sred = reinterpret_cast<int*>(smem + kOffRed);
-    double* sQ = reinterpret_cast<double*>(smem + kOffQ);
-    const int ncpz = (int)g.ncp[0], ncpx = (int)g.ncp[2];
-    const int nyx = (int)g.ncp[1] * ncpx;
-    const int lgp = tg.lg_nyx, lgx = tg.lg_nx;
-    double* sD = reinterpret_cast<double*>(smem + tg.off_ov);      // [3][ncpz][1 << lgp]
-    double* sP = sD + ((3 * ncpz) << lgp);                           // [8][3][1 << lgp]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sP = reinterpret_cast<double*>(smem);              // [3][nyx]
+    __shared__ AxTab tz_;
     const int tid = threadIdx.x;
-
-    // per-axis cubic weights / control indices (deform.c:639-690): 8 z, 8 y, up to 64 x entries
-    if (tid < 2 * kT + kStrip * kT) {
-        int a, oi;
-        AxTab* dst;
-        if (tid < 2 * kT) {
-            a = tid >> 3;
-            oi = (a == 0 ? sp.tz : sp.ty) * kT + (tid & 7);
-            dst = tabzy + tid;
-        } else {
-            a = 2;
-            oi = sp.tx0 * kT + (tid - 2 * kT);
-            dst = tabx + (tid - 2 * kT);
-        }
-        if (oi >= tg.out_len[a])
-            oi = tg.out_len[a] - 1;
+    const int oz = blockIdx.x;
+    const int ncpy = (int)g.ncp[1], ncpx = (int)g.ncp[2];
+    const int nyx = ncpy * ncpx;
+    auto entry = [&](int a, int oi, AxTab& t) {
         const double cp = control_coordinate(g.ncp[a], (int64_t)oi + g.off[a], g.in_len[a]);
         const int64_t start = window_start(cp, 3);
         const bool edge = start < 0 || start + 3 >= g.ncp[a];
@@ -349,9 +339,74 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& 
         spline_weights(cp, 3, w);
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            dst->w[l] = w[l];
-            dst->idx[l] = (int)(edge ? mirror_index(start + l, g.ncp[a]) : start + l);
+            t.w[l] = w[l];
+            t.idx[l] = (int)(edge ? mirror_index(start + l, g.ncp[a]) : start + l);
         }
+    };
+    if (tid == 0)
+        entry(0, oz, tz_);
+    if (oz == 0) {
+        AxTab* xt = const_cast<AxTab*>(tg.xt_global);
+        for (int ox = tid; ox < tg.out_len[2]; ox += kBlock) {
+            AxTab t;
+            entry(2, ox, t);
+            xt[ox] = t;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * nyx; e += kBlock) {
+        const int h = e / nyx, j = e - h * nyx;
+        const int j1 = j / ncpx, j2 = j - j1 * ncpx;
+        const char* base = g.disp + g.disp_stride[0] * h + g.disp_stride[2] * j1 + g.disp_stride[3] * j2;
+        double acc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            acc += tz_.w[l] * load_as_double(base + g.disp_stride[1] * tz_.idx[l], g.disp_dtype);
+        sP[e] = acc;
+    }
+    __syncthreads();
+    double* q = const_cast<double*>(tg.q_global);
+    for (int oy = tid; oy < tg.out_len[1]; oy += kBlock) {
+        AxTab ty;
+        entry(1, oy, ty);
+        double* row = q + (((int64_t)oz * tg.out_len[1] + oy) * 3 << tg.lg_nx);
+        for (int h = 0; h < 3; ++h)
+            for (int j2 = 0; j2 < ncpx; ++j2) {
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    acc += ty.w[l] * sP[h * nyx + ty.idx[l] * ncpx + j2];
+                row[(h << tg.lg_nx) + j2] = acc;
+            }
+    }
+}
+
+// Strip prologue: the strip's 64 x-table entries and its 64 rows of Q come from the per-call
+// tables into LDS; hot uniform parameters are parked in LDS.  Ends with a barrier.
+__device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& vstep,
+                                               const TileGeom& tg, const StripPos& sp, char* smem)
+{
+    int* sred = reinterpret_cast<int*>(smem + kOffRed);
+    double* sQ = reinterpret_cast<double*>(smem + kOffQ);
+    const int tid = threadIdx.x;
+    (void)g;
+
+    {   // x table: 64 entries x 48 bytes = 768 dwords
+        const int* src = reinterpret_cast<const int*>(tg.xt_global + sp.tx0 * kT);
+        int* dst = reinterpret_cast<int*>(smem + kOffTabX);
+        const int avail = (tg.out_len[2] - sp.tx0 * kT) * 12;      // dwords that exist
+        for (int e = tid; e < kStrip * kT * 12; e += kBlock)
+            dst[e] = e < avail ? src[e] : 0;
+    }
+    {   // Q rows: (zi, yy) -> global row (oz, oy); 4 threads per row
+        const int rowlen = 3 << tg.lg_nx;
+        const int r = tid >> 2;
+        const int oz = min(sp.tz * kT + (r >> 3), tg.out_len[0] - 1);
+        const int oy = min(sp.ty * kT + (r & 7), tg.out_len[1] - 1);
+        const double* src = tg.q_global + ((int64_t)oz * tg.out_len[1] + oy) * rowlen;
+        double* dst = sQ + r * rowlen;
+        for (int k = tid & 3; k < rowlen; k += 4)
+            dst[k] = src[k];
     }
     if (tid < 16) {
         const int k = tid & 7;
@@ -374,46 +429,6 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& 
         }
         if (k == 0)
             hp->nstep = vstep.nstep;
-    }
-    // control grid -> LDS (doubles), rows padded to 1 << lgp
-    for (int e = tid; e < ((3 * ncpz) << lgp); e += kBlock) {
-        const int j = e & ((1 << lgp) - 1), r = e >> lgp;
-        if (j < nyx) {
-            const int j1 = j / ncpx, j2 = j - j1 * ncpx;
-            const int h = r / ncpz, j0 = r - h * ncpz;
-            sD[e] = load_as_double(g.disp + g.disp_stride[0] * h + g.disp_stride[1] * j0 +
-                                       g.disp_stride[2] * j1 + g.disp_stride[3] * j2,
-                                   g.disp_dtype);
-        }
-    }
-    __syncthreads();
-    // P[zi][h][j] = sum_l wz[zi][l] * D[h][iz[zi][l]][j]
-    for (int e = tid; e < ((kT * 3) << lgp); e += kBlock) {
-        const int j = e & ((1 << lgp) - 1), r = e >> lgp;
-        if (j < nyx) {
-            const int zi = r / 3, h = r - zi * 3;
-            const AxTab& tz_ = tabzy[zi];
-            double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-                acc += tz_.w[l] * sD[((h * ncpz + tz_.idx[l]) << lgp) + j];
-            sP[e] = acc;
-        }
-    }
-    __syncthreads();
-    // Q[zi][y][h][j2] = sum_l wy[y][l] * P[zi][h][iy[y][l]][j2]
-    for (int q = tid; q < ((kT * kT * 3) << lgx); q += kBlock) {
-        const int j2 = q & ((1 << lgx) - 1), r = q >> lgx;
-        if (j2 < ncpx) {
-            const int zy = r / 3, h = r - zy * 3;
-            const int y = zy & 7, zi = zy >> 3;
-            const AxTab& ty_ = tabzy[kT + y];
-            double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-                acc += ty_.w[l] * sP[((zi * 3 + h) << lgp) + ty_.idx[l] * ncpx + j2];
-            sQ[q] = acc;
-        }
     }
     __syncthreads();
 }
@@ -1058,12 +1073,11 @@ inline int ceil_log2(int64_t n)
     return l;
 }
 
-inline size_t dp_bytes(const GridGeom& g)
-{
-    const int lgp = ceil_log2(g.ncp[1] * g.ncp[2]);
-    return 8 * (((size_t)3 * g.ncp[0] + kT * 3) << lgp);
-}
 inline size_t q_bytes(const GridGeom& g) { return 8 * ((size_t)(kT * kT * 3) << ceil_log2(g.ncp[2])); }
+inline size_t q_global_bytes(const GridGeom& g)
+{
+    return 8 * (((size_t)g.out_len[0] * (size_t)g.out_len[1] * 3) << ceil_log2(g.ncp[2]));
+}
 
 template <typename T, int ORDER, bool PAIR, bool GRAD>
 hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
@@ -1114,22 +1128,32 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         tg.box_cap = sizeof(T) == 4 ? 6144 : 4096;
         box = (size_t)tg.box_cap * sizeof(T);
     }
-    size_t overlay = box > dp_bytes(g) ? box : dp_bytes(g);
-    overlay = (overlay + 15) & ~(size_t)15;
+    size_t overlay = (box + 15) & ~(size_t)15;
     tg.off_ov = (int)(kOffQ + ((q_bytes(g) + 15) & ~(size_t)15));
-    const size_t lds = tg.off_ov + overlay;
-
+    size_t lds = tg.off_ov + overlay;
+    if (const char* pad = getenv("EDHIP_LDS_PAD"))
+        lds += (size_t)atoi(pad);
     {
         const char* dbg = getenv("EDHIP_TILE_DBG");
         tg.dbg = dbg ? atoi(dbg) : 0;
     }
-    // spill worklist: stream-ordered scratch, counter zeroed on the stream
-    void* spill = nullptr;
-    hipError_t e = hipMallocAsync(&spill, sizeof(int) * ((size_t)ntiles + 1), stream);
-    if (e != hipSuccess)
+    // stream-ordered scratch: spill worklist | x table | Q
+    const size_t spill_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
+    const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
+    hipError_t e = hipSuccess;
+    void* ws = workspace_reserve(stream, spill_bytes + xt_bytes + q_global_bytes(g), &e);
+    if (!ws)
         return e;
-    tg.spill = (int*)spill;
+    tg.spill = (int*)ws;
+    tg.xt_global = (const AxTab*)((char*)ws + spill_bytes);
+    tg.q_global = (const double*)((char*)ws + spill_bytes + xt_bytes);
+    void* spill = ws;
     e = hipMemsetAsync(spill, 0, sizeof(int), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0]), dim3(kBlock),
+                           sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
         if (GRAD)
@@ -1146,8 +1170,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
                            stream, g, ve, tg);
         e = hipGetLastError();
     }
-    const hipError_t e2 = hipFreeAsync(spill, stream);
-    return e != hipSuccess ? e : e2;
+    return e;
 }
 
 }  // namespace
@@ -1171,8 +1194,11 @@ bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
     }
     if (in_span >= 0x7fffffffLL || out_span >= 0x7fffffffLL)   // 32-bit element offsets inside a volume
         return false;
-    // head + Q + max(box, D + P) must stay within a 64 KiB block
-    if (kOffQ + q_bytes(g) + 16 + (dp_bytes(g) > 32800 ? dp_bytes(g) : 32800) > (size_t)64 * 1024)
+    // head + Q + box must stay within a 64 KiB block; the per-call Q table within 512 MiB; the
+    // tables kernel keeps 3 * ncp_y * ncp_x doubles in LDS
+    if (kOffQ + q_bytes(g) + 16 + 32800 > (size_t)64 * 1024)
+        return false;
+    if (q_global_bytes(g) > ((size_t)512 << 20) || 24 * (size_t)g.ncp[1] * (size_t)g.ncp[2] > 48 * 1024)
         return false;
     return true;
 }

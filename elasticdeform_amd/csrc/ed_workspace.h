@@ -1,0 +1,23 @@
+// ed_workspace.h -- per-(device, stream) cached scratch buffers.
+//
+// The kernels need a little device scratch per call (spill worklists, the displacement tables of
+// the tile kernels, the fp64 line buffer of the exact prefilter).  hipMallocAsync / hipFreeAsync
+// per call costs hundreds of microseconds of host time on ROCm 7.2 -- more than the kernels -- so
+// scratch is kept: one buffer per (device, stream), grown on demand, reused by every later call on
+// that stream.  Work on one stream is ordered, so consecutive calls can share the buffer; growing
+// synchronises that stream once before the old buffer is released.  Buffers live until the
+// process exits.  The library stays re-entrant: the table is mutex-protected and calls on
+// different streams never share a buffer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace ed {
+
+// Returns a device pointer to at least `bytes` bytes of scratch owned by (current device, stream),
+// or nullptr with *err set.  The contents are unspecified.
+void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err);
+
+}  // namespace ed

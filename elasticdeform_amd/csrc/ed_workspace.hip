@@ -1,0 +1,61 @@
+#include "ed_workspace.h"
+
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace ed {
+
+namespace {
+struct Buffer {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+std::mutex g_mutex;
+std::map<std::pair<int, hipStream_t>, Buffer> g_buffers;
+}  // namespace
+
+void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
+{
+    *err = hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        *err = e;
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    Buffer& b = g_buffers[std::make_pair(dev, stream)];
+    if (b.cap >= bytes && b.ptr)
+        return b.ptr;
+    if (b.ptr) {
+        // earlier kernels on this stream may still be using the old buffer
+        e = hipStreamSynchronize(stream);
+        if (e == hipSuccess)
+            e = hipFree(b.ptr);
+        b.ptr = nullptr;
+        b.cap = 0;
+        if (e != hipSuccess) {
+            *err = e;
+            return nullptr;
+        }
+    }
+    // grow geometrically, 1 MiB granularity
+    size_t want = bytes + bytes / 4;
+    want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    e = hipMalloc(&b.ptr, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(&b.ptr, bytes);
+        want = bytes;
+    }
+    if (e != hipSuccess) {
+        b.ptr = nullptr;
+        *err = e;
+        return nullptr;
+    }
+    b.cap = want;
+    return b.ptr;
+}
+
+}  // namespace ed

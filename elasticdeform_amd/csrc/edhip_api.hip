@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "ed_params.h"
+#include "ed_workspace.h"
 #include "edhip.h"
 
 namespace {
@@ -326,17 +327,14 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
         if (lines > p.nlines)
             lines = p.nlines;
         p.ws_lines = lines;
-        void* ws = nullptr;
-        hipError_t e = hipMallocAsync(&ws, (size_t)lines * (size_t)p.len * 8, stream);
-        if (e != hipSuccess)
+        hipError_t e = hipSuccess;
+        void* ws = workspace_reserve(stream, (size_t)lines * (size_t)p.len * 8, &e);
+        if (!ws)
             return hip_fail(err, errlen, e, "scratch allocation");
         p.ws = (double*)ws;
         e = launch_spline_filter(p, stream);
-        const hipError_t e2 = hipFreeAsync(ws, stream);
         if (e != hipSuccess)
             return hip_fail(err, errlen, e, "spline filter launch");
-        if (e2 != hipSuccess)
-            return hip_fail(err, errlen, e2, "scratch release");
     } else {
         p.ws = nullptr;
         p.ws_lines = p.nlines;
