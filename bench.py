@@ -18,7 +18,8 @@ owns an independent volume (different seed), no data-path collective (the path s
 SURVEY.md section 8e) => weak scaling.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = K1 forward (deform_fast_kernel<float,3,3,fwd>), HBM-bound.
+  roofline      dominant kernel = K1 forward (deform_tile3_fwd_kernel<float,3,true> plus its tiny
+                tables / spill companions, i.e. one edhip_deform(gradient=0) call), HBM-bound.
                 achieved = algorithmic bytes per launch (8 B/voxel: 4 read + 4 written,
                 SURVEY.md 8d) / average launch duration, measured live with HIP events on the
                 stream the kernel is launched on; peak 8 TB/s.
@@ -167,6 +168,8 @@ def main():
     def timed(fn, iters):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(iters)]
+        for _ in range(2):      # untimed: first-use allocations of the torch caching allocator
+            fn()
         torch.cuda.synchronize()
         for a, b in evs:
             a.record()
@@ -229,7 +232,7 @@ def main():
                        "parallelism": "1 volume per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                         "kernel": "K1 forward deform (edhip_deform gradient=0, prefiltered input)",
+                         "kernel": "K1 forward deform: deform_tile3_fwd_kernel<float,3,true> (one edhip_deform gradient=0 call on the prefiltered input)",
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "avg_launch_us": round(k1_ms * 1e3, 2),
                          "median_launch_us": round(k1_med * 1e3, 2)},

@@ -1,0 +1,69 @@
+// dev tool: calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE on MI355X for the access patterns of the
+// tile kernels (16-byte lanes in 64-byte runs; 4-byte lanes in 32-byte runs).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+
+// read: every 16-byte chunk of buf exactly once; lanes 4q..4q+3 read one 64-byte run, consecutive
+// runs of a wave are `run_stride` floats apart (mimics staging rows of a box)
+__global__ void rd16_runs(const float* buf, size_t nchunks, int run_stride_chunks, float* sink)
+{
+    size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    float acc = 0;
+    for (; id < nchunks; id += (size_t)gridDim.x * blockDim.x) {
+        // permute runs so that neighbouring lanes-of-4 hit rows far apart
+        size_t run = id >> 2, q = id & 3;
+        size_t nruns = nchunks >> 2;
+        size_t prun = (run * (size_t)run_stride_chunks) % nruns;   // stride coprime with nruns
+        const F4u v = *reinterpret_cast<const F4u*>(buf + (prun * 4 + q) * 4);
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == -1.f) *sink = acc;
+}
+__global__ void rd16_stream(const float4* buf, size_t n, float* sink)
+{
+    size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    float acc = 0;
+    for (; id < n; id += (size_t)gridDim.x * blockDim.x) { float4 v = buf[id]; acc += v.x + v.w; }
+    if (acc == -1.f) *sink = acc;
+}
+__global__ void rd4_stream(const float* buf, size_t n, float* sink)
+{
+    size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    float acc = 0;
+    for (; id < n; id += (size_t)gridDim.x * blockDim.x) acc += buf[id];
+    if (acc == -1.f) *sink = acc;
+}
+// write: 4-byte lanes; groups of 8 lanes write one 32-byte run; runs of a wave land in 8 different
+// 128-byte lines (mimics the 8-wide x rows of an output tile), every byte written exactly once
+__global__ void wr4_runs32(float* buf, size_t n)
+{
+    size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; id < n; id += (size_t)gridDim.x * blockDim.x) {
+        size_t run = id >> 3, e = id & 7;
+        size_t nruns = n >> 3;
+        size_t prun = (run * 1031) % nruns;
+        buf[prun * 8 + e] = 1.0f;
+    }
+}
+__global__ void wr4_stream(float* buf, size_t n)
+{
+    size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; id < n; id += (size_t)gridDim.x * blockDim.x) buf[id] = 1.0f;
+}
+int main()
+{
+    const size_t bytes = (size_t)1 << 30;       // 1 GiB: larger than the 256 MiB Infinity Cache
+    float* buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 0, bytes));
+    float* sink; CK(hipMalloc(&sink, 4));
+    const size_t nf = bytes / 4, n16 = bytes / 16;
+    hipLaunchKernelGGL(rd4_stream, dim3(4096), dim3(256), 0, 0, buf, nf, sink);
+    hipLaunchKernelGGL(rd16_stream, dim3(4096), dim3(256), 0, 0, (const float4*)buf, n16, sink);
+    hipLaunchKernelGGL(rd16_runs, dim3(4096), dim3(256), 0, 0, buf, n16, 1031, sink);
+    hipLaunchKernelGGL(wr4_stream, dim3(4096), dim3(256), 0, 0, buf, nf);
+    hipLaunchKernelGGL(wr4_runs32, dim3(4096), dim3(256), 0, 0, buf, nf);
+    CK(hipDeviceSynchronize());
+    printf("each kernel touches %zu bytes exactly once\n", bytes);
+    return 0;
+}
