@@ -64,12 +64,11 @@ struct __attribute__((packed, aligned(4))) F4u {
 static_assert(sizeof(AxTab) == 48, "AxTab layout");
 
 // LDS carve (bytes)
-constexpr int kOffTabZY = 0;                              // [2][8] AxTab
-constexpr int kOffTabX = 2 * kT * 48;                     // [kStrip][8] AxTab
+constexpr int kOffTabX = 0;                               // [kStrip][8] AxTab
 constexpr int kOffRed = kOffTabX + kStrip * kT * 48;      // int[2][8]: lo[3], hi[3], -, -
 constexpr int kOffSum = kOffRed + 64;                     // float[2][4]: per-wave sum |dY| (K2)
 constexpr int kOffHot = kOffSum + 32;                     // HotParams (uniform values kept out of SGPRs)
-constexpr int kOffQ = kOffHot + 512;
+constexpr int kOffQ = kOffHot + 416;
 static_assert(kOffQ % 16 == 0, "LDS carve alignment");
 
 // Uniform per-call values the per-voxel code needs.  Kept in LDS and fetched with broadcast reads:
@@ -87,7 +86,7 @@ struct HotParams {
     int nstep;
     int pad_;
 };
-static_assert(sizeof(HotParams) <= 512, "HotParams must fit its LDS slot");
+static_assert(sizeof(HotParams) <= 416, "HotParams must fit its LDS slot");
 
 __device__ __forceinline__ int mirror_i32(int idx, int len)
 {
@@ -275,7 +274,7 @@ struct TileGeom {
     int tiles[3];         // number of tiles per axis
     int strips_x;         // strips per tile row
     int nstrips;
-    int lg_nyx, lg_nx;    // log2 of ncp_y*ncp_x and ncp_x padded to powers of two
+    int ncpx;             // control points along x = stride of one component row of Q
     int box_cap;          // elements per LDS copy
     int off_ov;           // LDS byte offset of the overlay region (box | D, P)
     int in_stride[3];     // element strides (the tile kernels require < 2^31 elements per volume)
@@ -287,7 +286,7 @@ struct TileGeom {
     double inv_period[3];
     double affine[12];    // inverse map, 3 x 4
     int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
-    const double* q_global;   // [O_z][O_y][3][1 << lg_nx]: displacement contracted over z and y
+    const double* q_global;   // [O_z][O_y][3][ncpx]: displacement contracted over z and y
     const AxTab* xt_global;   // [O_x]: cubic weights / control indices along x
     int dbg;              // ablation switches for profiling (EDHIP_TILE_DBG), 0 in production
 };
@@ -369,14 +368,14 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     for (int oy = tid; oy < tg.out_len[1]; oy += kBlock) {
         AxTab ty;
         entry(1, oy, ty);
-        double* row = q + (((int64_t)oz * tg.out_len[1] + oy) * 3 << tg.lg_nx);
+        double* row = q + ((int64_t)oz * tg.out_len[1] + oy) * 3 * ncpx;
         for (int h = 0; h < 3; ++h)
             for (int j2 = 0; j2 < ncpx; ++j2) {
                 double acc = 0.0;
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
                     acc += ty.w[l] * sP[h * nyx + ty.idx[l] * ncpx + j2];
-                row[(h << tg.lg_nx) + j2] = acc;
+                row[h * ncpx + j2] = acc;
             }
     }
 }
@@ -399,7 +398,7 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& 
             dst[e] = e < avail ? src[e] : 0;
     }
     {   // Q rows: (zi, yy) -> global row (oz, oy); 4 threads per row
-        const int rowlen = 3 << tg.lg_nx;
+        const int rowlen = 3 * tg.ncpx;
         const int r = tid >> 2;
         const int oz = min(sp.tz * kT + (r >> 3), tg.out_len[0] - 1);
         const int oy = min(sp.ty * kT + (r & 7), tg.out_len[1] - 1);
@@ -443,7 +442,7 @@ __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const HotParams
     bool oob = false;
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
-        const double* qrow = sQ + (((zi * kT + yy) * 3 + h) << tg.lg_nx);
+        const double* qrow = sQ + ((zi * kT + yy) * 3 + h) * tg.ncpx;
         double d = 0.0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
@@ -515,7 +514,7 @@ __device__ __forceinline__ void step_offsets(const IOView& v, int64_t ss, int64_
 // K1: forward
 // ================================================================================================
 template <typename T, int ORDER, bool PAIR>
-__global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridGeom g,
+__global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridGeom g,
                                                                      const IOView v,
                                                                      const TileGeom tg)
 {
@@ -531,7 +530,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_fwd_kernel(const GridG
     const double* sQ = reinterpret_cast<const double*>(smem + kOffQ);
     const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
     T* box0 = reinterpret_cast<T*>(smem + tg.off_ov);
-    T* box1 = box0 + tg.box_cap + 8;      // +8 elements: the two copies sit on disjoint LDS banks
+    T* box1 = box0 + tg.box_cap;          // cap = 56 (mod 64): the two copies sit on disjoint LDS banks
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1073,10 +1072,10 @@ inline int ceil_log2(int64_t n)
     return l;
 }
 
-inline size_t q_bytes(const GridGeom& g) { return 8 * ((size_t)(kT * kT * 3) << ceil_log2(g.ncp[2])); }
+inline size_t q_bytes(const GridGeom& g) { return 8 * (size_t)(kT * kT * 3) * (size_t)g.ncp[2]; }
 inline size_t q_global_bytes(const GridGeom& g)
 {
-    return 8 * (((size_t)g.out_len[0] * (size_t)g.out_len[1] * 3) << ceil_log2(g.ncp[2]));
+    return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 3 * (size_t)g.ncp[2];
 }
 
 template <typename T, int ORDER, bool PAIR, bool GRAD>
@@ -1113,8 +1112,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     if (ntiles > 0x3fffffffLL)
         return hipErrorInvalidValue;
     tg.nstrips = (int)nstrips;
-    tg.lg_nyx = ceil_log2(g.ncp[1] * g.ncp[2]);
-    tg.lg_nx = ceil_log2(g.ncp[2]);
+    tg.ncpx = (int)g.ncp[2];
     // LDS: head | Q | overlay (box | D, P).  K1 float32 odd orders: two shifted copies of 4096
     // elements; otherwise one copy (6144 x 4 bytes or 4096 x 8 bytes)
     size_t box;
@@ -1122,8 +1120,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         tg.box_cap = 8192;
         box = 8192 * 4;
     } else if (PAIR) {
-        tg.box_cap = 4096;
-        box = (2 * 4096 + 8) * sizeof(T);
+        tg.box_cap = 3704;      // 57 * 64 + 56; two copies + head + Q stay under 40 KiB -> 4 blocks per CU
+        box = 2 * 3704 * sizeof(T);
     } else {
         tg.box_cap = sizeof(T) == 4 ? 6144 : 4096;
         box = (size_t)tg.box_cap * sizeof(T);
@@ -1196,7 +1194,7 @@ bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
         return false;
     // head + Q + box must stay within a 64 KiB block; the per-call Q table within 512 MiB; the
     // tables kernel keeps 3 * ncp_y * ncp_x doubles in LDS
-    if (kOffQ + q_bytes(g) + 16 + 32800 > (size_t)64 * 1024)
+    if (kOffQ + q_bytes(g) + 16 + 32768 > (size_t)64 * 1024)
         return false;
     if (q_global_bytes(g) > ((size_t)512 << 20) || 24 * (size_t)g.ncp[1] * (size_t)g.ncp[2] > 48 * 1024)
         return false;
