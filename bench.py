@@ -185,7 +185,7 @@ def main():
 
     # K1 alone: prefiltered inputs prepared once, then only edhip_deform(gradient=0) between events
     Xf = dgm._filter_axes(X, [0, 1, 2], 3, False, dev)
-    df = dgm._prefilter_displacement(disp, dev)
+    df = dgm._filter_axes(disp, [1, 2, 3], 3, False, dev)
     out = torch.empty_like(X)
     dxs = torch.zeros_like(X)
     stream = torch.cuda.current_stream(dev).cuda_stream

@@ -16,6 +16,8 @@ MAX_DIMS = 8
 MAX_AXES = 4
 
 FLAG_AUTO, FLAG_EXACT, FLAG_FAST = 0, 1, 2
+FLAG_RAW_DISPLACEMENT = 4      # edhip_deform prefilters the control grid itself (<= 4096 points)
+RAW_DISPLACEMENT_MAX_POINTS = 4096
 
 # enum edhip_dtype
 DTYPE_CODES = {

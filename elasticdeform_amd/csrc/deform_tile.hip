@@ -1139,9 +1139,12 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     const size_t spill_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
     const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
     hipError_t e = hipSuccess;
-    void* ws = workspace_reserve(stream, spill_bytes + xt_bytes + q_global_bytes(g), &e);
+    // (edhip_deform reserved deform_tile_workspace_bytes() up front, so this does not move the
+    // prefiltered control grid that may sit in the head of the workspace)
+    void* ws = workspace_reserve(stream, kWorkspaceGridBytes + spill_bytes + xt_bytes + q_global_bytes(g), &e);
     if (!ws)
         return e;
+    ws = (char*)ws + kWorkspaceGridBytes;
     tg.spill = (int*)ws;
     tg.xt_global = (const AxTab*)((char*)ws + spill_bytes);
     tg.q_global = (const double*)((char*)ws + spill_bytes + xt_bytes);
@@ -1172,6 +1175,21 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
 }
 
 }  // namespace
+
+size_t deform_tile_workspace_bytes(const GridGeom& g)
+{
+    if (g.naxis != 3)
+        return kWorkspaceGridBytes;
+    int64_t ntiles = 1;
+    for (int k = 0; k < 3; ++k)
+        ntiles *= (g.out_len[k] + kT - 1) / kT;
+    const size_t spill_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
+    const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
+    const size_t q = q_global_bytes(g);
+    if (q > ((size_t)512 << 20))
+        return kWorkspaceGridBytes;
+    return kWorkspaceGridBytes + spill_bytes + xt_bytes + q;
+}
 
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
 {

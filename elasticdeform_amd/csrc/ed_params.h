@@ -56,6 +56,7 @@ bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient);
 // LDS-tiled forward kernel (3 deformed axes, order >= 2): the benchmark's hot kernel.
 hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient);
+size_t deform_tile_workspace_bytes(const GridGeom& g);   // scratch the tile path will ask for
 
 struct FilterParams {
     const char* in;
@@ -79,6 +80,22 @@ struct FilterParams {
 };
 
 hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream);
+
+// one-launch order-3 prefilter of a small control grid along every axis but the first
+struct GridPrefilter {
+    const char* in;
+    char* out;               // contiguous, same dtype
+    int dtype, elem_size;
+    int ndim, total;
+    int shape[kMaxAxes + 1];
+    int64_t stride_bytes[kMaxAxes + 1];
+    double pole, gain;
+    double pole_pow[kMaxAxes + 1];   // pole^(shape[ax] - 1), host libm
+};
+hipError_t launch_grid_prefilter(const GridPrefilter& p, hipStream_t stream);
+
+// first bytes of every per-stream workspace are reserved for the prefiltered control grid
+constexpr size_t kWorkspaceGridBytes = 64 * 1024;
 
 // fast path (orders 2/3, float32/float64, lines >= 64 samples, no scratch); hipErrorNotSupported
 // (nothing launched) when the case is outside its envelope

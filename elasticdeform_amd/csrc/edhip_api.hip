@@ -145,6 +145,43 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
     }
     for (int k = 0; k <= naxis; ++k)
         g.disp_stride[k] = displacement->stride_bytes[k];
+    if (flags & EDHIP_FLAG_RAW_DISPLACEMENT) {
+        // prefilter the raw control grid into the head of the stream's workspace (one launch)
+        int64_t total = 1;
+        for (int k = 0; k <= naxis; ++k)
+            total *= displacement->shape[k];
+        if (total > 4096)
+            return fail(err, errlen, EDHIP_ERR_UNSUPPORTED,
+                        "raw displacement grids are limited to 4096 points");
+        // reserve everything this call can need now: a later, larger request would move the buffer
+        // and lose the grid
+        hipError_t e = hipSuccess;
+        void* ws = workspace_reserve(stream, deform_tile_workspace_bytes(g), &e);
+        if (!ws)
+            return hip_fail(err, errlen, e, "scratch allocation");
+        GridPrefilter gp;
+        memset(&gp, 0, sizeof(gp));
+        gp.in = (const char*)displacement->data;
+        gp.out = (char*)ws;
+        gp.dtype = displacement->dtype;
+        gp.elem_size = dtype_size(displacement->dtype);
+        gp.ndim = naxis + 1;
+        gp.total = (int)total;
+        gp.pole = -0.267949192431122706472553658494127633;      // order 3, SciPy's literal
+        gp.gain = (1.0 - gp.pole) * (1.0 - 1.0 / gp.pole);
+        int64_t stride = gp.elem_size;
+        for (int k = naxis; k >= 0; --k) {
+            gp.shape[k] = (int)displacement->shape[k];
+            gp.stride_bytes[k] = displacement->stride_bytes[k];
+            gp.pole_pow[k] = std::pow(gp.pole, (double)(gp.shape[k] - 1));
+            g.disp_stride[k] = stride;
+            stride *= gp.shape[k];
+        }
+        e = launch_grid_prefilter(gp, stream);
+        if (e != hipSuccess)
+            return hip_fail(err, errlen, e, "grid prefilter launch");
+        g.disp = (const char*)ws;
+    }
     if (affine)
         for (int k = 0; k < naxis * (naxis + 1); ++k)
             g.affine[k] = affine[k];
@@ -328,10 +365,10 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
             lines = p.nlines;
         p.ws_lines = lines;
         hipError_t e = hipSuccess;
-        void* ws = workspace_reserve(stream, (size_t)lines * (size_t)p.len * 8, &e);
+        void* ws = workspace_reserve(stream, kWorkspaceGridBytes + (size_t)lines * (size_t)p.len * 8, &e);
         if (!ws)
             return hip_fail(err, errlen, e, "scratch allocation");
-        p.ws = (double*)ws;
+        p.ws = (double*)((char*)ws + kWorkspaceGridBytes);
         e = launch_spline_filter(p, stream);
         if (e != hipSuccess)
             return hip_fail(err, errlen, e, "spline filter launch");

@@ -179,7 +179,81 @@ __global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterPa
     }
 }
 
+// Whole-grid order-3 prefilter of a small control grid (<= 4096 points) in ONE launch: the grid
+// sits in LDS as doubles, every grid axis is filtered in turn by the same sequential recursion
+// as prefilter_kernel (one thread per line), and after each axis the values are rounded to the
+// grid's storage dtype exactly like the reference's per-axis `output=displacement_f` round trip
+// (deform_grid.py:166-169).  Output: contiguous [naxis][ncp...] array of the same dtype.
+__global__ __launch_bounds__(256) void grid_prefilter_kernel(const GridPrefilter p)
+{
+    __shared__ double s[4096];
+    const int tid = threadIdx.x;
+    const int total = p.total;
+    // gather (arbitrary strides) -> LDS, C order
+    for (int e = tid; e < total; e += 256) {
+        int r = e;
+        int64_t off = 0;
+        for (int d = p.ndim - 1; d >= 0; --d) {
+            const int q = r / p.shape[d];
+            off += (int64_t)(r - q * p.shape[d]) * p.stride_bytes[d];
+            r = q;
+        }
+        s[e] = load_as_double(p.in + off, p.dtype);
+    }
+    __syncthreads();
+    const double z = p.pole, gain = p.gain;
+    for (int ax = 1; ax < p.ndim; ++ax) {
+        const int n = p.shape[ax];
+        int inner = 1;
+        for (int d = ax + 1; d < p.ndim; ++d)
+            inner *= p.shape[d];
+        const int nlines = total / n;
+        if (n >= 2) {
+            const double zn1 = p.pole_pow[ax];
+            for (int line = tid; line < nlines; line += 256) {
+                const int outer = line / inner, in = line - outer * inner;
+                double* c = s + (int64_t)outer * n * inner + in;     // element i at c[i * inner]
+                for (int i = 0; i < n; ++i)
+                    c[i * inner] *= gain;
+                double c0 = c[0] + zn1 * c[(n - 1) * inner];
+                double zi = z;
+                for (int i = 1; i < n - 1; ++i) {
+                    c0 += zi * (c[i * inner] + zn1 * c[(n - 1 - i) * inner]);
+                    zi *= z;
+                }
+                c0 /= 1 - zn1 * zn1;
+                c[0] = c0;
+                for (int i = 1; i < n; ++i)
+                    c[i * inner] += z * c[(i - 1) * inner];
+                c[(n - 1) * inner] = (z * c[(n - 2) * inner] + c[(n - 1) * inner]) * z / (z * z - 1);
+                for (int i = n - 2; i >= 0; --i)
+                    c[i * inner] = z * (c[(i + 1) * inner] - c[i * inner]);
+            }
+        }
+        __syncthreads();
+        // round trip through the storage dtype after every axis (plain C cast, as the line
+        // buffer write-back does)
+        if (p.dtype != EDHIP_F64) {
+            for (int e = tid; e < total; e += 256) {
+                char tmp[8];
+                store_cast(tmp, p.dtype, s[e]);
+                s[e] = load_as_double(tmp, p.dtype);
+            }
+            __syncthreads();
+        }
+    }
+    const int esz = p.elem_size;
+    for (int e = tid; e < total; e += 256)
+        store_cast(p.out + (int64_t)e * esz, p.dtype, s[e]);
+}
+
 }  // namespace
+
+hipError_t launch_grid_prefilter(const GridPrefilter& p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(grid_prefilter_kernel, dim3(1), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
 {

@@ -127,10 +127,16 @@ def _filter_axes(x, axes, order, transpose, device):
 
 def _prefilter_displacement(displacement, device):
     """Order-3 prefilter of the control grid along every grid axis (deform_grid.py:166-169,
-    :269-272); the output keeps the displacement's dtype like numpy.zeros_like there."""
+    :269-272); the output keeps the displacement's dtype like numpy.zeros_like there.
+
+    Returns (grid, extra_flags): small grids (the normal case) are handed over raw and filtered
+    inside edhip_deform in a single launch (EDHIP_FLAG_RAW_DISPLACEMENT, same arithmetic and the
+    same per-axis rounding); larger ones go through edhip_spline_filter1d axis by axis."""
     if displacement.ndim < 2:
-        return displacement
-    return _filter_axes(displacement, range(1, displacement.ndim), 3, False, device)
+        return displacement, 0
+    if displacement.numel() <= _lib.RAW_DISPLACEMENT_MAX_POINTS:
+        return displacement, _lib.FLAG_RAW_DISPLACEMENT
+    return _filter_axes(displacement, range(1, displacement.ndim), 3, False, device), 0
 
 
 def deform_random_grid(X, sigma=25, points=3, order=3, mode='constant', cval=0.0,
@@ -174,7 +180,7 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
         Xf = [(_filter_axes(x, plan.axis[i], int(plan.order[i]), False, device)
                if prefilter and plan.order[i] > 1 else x) for i, x in enumerate(Xd)]
         # ... and always the displacement (deform_grid.py:166-169)
-        df = _prefilter_displacement(dd, device)
+        df, dflag = _prefilter_displacement(dd, device)
 
         # every output element is written by the kernel (value or cval), so no zero fill is needed
         outs = [torch.empty(tuple(int(s) for s in shape), dtype=x.dtype, device=device)
@@ -182,7 +188,7 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
 
         _lib.deform(False, [_desc(x) for x in Xf], _desc(df), plan.output_offset,
                     [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine, _flags, _stream(device))
+                    plan.inverse_affine, _flags | dflag, _stream(device))
         res = [_from_device(o, x) for o, x in zip(outs, Xs)]
     return res if isinstance(X, list) else res[0]
 
@@ -219,11 +225,11 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
                              % (str(plan.output_shapes), str([tuple(dy.shape) for dy in dYs])))
 
         dd = _to_device(displacement, device)
-        df = _prefilter_displacement(dd, device)
+        df, dflag = _prefilter_displacement(dd, device)
 
         _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
                     [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine, _flags, _stream(device))
+                    plan.inverse_affine, _flags | dflag, _stream(device))
 
         # gradient of the prefilter: its transpose along each deformed axis (deform_grid.py:276-286)
         dXf = [(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device)

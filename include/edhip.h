@@ -94,7 +94,13 @@ enum edhip_status {
 enum edhip_flags {
     EDHIP_FLAG_AUTO = 0,       /* f32 data -> fast path; every other dtype -> exact path */
     EDHIP_FLAG_EXACT = 1,      /* fp64 arithmetic in the reference's own evaluation order (bit-comparable) */
-    EDHIP_FLAG_FAST = 2        /* fp64 coordinates, restructured (separable) sums, data-width tap accumulation */
+    EDHIP_FLAG_FAST = 2,       /* fp64 coordinates, restructured (separable) sums, data-width tap accumulation */
+    /* edhip_deform only: `displacement` is the RAW control grid; the library applies the order-3
+     * mirror prefilter along every grid axis itself (what deform_grid.py:166-169,269-272 does with
+     * SciPy before calling the C code), in one launch, with the same arithmetic and the same
+     * per-axis rounding to the grid's dtype.  Grids of more than 4096 points are refused
+     * (EDHIP_ERR_UNSUPPORTED): prefilter those with edhip_spline_filter1d. */
+    EDHIP_FLAG_RAW_DISPLACEMENT = 4
 };
 
 /* strided N-d array in device memory: the POD stand-in for PyArrayObject* */

@@ -320,3 +320,22 @@ def test_fast_prefilter_kernels():
                     want = scipy.ndimage.spline_filter1d(x.T.astype(np.float64), order=order, axis=1)
                     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0,
                                                atol=tol * np.abs(want).max())
+
+
+def test_raw_displacement_flag_equals_explicit_prefilter():
+    """EDHIP_FLAG_RAW_DISPLACEMENT (one-launch prefilter of the control grid inside edhip_deform)
+    must equal the per-axis prefilter bit for bit, including the per-axis rounding to the grid's
+    own dtype (float32 grids) that deform_grid.py:166-169 implies."""
+    rng = np.random.default_rng(31)
+    X = rng.random((20, 24, 22))
+    for ddt in (np.float64, np.float32):
+        for pts in ((3, 3, 3), (2, 5, 4), (1, 3, 6)):
+            disp = (rng.standard_normal((3,) + pts) * 2).astype(ddt)
+            want = orc.deform_grid(X, disp, order=3, mode="mirror")
+            got = ed.deform_grid(X, disp, order=3, mode="mirror")
+            np.testing.assert_array_equal(got, want)
+    # 2-D, float32 image through the fast kernels, float32 grid
+    Y = rng.random((70, 90)).astype(np.float32)
+    disp = (rng.standard_normal((2, 4, 3)) * 3).astype(np.float32)
+    np.testing.assert_allclose(ed.deform_grid(Y, disp, order=3), orc.deform_grid(Y, disp, order=3),
+                               **F32_TOL)
