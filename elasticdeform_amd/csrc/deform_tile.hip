@@ -232,9 +232,13 @@ __device__ __forceinline__ void weights_from_frac(T x, T* w)
         const T y = (T)0.5 - x;
         w[0] = (T)0.5 * y * y;
     } else if (ORDER == 3) {
-        w[1] = (x * x * (x - (T)2) * (T)3 + (T)4) * (T)(1.0 / 6.0);
-        w[2] = (z * z * (z - (T)2) * (T)3 + (T)4) * (T)(1.0 / 6.0);
-        w[0] = z * z * z * (T)(1.0 / 6.0);
+        // all four cubic pieces in closed form (cheaper than "last = 1 - sum"; same polynomials)
+        const T x2 = x * x, z2 = z * z;
+        w[0] = z2 * z * (T)(1.0 / 6.0);
+        w[3] = x2 * x * (T)(1.0 / 6.0);
+        w[1] = x2 * (x * (T)0.5 - (T)1) + (T)(2.0 / 3.0);
+        w[2] = z2 * (z * (T)0.5 - (T)1) + (T)(2.0 / 3.0);
+        return;
     } else if (ORDER == 4) {
         T t = x * x;
         w[2] = t * (t * (T)0.25 - (T)0.625) + (T)(115.0 / 192.0);
@@ -438,7 +442,8 @@ __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const HotParams
                                              const AxTab& tx_, int zi, int yy, const int* o,
                                              int* start, T* frac)
 {
-    double c[3];
+    double c[3], fl[3];
+    int ci[3];
     bool oob = false;
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
@@ -447,17 +452,20 @@ __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const HotParams
 #pragma unroll
         for (int l = 0; l < 4; ++l)
             d = fma(tx_.w[l], qrow[tx_.idx[l]], d);
-        double b;
         if (tg.has_affine) {
-            b = hp->affine[h * 4 + 3];
+            double b = hp->affine[h * 4 + 3];
 #pragma unroll
             for (int l = 0; l < 3; ++l)
                 b = fma(hp->affine[h * 4 + l], (double)o[l], b);
+            c[h] = b + hp->offd[h] + d;
         } else {
-            b = (double)o[h];
+            c[h] = (double)(o[h] + tg.off[h]) + d;      // the crop offset folds into the integer
         }
-        c[h] = b + hp->offd[h] + d;
-        oob = oob || c[h] < 0.0 || c[h] > hp->last[h];
+        fl[h] = floor((ORDER & 1) ? c[h] : c[h] + 0.5);
+        ci[h] = (int)fl[h];
+        // in range <=> 0 <= c < I-1 (c == I-1 exactly takes the slow path, which leaves it alone)
+        const int lim = (ORDER & 1) ? tg.in_len[h] - 1 : tg.in_len[h];
+        oob = oob || (unsigned)ci[h] >= (unsigned)lim || ((ORDER & 1) == 0 && (c[h] < 0.0 || c[h] > hp->last[h]));
     }
     bool cst = false;
     if (oob) {
@@ -467,13 +475,14 @@ __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const HotParams
             c[h] = map_coordinate_fast(c[h], (int)hp->last[h] + 1, tg.mode, hp->period[h],
                                        hp->inv_period[h]);
             cst = cst || !(c[h] > -1.0);
+            fl[h] = floor((ORDER & 1) ? c[h] : c[h] + 0.5);
+            ci[h] = (int)fl[h];
         }
     }
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
-        const double fl = floor((ORDER & 1) ? c[h] : c[h] + 0.5);
-        start[h] = cst ? 0 : (int)fl - ORDER / 2;
-        frac[h] = (T)(c[h] - fl);
+        start[h] = cst ? 0 : ci[h] - ORDER / 2;
+        frac[h] = (T)(c[h] - fl[h]);
     }
     return cst;
 }
