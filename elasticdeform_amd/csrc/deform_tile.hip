@@ -736,8 +736,11 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                     val = a0;
                 }
                 const int oz = o0[0] + wave + 4 * i, oy = o0[1] + yy, ox = o0[2] + xx;
-                out[out_off + (oz * tg.out_stride[0] + oy * tg.out_stride[1] + ox * tg.out_stride[2])] =
-                    val;
+                T* optr = out + (out_off + (oz * tg.out_stride[0] + oy * tg.out_stride[1] + ox * tg.out_stride[2]));
+                if (tg.dbg & 256)
+                    __builtin_nontemporal_store(val, optr);
+                else
+                    *optr = val;
             }
         }
     }

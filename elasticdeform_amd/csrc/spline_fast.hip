@@ -27,6 +27,7 @@
 //
 // Algorithmic bytes: 2 * sizeof(T) per sample per axis; the 32-sample warm-ups are re-reads that
 // hit L2.
+#include <cstdlib>
 #include <cstring>
 
 #include "ed_device.h"
@@ -122,7 +123,9 @@ __device__ __forceinline__ double warm_anticausal(const T (&xs)[kK], double z)
 }
 
 // ---- lines along a strided axis: lane <-> line ---------------------------------------------------
-template <typename T>
+// UNIT: the filtered axis itself is contiguous (element stride 1 in and out).  A lane still owns a
+// line, but its 64 / 32 consecutive samples move as 16-byte vector loads / stores.
+template <typename T, bool UNIT>
 __global__ __launch_bounds__(kBlock) void prefilter_fast_strided_kernel(const FastFilter p)
 {
     const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void prefilter_fast_strided_kernel(const Fa
 
     auto sample = [&](int64_t j) -> T {
         const int64_t i = ext_index(j, n, tr);
-        return i >= 0 ? src[i * p.in_axis_stride] : (T)0;
+        return i >= 0 ? src[UNIT ? i : i * p.in_axis_stride] : (T)0;
     };
 
     double ya_next;
@@ -165,10 +168,10 @@ __global__ __launch_bounds__(kBlock) void prefilter_fast_strided_kernel(const Fa
     for (int64_t b = e - kB; b >= a; b -= kB) {
         T xs[kK + kB];
         if (b - kK >= 0 && b + kB <= n) {          // interior block (wave-uniform): plain loads
-            const T* q = src + (b - kK) * p.in_axis_stride;
+            const T* q = src + (b - kK) * (UNIT ? 1 : p.in_axis_stride);
 #pragma unroll
             for (int k = 0; k < kK + kB; ++k)
-                xs[k] = q[k * p.in_axis_stride];
+                xs[k] = q[UNIT ? k : k * p.in_axis_stride];
         } else {
 #pragma unroll
             for (int k = 0; k < kK + kB; ++k)
@@ -203,10 +206,16 @@ __global__ __launch_bounds__(kBlock) void prefilter_fast_strided_kernel(const Fa
                 }
             }
         }
+        if (UNIT && b + kB <= n) {
 #pragma unroll
-        for (int k = 0; k < kB; ++k)
-            if (b + k < n)
-                dst[(b + k) * p.out_axis_stride] = (T)o[k];
+            for (int k = 0; k < kB; ++k)
+                dst[b + k] = (T)o[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kB; ++k)
+                if (b + k < n)
+                    dst[(b + k) * (UNIT ? 1 : p.out_axis_stride)] = (T)o[k];
+        }
     }
 }
 
@@ -412,7 +421,18 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
     p.seg_len = seg_blocks * kB;
     p.nseg = (int)((nblocks_line + seg_blocks - 1) / seg_blocks);
 
-    if (contig) {
+    if (contig && !getenv("EDHIP_CONTIG_LDS")) {
+        const int64_t threads = p.nlines * p.nseg;
+        const int64_t nblk = (threads + kBlock - 1) / kBlock;
+        if (nblk > 0x7fffffffLL)
+            return hipErrorNotSupported;
+        if (fp.in_dtype == EDHIP_F32)
+            hipLaunchKernelGGL((prefilter_fast_strided_kernel<float, true>), dim3((unsigned)nblk),
+                               dim3(kBlock), 0, stream, p);
+        else
+            hipLaunchKernelGGL((prefilter_fast_strided_kernel<double, true>), dim3((unsigned)nblk),
+                               dim3(kBlock), 0, stream, p);
+    } else if (contig) {
         const int64_t groups = (p.nlines + 63) / 64;
         const int64_t waves = groups * p.nseg;
         const int wpb = fp.in_dtype == EDHIP_F32 ? contig_waves<float>() : contig_waves<double>();
@@ -431,10 +451,10 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
         if (nblk > 0x7fffffffLL)
             return hipErrorNotSupported;
         if (fp.in_dtype == EDHIP_F32)
-            hipLaunchKernelGGL(prefilter_fast_strided_kernel<float>, dim3((unsigned)nblk),
+            hipLaunchKernelGGL((prefilter_fast_strided_kernel<float, false>), dim3((unsigned)nblk),
                                dim3(kBlock), 0, stream, p);
         else
-            hipLaunchKernelGGL(prefilter_fast_strided_kernel<double>, dim3((unsigned)nblk),
+            hipLaunchKernelGGL((prefilter_fast_strided_kernel<double, false>), dim3((unsigned)nblk),
                                dim3(kBlock), 0, stream, p);
     }
     return hipGetLastError();
