@@ -522,7 +522,9 @@ __device__ __forceinline__ void step_offsets(const IOView& v, int64_t ss, int64_
 // ================================================================================================
 // K1: forward
 // ================================================================================================
-template <typename T, int ORDER, bool PAIR>
+// ABL: compile-time ablation switches for profiling (0 in production): 1 skip staging loads,
+// 2 skip gather, 4 skip coordinates, 16 prologue only, 32 skip staging entirely
+template <typename T, int ORDER, bool PAIR, int ABL = 0>
 __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridGeom g,
                                                                      const IOView v,
                                                                      const TileGeom tg)
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
     const int yy = lane >> 3, xx = lane & 7;
     const T* __restrict__ in = reinterpret_cast<const T*>(v.in);
     T* out = reinterpret_cast<T*>(v.out);
-    if (tg.dbg & 16)
+    if (ABL & 16)
         return;
 
     for (int ti = 0; ti < sp.ntile; ++ti) {
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
             const int zi = wave + 4 * i;
             const int o[3] = {o0[0] + zi, o0[1] + yy, o0[2] + xx};
             valid[i] = o[0] < tg.out_len[0] && o[1] < tg.out_len[1] && o[2] < tg.out_len[2];
-            if (tg.dbg & 4) {
+            if (ABL & 4) {
                 constant[i] = false;
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
         const bool x_inside = b0[2] >= 0 && b0[2] + ext[2] <= tg.in_len[2];
         // the whole padded row (and its one-element shift) lies inside the line: vector staging
         const bool wide = tg.in_stride[2] == 1 && b0[2] >= 0 && b0[2] + pitch + 1 <= tg.in_len[2] &&
-                          !(tg.dbg & 1);
+                          !(ABL & 1);
         const float inv_by = 1.0f / (float)by;
 
         for (int64_t ss = 0; ss < v.nsteps; ++ss) {
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
             step_offsets(hp, ss, in_off, out_off);
             const T* src = in + in_off;
 
-            if (any && !(tg.dbg & 32)) {
+            if (any && !(ABL & 32)) {
                 // ---- phase C: stage the source box (mirror-mapped) into LDS ----------------------
                 if (ss > 0)
                     __syncthreads();     // previous step's gathers are done with the box
@@ -636,10 +638,11 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                     // r (4 / 12 chunks per row, consecutive lanes -> consecutive chunks: global
                     // reads are 64-byte runs, LDS writes conflict-free b128); the shifted copy is a
                     // second, 4-byte-offset load of the same run.
-                    const int cpr = pitch >> 2;
+                    const int cpr = pitch >> 2;              // 2, 4, 6, 10, 12 or 14 chunks per row
                     const int total = nrows * cpr;
+                    const float inv_cpr = 1.0f / (float)cpr;
                     for (int idx = tid; idx < total; idx += kBlock) {
-                        const int r = cpr == 4 ? idx >> 2 : idx / 12;
+                        const int r = cpr == 4 ? idx >> 2 : (int)(((float)idx + 0.5f) * inv_cpr);
                         const int q = idx - r * cpr;
                         const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                         const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                     T* d1 = box1 + r * pitch;
                     for (int xi = sub; xi < ext[2]; xi += 8) {
                         const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
-                        const T val = (tg.dbg & 1) ? (T)xs : rowp[xs * tg.in_stride[2]];
+                        const T val = (ABL & 1) ? (T)xs : rowp[xs * tg.in_stride[2]];
                         d0[xi] = val;
                         if (PAIR && xi > 0)
                             d1[xi - 1] = val;
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                 T val;
                 if (constant[i]) {
                     val = (T)v.cval;
-                } else if (tg.dbg & 2) {
+                } else if (ABL & 2) {
                     val = frac[i][0] + frac[i][1] + frac[i][2] + (T)start[i][0];
                 } else {
                     T w0[NT], w1[NT], w2[NT];
@@ -737,10 +740,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                 }
                 const int oz = o0[0] + wave + 4 * i, oy = o0[1] + yy, ox = o0[2] + xx;
                 T* optr = out + (out_off + (oz * tg.out_stride[0] + oy * tg.out_stride[1] + ox * tg.out_stride[2]));
-                if (tg.dbg & 256)
-                    __builtin_nontemporal_store(val, optr);
-                else
-                    *optr = val;
+                *optr = val;
             }
         }
     }
@@ -964,70 +964,78 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
 }
 
 // ================================================================================================
-// spill kernels: tiles that did not fit in LDS, one thread per voxel, straight from global memory;
-// displacement by the direct 64-tap sum (deform.c:693-758), taps with the per-tap mirror map
+// direct kernel: no LDS staging.  One block per 8^3 tile, two voxels per thread; displacement from
+// the per-call tables (Q, XT: 12 fp64 FMAs per voxel), taps straight from / to global memory with
+// the per-axis mirror map of deform.c:791-813.  Two uses:
+//   WORKLIST = true : finishes the tiles the LDS kernels could not hold (strong folding, 'wrap'
+//                     seams) from the spill worklist;
+//   WORKLIST = false: the whole volume, for spline orders 0 and 1 (1 / 8 taps per voxel: staging a
+//                     source box would cost more than it saves).
 // ================================================================================================
-template <typename T, int ORDER, bool GRAD>
-__global__ __launch_bounds__(kBlock) void deform_tile3_spill_kernel(const GridGeom g, const IOView v,
-                                                                    const TileGeom tg)
+template <typename T, int ORDER, bool GRAD, bool WORKLIST>
+__global__ __launch_bounds__(kBlock) void deform_tile3_direct_kernel(const GridGeom g, const IOView v,
+                                                                     const TileGeom tg)
 {
     constexpr int NT = ORDER + 1;
-    const int nspill = tg.spill[0];
+    (void)g;
     T* inp = reinterpret_cast<T*>(const_cast<char*>(v.in));
     T* outp = reinterpret_cast<T*>(v.out);
-    for (int s = blockIdx.x; s < nspill; s += gridDim.x) {
-        int t = tg.spill[1 + s];
+    const int ntile_total = tg.tiles[0] * tg.tiles[1] * tg.tiles[2];
+    const int nwork = WORKLIST ? tg.spill[0] : ntile_total;
+    const int tid = threadIdx.x;
+    const int xx = tid & 7, yy = (tid >> 3) & 7, zq = tid >> 6;
+    for (int s = blockIdx.x; s < nwork; s += gridDim.x) {
+        int t = WORKLIST ? tg.spill[1 + s] : s;
         const int tx = t % tg.tiles[2];
         t /= tg.tiles[2];
         const int ty = t % tg.tiles[1];
         const int tz = t / tg.tiles[1];
-        for (int vox = threadIdx.x; vox < kT * kT * kT; vox += kBlock) {
-            const int o[3] = {tz * kT + (vox >> 6), ty * kT + ((vox >> 3) & 7), tx * kT + (vox & 7)};
-            if (o[0] >= tg.out_len[0] || o[1] >= tg.out_len[1] || o[2] >= tg.out_len[2])
+        const int ox = tx * kT + xx, oy = ty * kT + yy;
+        if (ox >= tg.out_len[2] || oy >= tg.out_len[1])
+            continue;
+        const AxTab tx_ = tg.xt_global[ox];
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            const int oz = tz * kT + zq + 4 * i;
+            if (oz >= tg.out_len[0])
                 continue;
-            double dw[3][4];
-            int64_t dtap[3][4];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double cp = control_coordinate(g.ncp[k], (int64_t)o[k] + g.off[k], g.in_len[k]);
-                const int64_t st = window_start(cp, 3);
-                const bool edge = st < 0 || st + 3 >= g.ncp[k];
-#pragma unroll
-                for (int l = 0; l < 4; ++l)
-                    dtap[k][l] = (edge ? mirror_index(st + l, g.ncp[k]) : st + l) * g.disp_stride[k + 1];
-                spline_weights(cp, 3, dw[k]);
-            }
-            int start[3];
-            T w[3][NT];
+            const int o[3] = {oz, oy, ox};
+            const double* qrow0 = tg.q_global + ((int64_t)oz * tg.out_len[1] + oy) * 3 * tg.ncpx;
+            // coordinates (same arithmetic as voxel_coords, tables read from global memory)
+            double c[3];
             bool cst = false;
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                const char* base = g.disp + g.disp_stride[0] * h;
+                const double* qrow = qrow0 + h * tg.ncpx;
                 double d = 0.0;
-                for (int t2 = 0; t2 < 64; ++t2) {
-                    const int l0 = t2 >> 4, l1 = (t2 >> 2) & 3, l2 = t2 & 3;
-                    d += load_as_double(base + dtap[0][l0] + dtap[1][l1] + dtap[2][l2], g.disp_dtype) *
-                         dw[0][l0] * dw[1][l1] * dw[2][l2];
-                }
-                double c;
-                if (g.has_affine) {
-                    c = g.affine[h * 4 + 3];
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    d = fma(tx_.w[l], qrow[tx_.idx[l]], d);
+                double b;
+                if (tg.has_affine) {
+                    b = tg.affine[h * 4 + 3];
 #pragma unroll
                     for (int l = 0; l < 3; ++l)
-                        c += g.affine[h * 4 + l] * (double)o[l];
+                        b = fma(tg.affine[h * 4 + l], (double)o[l], b);
+                    b += (double)tg.off[h];
                 } else {
-                    c = (double)o[h];
+                    b = (double)(o[h] + tg.off[h]);
                 }
-                c = map_coordinate_fast(c + (double)g.off[h] + d, tg.in_len[h], tg.mode, tg.period[h],
-                                        tg.inv_period[h]);
-                const bool bad = !(c > -1.0);
-                cst = cst || bad;
-                const double fl = floor((ORDER & 1) ? c : c + 0.5);
-                start[h] = bad ? 0 : (int)fl - ORDER / 2;
-                weights_from_frac<T, ORDER>((T)(c - fl), w[h]);
+                c[h] = map_coordinate_fast(b + d, tg.in_len[h], tg.mode, tg.period[h], tg.inv_period[h]);
+                cst = cst || !(c[h] > -1.0);
             }
-            const int64_t obase = (int64_t)o[0] * tg.out_stride[0] + (int64_t)o[1] * tg.out_stride[1] +
-                                  (int64_t)o[2] * tg.out_stride[2];
+            int tap[3][NT];
+            T w[3][NT];
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                const double fl = floor((ORDER & 1) ? c[h] : c[h] + 0.5);
+                const int st = cst ? 0 : (int)fl - ORDER / 2;
+                weights_from_frac<T, ORDER>((T)(c[h] - fl), w[h]);
+#pragma unroll
+                for (int l = 0; l < NT; ++l)
+                    tap[h][l] = mirror_i32(st + l, tg.in_len[h]) * tg.in_stride[h];
+            }
+            const int obase = o[0] * tg.out_stride[0] + o[1] * tg.out_stride[1] + o[2] * tg.out_stride[2];
             for (int64_t ss = 0; ss < v.nsteps; ++ss) {
                 int64_t in_off, out_off;
                 step_offsets(v, ss, in_off, out_off);
@@ -1038,15 +1046,16 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_spill_kernel(const GridGe
                         val = (T)v.cval;
                     } else {
                         T a0 = 0;
+#pragma unroll
                         for (int l0 = 0; l0 < NT; ++l0) {
-                            const T* p0 = src + (int64_t)mirror_i32(start[0] + l0, tg.in_len[0]) * tg.in_stride[0];
                             T a1 = 0;
+#pragma unroll
                             for (int l1 = 0; l1 < NT; ++l1) {
-                                const T* p1 = p0 + (int64_t)mirror_i32(start[1] + l1, tg.in_len[1]) * tg.in_stride[1];
+                                const T* p1 = src + (tap[0][l0] + tap[1][l1]);
                                 T a2 = 0;
 #pragma unroll
                                 for (int l2 = 0; l2 < NT; ++l2)
-                                    a2 += w[2][l2] * p1[(int64_t)mirror_i32(start[2] + l2, tg.in_len[2]) * tg.in_stride[2]];
+                                    a2 += w[2][l2] * p1[tap[2][l2]];
                                 a1 += w[1][l1] * a2;
                             }
                             a0 += w[0][l0] * a1;
@@ -1056,16 +1065,16 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_spill_kernel(const GridGe
                     outp[out_off + obase] = val;
                 } else if (!cst) {
                     const T grad = outp[out_off + obase];
+#pragma unroll
                     for (int l0 = 0; l0 < NT; ++l0) {
-                        T* p0 = src + (int64_t)mirror_i32(start[0] + l0, tg.in_len[0]) * tg.in_stride[0];
                         const T g0 = grad * w[0][l0];
+#pragma unroll
                         for (int l1 = 0; l1 < NT; ++l1) {
-                            T* p1 = p0 + (int64_t)mirror_i32(start[1] + l1, tg.in_len[1]) * tg.in_stride[1];
+                            T* p1 = src + (tap[0][l0] + tap[1][l1]);
                             const T g1 = g0 * w[1][l1];
 #pragma unroll
                             for (int l2 = 0; l2 < NT; ++l2)
-                                unsafeAtomicAdd(p1 + (int64_t)mirror_i32(start[2] + l2, tg.in_len[2]) * tg.in_stride[2],
-                                                g1 * w[2][l2]);
+                                unsafeAtomicAdd(p1 + tap[2][l2], g1 * w[2][l2]);
                         }
                     }
                 }
@@ -1135,7 +1144,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         tg.box_cap = 3704;      // 57 * 64 + 56; two copies + head + Q stay under 40 KiB -> 4 blocks per CU
         box = 2 * 3704 * sizeof(T);
     } else {
-        tg.box_cap = sizeof(T) == 4 ? 6144 : 4096;
+        // single copy: orders 4 / 5 have 5- / 6-wide windows and need the larger budget
+        tg.box_cap = sizeof(T) == 4 ? (ORDER >= 4 ? 8192 : 6144) : 4096;
         box = (size_t)tg.box_cap * sizeof(T);
     }
     size_t overlay = (box + 15) & ~(size_t)15;
@@ -1167,20 +1177,40 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
                            sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
         e = hipGetLastError();
     }
+    if (ORDER < 2) {
+        // 1 / 8 taps per voxel: no source box, straight from global memory
+        if (e == hipSuccess) {
+            const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
+            hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, false>), dim3(nblk),
+                               dim3(kBlock), 0, stream, g, ve, tg);
+            e = hipGetLastError();
+        }
+        return e;
+    }
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
         if (GRAD)
-            hipLaunchKernelGGL((deform_tile3_grad_kernel<ORDER, 16>), dim3(nblk), dim3(kBlock), lds,
-                               stream, g, ve, tg);
-        else
+            hipLaunchKernelGGL((deform_tile3_grad_kernel<(ORDER < 2 ? 2 : ORDER), 16>), dim3(nblk),
+                               dim3(kBlock), lds, stream, g, ve, tg);
+        else if (PAIR && ORDER == 3 && sizeof(T) == 4 && tg.dbg) {
+            // profiling builds of the benchmark kernel (EDHIP_TILE_DBG), never used otherwise
+            switch (tg.dbg) {
+            case 2: hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR, 2>), dim3(nblk), dim3(kBlock), lds, stream, g, ve, tg); break;
+            case 4: hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR, 4>), dim3(nblk), dim3(kBlock), lds, stream, g, ve, tg); break;
+            case 6: hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR, 6>), dim3(nblk), dim3(kBlock), lds, stream, g, ve, tg); break;
+            case 16: hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR, 16>), dim3(nblk), dim3(kBlock), lds, stream, g, ve, tg); break;
+            case 38: hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR, 38>), dim3(nblk), dim3(kBlock), lds, stream, g, ve, tg); break;
+            default: hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR, 0>), dim3(nblk), dim3(kBlock), lds, stream, g, ve, tg); break;
+            }
+        } else
             hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR>), dim3(nblk), dim3(kBlock),
                                lds, stream, g, ve, tg);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
         const unsigned nsp = (unsigned)(ntiles < 2048 ? ntiles : 2048);
-        hipLaunchKernelGGL((deform_tile3_spill_kernel<T, ORDER, GRAD>), dim3(nsp), dim3(kBlock), 0,
-                           stream, g, ve, tg);
+        hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, true>), dim3(nsp), dim3(kBlock),
+                           0, stream, g, ve, tg);
         e = hipGetLastError();
     }
     return e;
@@ -1205,9 +1235,9 @@ size_t deform_tile_workspace_bytes(const GridGeom& g)
 
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
 {
-    if (g.naxis != 3 || v.order < 2)
+    if (g.naxis != 3)
         return false;
-    if (gradient && v.in_dtype != EDHIP_F32)
+    if (gradient && v.order >= 2 && v.in_dtype != EDHIP_F32)
         return false;
     if (!deform_fast_supported(g, v, gradient))
         return false;
@@ -1235,6 +1265,22 @@ hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, 
 {
     if (!deform_tile_supported(g, v, gradient))
         return hipErrorNotSupported;
+    const bool f32 = v.in_dtype == EDHIP_F32;
+    if (v.order < 2) {
+        // direct kernel (forward gathers / float atomics)
+        if (gradient) {
+            if (f32)
+                return v.order == 0 ? launch_tile<float, 0, false, true>(g, v, stream)
+                                    : launch_tile<float, 1, false, true>(g, v, stream);
+            return v.order == 0 ? launch_tile<double, 0, false, true>(g, v, stream)
+                                : launch_tile<double, 1, false, true>(g, v, stream);
+        }
+        if (f32)
+            return v.order == 0 ? launch_tile<float, 0, false, false>(g, v, stream)
+                                : launch_tile<float, 1, false, false>(g, v, stream);
+        return v.order == 0 ? launch_tile<double, 0, false, false>(g, v, stream)
+                            : launch_tile<double, 1, false, false>(g, v, stream);
+    }
     if (gradient) {
         switch (v.order) {
         case 2: return launch_tile<float, 2, false, true>(g, v, stream);
@@ -1244,12 +1290,12 @@ hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, 
         default: return hipErrorNotSupported;
         }
     }
-    if (v.in_dtype == EDHIP_F32) {
+    if (f32) {
         switch (v.order) {
         case 2: return launch_tile<float, 2, false, false>(g, v, stream);
         case 3: return launch_tile<float, 3, true, false>(g, v, stream);
         case 4: return launch_tile<float, 4, false, false>(g, v, stream);
-        case 5: return launch_tile<float, 5, true, false>(g, v, stream);
+        case 5: return launch_tile<float, 5, false, false>(g, v, stream);
         default: return hipErrorNotSupported;
         }
     }
