@@ -290,6 +290,7 @@ struct TileGeom {
     double inv_period[3];
     double affine[12];    // inverse map, 3 x 4
     int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
+    const int* worklist;  // second-level pass: [0] = count, [1..] = tile ids to process (else nullptr)
     const double* q_global;   // [O_z][O_y][3][ncpx]: displacement contracted over z and y
     const AxTab* xt_global;   // [O_x]: cubic weights / control indices along x
     int dbg;              // ablation switches for profiling (EDHIP_TILE_DBG), 0 in production
@@ -299,8 +300,22 @@ struct StripPos {
     int tz, ty, tx0, ntile;   // tile coordinates of the strip and number of tiles in it
 };
 
-__device__ __forceinline__ bool strip_position(const TileGeom& tg, StripPos& sp)
+__device__ __forceinline__ bool strip_position(const TileGeom& tg, int work, StripPos& sp)
 {
+    if (tg.worklist) {
+        // second-level pass: one 8^3 tile per work item, taken from the first level's spill list
+        if (work >= tg.worklist[0])
+            return false;
+        int t = tg.worklist[1 + work];
+        sp.tx0 = t % tg.tiles[2];
+        t /= tg.tiles[2];
+        sp.ty = t % tg.tiles[1];
+        sp.tz = t / tg.tiles[1];
+        sp.ntile = 1;
+        return true;
+    }
+    if (work != (int)blockIdx.x)
+        return false;        // first level: one strip per block
     // strips are dealt to the XCDs in contiguous chunks (block b runs on XCD b % 8): neighbouring
     // strips, whose source boxes overlap, share an L2
     const int b = blockIdx.x;
@@ -531,9 +546,12 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
 {
     constexpr int NT = ORDER + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int work = blockIdx.x;; work += gridDim.x) {
     StripPos sp;
-    if (!strip_position(tg, sp))
+    if (!strip_position(tg, work, sp))
         return;
+    if (work != (int)blockIdx.x)
+        __syncthreads();      // the previous work item is done with the LDS
     strip_prologue(g, v, tg, sp, smem);
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
@@ -744,6 +762,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
             }
         }
     }
+    }   // work items
 }
 
 // ================================================================================================
@@ -756,9 +775,13 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
 {
     constexpr int NT = ORDER + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int phase = 0;      // parity of the per-wave |dY| sum slots
+    for (int work = blockIdx.x;; work += gridDim.x) {
     StripPos sp;
-    if (!strip_position(tg, sp))
+    if (!strip_position(tg, work, sp))
         return;
+    if (work != (int)blockIdx.x)
+        __syncthreads();      // the previous work item is done with the LDS
     strip_prologue(g, v, tg, sp, smem);
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
@@ -777,7 +800,6 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
     const int ntile = (sp.ntile * kT + TX - 1) / TX;
     float* dx = reinterpret_cast<float*>(const_cast<char*>(v.in));      // accumulated into
     const float* __restrict__ dy = reinterpret_cast<const float*>(v.out);
-    int phase = 0;      // parity of the gmax slot
 
     for (int ti = 0; ti < ntile; ++ti) {
         const int o0[3] = {sp.tz * kT, sp.ty * kT, sp.tx0 * kT + ti * TX};
@@ -961,6 +983,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
             }
         }
     }
+    }   // work items
 }
 
 // ================================================================================================
@@ -1157,21 +1180,25 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         const char* dbg = getenv("EDHIP_TILE_DBG");
         tg.dbg = dbg ? atoi(dbg) : 0;
     }
-    // stream-ordered scratch: spill worklist | x table | Q
-    const size_t spill_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
+    // scratch: first-level spill list | second-level spill list | x table | Q
+    const size_t list_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
     const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
     hipError_t e = hipSuccess;
     // (edhip_deform reserved deform_tile_workspace_bytes() up front, so this does not move the
     // prefiltered control grid that may sit in the head of the workspace)
-    void* ws = workspace_reserve(stream, kWorkspaceGridBytes + spill_bytes + xt_bytes + q_global_bytes(g), &e);
+    void* ws = workspace_reserve(stream, kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q_global_bytes(g), &e);
     if (!ws)
         return e;
     ws = (char*)ws + kWorkspaceGridBytes;
-    tg.spill = (int*)ws;
-    tg.xt_global = (const AxTab*)((char*)ws + spill_bytes);
-    tg.q_global = (const double*)((char*)ws + spill_bytes + xt_bytes);
-    void* spill = ws;
-    e = hipMemsetAsync(spill, 0, sizeof(int), stream);
+    int* list_a = (int*)ws;
+    int* list_b = (int*)((char*)ws + list_bytes);
+    tg.xt_global = (const AxTab*)((char*)ws + 2 * list_bytes);
+    tg.q_global = (const double*)((char*)ws + 2 * list_bytes + xt_bytes);
+    tg.worklist = nullptr;
+    tg.spill = list_a;
+    e = hipMemsetAsync(list_a, 0, sizeof(int), stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(list_b, 0, sizeof(int), stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0]), dim3(kBlock),
                            sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
@@ -1187,6 +1214,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         }
         return e;
     }
+    // ---- level 1: strips, small boxes, highest occupancy ------------------------------------------
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
         if (GRAD)
@@ -1207,10 +1235,33 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
                                lds, stream, g, ve, tg);
         e = hipGetLastError();
     }
+    // ---- level 2: the tiles level 1 could not hold, one 8^3 tile per work item, a 48 KiB box
+    //      (single copy, 24- / 56-wide rows), grid-stride over the worklist --------------------------
+    TileGeom t2 = tg;
+    t2.worklist = list_a;
+    t2.spill = list_b;
+    size_t box2 = 48 * 1024;
+    if (t2.off_ov + box2 > 64 * 1024)
+        box2 = (64 * 1024 - t2.off_ov) & ~(size_t)63;
+    t2.box_cap = (int)(box2 / (GRAD ? 4 : sizeof(T)));
+    const size_t lds2 = t2.off_ov + box2;
+    const unsigned n2 = (unsigned)(ntiles < 512 ? ntiles : 512);
     if (e == hipSuccess) {
-        const unsigned nsp = (unsigned)(ntiles < 2048 ? ntiles : 2048);
+        if (GRAD)
+            hipLaunchKernelGGL((deform_tile3_grad_kernel<(ORDER < 2 ? 2 : ORDER), 8>), dim3(n2),
+                               dim3(kBlock), lds2, stream, g, ve, t2);
+        else
+            hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, false>), dim3(n2), dim3(kBlock), lds2,
+                               stream, g, ve, t2);
+        e = hipGetLastError();
+    }
+    // ---- level 3: whatever is left goes straight through global memory ----------------------------
+    if (e == hipSuccess) {
+        TileGeom t3 = tg;
+        t3.spill = list_b;
+        const unsigned nsp = (unsigned)(ntiles < 512 ? ntiles : 512);
         hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, true>), dim3(nsp), dim3(kBlock),
-                           0, stream, g, ve, tg);
+                           0, stream, g, ve, t3);
         e = hipGetLastError();
     }
     return e;
@@ -1225,12 +1276,12 @@ size_t deform_tile_workspace_bytes(const GridGeom& g)
     int64_t ntiles = 1;
     for (int k = 0; k < 3; ++k)
         ntiles *= (g.out_len[k] + kT - 1) / kT;
-    const size_t spill_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
+    const size_t list_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
     const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
     const size_t q = q_global_bytes(g);
     if (q > ((size_t)512 << 20))
         return kWorkspaceGridBytes;
-    return kWorkspaceGridBytes + spill_bytes + xt_bytes + q;
+    return kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q;
 }
 
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
