@@ -125,7 +125,10 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL on ROCm
+        # "nccl" is RCCL on ROCm; EDHIP_BENCH_BACKEND=gloo exists only to exercise this branch on a
+        # single-GPU box
+        dist.init_process_group(os.environ.get("EDHIP_BENCH_BACKEND", "nccl"), rank=rank,
+                                world_size=world)
 
     import elasticdeform_amd as ed
     import importlib
