@@ -236,7 +236,7 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         else if (flags & EDHIP_FLAG_FAST)
             use_fast = deform_fast_supported(g, v, gradient);
         else
-            use_fast = in.dtype == EDHIP_F32 && out.dtype == EDHIP_F32 &&
+            use_fast = (in.dtype == EDHIP_F32 || in.dtype == EDHIP_F64) && out.dtype == in.dtype &&
                        deform_fast_supported(g, v, gradient);
         hipError_t e;
         if (!use_fast)
@@ -338,10 +338,10 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
         p.trunc_branch[h] = max < p.len;                                // deform.c:1119,1134
     }
 
-    // fast path: float32 by default, float64 on request; same operator, no scratch, ~1e-16 relative
-    // to the sequential recursion (see spline_fast.hip)
+    // fast path for float32 / float64 unless the caller asks for the exact one; same operator, no
+    // scratch, ~1e-16 relative to the sequential recursion (see spline_fast.hip)
     const bool want_fast = !(flags & EDHIP_FLAG_EXACT) &&
-                           (input->dtype == EDHIP_F32 || (flags & EDHIP_FLAG_FAST));
+                           (input->dtype == EDHIP_F32 || input->dtype == EDHIP_F64);
     if (want_fast && p.npoles == 1) {
         const hipError_t e = launch_spline_filter_fast(p, order, input->ndim, axis, input->shape,
                                                        input->stride_bytes, output->stride_bytes,

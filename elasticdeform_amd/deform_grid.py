@@ -27,9 +27,10 @@ _flags = _ARITHMETIC.get(os.environ.get('EDHIP_ARITHMETIC', 'auto').lower(), _li
 
 
 def set_arithmetic(kind):
-    """Select the kernels' arithmetic: 'auto' (float32 volumes -> fast path, everything else ->
-    exact path), 'exact' (fp64, reference evaluation order, bit-comparable with the reference)
-    or 'fast' (also float64 volumes through the restructured path).  Returns the previous value."""
+    """Select the kernels' arithmetic: 'auto' (float32 / float64 volumes -> fast path, integer and
+    bool volumes -> exact path), 'exact' (fp64 arithmetic in the reference's evaluation order for
+    every dtype: float64 / float32 / integer outputs bit-comparable with the reference) or 'fast'
+    (same as 'auto' today).  Returns the previous value."""
     global _flags
     if kind not in _ARITHMETIC:
         raise ValueError("arithmetic must be one of %s" % sorted(_ARITHMETIC))

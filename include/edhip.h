@@ -92,9 +92,10 @@ enum edhip_status {
 
 /* arithmetic selection for edhip_deform / edhip_spline_filter1d */
 enum edhip_flags {
-    EDHIP_FLAG_AUTO = 0,       /* f32 data -> fast path; every other dtype -> exact path */
+    EDHIP_FLAG_AUTO = 0,       /* float32 / float64 data -> fast path; integer and bool data -> exact path */
     EDHIP_FLAG_EXACT = 1,      /* fp64 arithmetic in the reference's own evaluation order (bit-comparable) */
-    EDHIP_FLAG_FAST = 2,       /* fp64 coordinates, restructured (separable) sums, data-width tap accumulation */
+    EDHIP_FLAG_FAST = 2,       /* fp64 coordinates, restructured (separable) sums, data-width tap accumulation
+                                  (what AUTO selects for floating-point data) */
     /* edhip_deform only: `displacement` is the RAW control grid; the library applies the order-3
      * mirror prefilter along every grid axis itself (what deform_grid.py:166-169,269-272 does with
      * SciPy before calling the C code), in one launch, with the same arithmetic and the same
