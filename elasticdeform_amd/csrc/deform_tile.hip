@@ -290,6 +290,7 @@ struct TileGeom {
     double inv_period[3];
     double affine[12];    // inverse map, 3 x 4
     int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
+    int* spill_next;      // the second level's spill list (its count is reset by the tables kernel)
     const int* worklist;  // second-level pass: [0] = count, [1..] = tile ids to process (else nullptr)
     const double* q_global;   // [O_z][O_y][3][ncpx]: displacement contracted over z and y
     const AxTab* xt_global;   // [O_x]: cubic weights / control indices along x
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     const int oz = blockIdx.x;
     const int ncpy = (int)g.ncp[1], ncpx = (int)g.ncp[2];
     const int nyx = ncpy * ncpx;
+    if (oz == 0 && tid == 0) {      // reset both spill counters (saves two memset launches per call)
+        tg.spill[0] = 0;
+        tg.spill_next[0] = 0;
+    }
     auto entry = [&](int a, int oi, AxTab& t) {
         const double cp = control_coordinate(g.ncp[a], (int64_t)oi + g.off[a], g.in_len[a]);
         const int64_t start = window_start(cp, 3);
@@ -1196,10 +1201,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     tg.q_global = (const double*)((char*)ws + 2 * list_bytes + xt_bytes);
     tg.worklist = nullptr;
     tg.spill = list_a;
-    e = hipMemsetAsync(list_a, 0, sizeof(int), stream);
-    if (e == hipSuccess)
-        e = hipMemsetAsync(list_b, 0, sizeof(int), stream);
-    if (e == hipSuccess) {
+    tg.spill_next = list_b;
+    {
         hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0]), dim3(kBlock),
                            sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
         e = hipGetLastError();

@@ -27,8 +27,10 @@
 //
 // Algorithmic bytes: 2 * sizeof(T) per sample per axis; the 32-sample warm-ups are re-reads that
 // hit L2.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "ed_device.h"
 #include "ed_params.h"
@@ -361,6 +363,703 @@ __global__ __launch_bounds__(64 * contig_waves<T>()) void prefilter_fast_contig_
     }
 }
 
+
+// ================================================================================================
+// Whole-line tiles (the default whenever a tile of complete lines fits the LDS): a workgroup loads
+// C (or R) complete lines into LDS with row-contiguous 16-byte loads -- every sample is read from
+// global memory exactly once -- and then every (line, 32-output block) pair is an independent work
+// item: causal and anti-causal recursions both restart from a 32-sample warm-up read from LDS, so
+// there is no carried state, no sequential dependency between blocks and no global re-read.
+// Whole lines per tile also make the kernels safe in place.
+//
+//   strided axis : tile [32 | n | 32+ halo][C], C = 256 bytes of adjacent lines; lane <-> line,
+//                  blocks across waves; the mirror / zero extension is materialised in the halo
+//                  rows; outputs go straight from registers to global memory (256-byte rows).
+//   contiguous   : tile [R][32 | n | 32+ halo], R in {32, 16, 8} lines; the mirror / zero extension
+//                  is materialised in the halo; lane <-> line reads 16-byte vectors (pitch / VEC odd:
+//                  conflict-free); outputs return through the tile so that global stores are
+//                  row-contiguous 16-byte vectors.
+// ================================================================================================
+struct LineTile {
+    const char* in;
+    char* out;
+    int n;                       // line length
+    int nb;                      // number of 32-output blocks per line
+    int64_t in_axis_stride, out_axis_stride;      // elements
+    int ncol;                    // strided: extent of the unit-stride outer axis (columns)
+    int col_tiles;               // strided: tiles along it
+    int nouter;                  // remaining outer axes (strided: without the column axis)
+    int64_t outer_len[EDHIP_MAX_DIMS];
+    int64_t in_outer_stride[EDHIP_MAX_DIMS];
+    int64_t out_outer_stride[EDHIP_MAX_DIMS];
+    int64_t nlines;              // contiguous: number of lines
+    int rows;                    // contiguous: lines per tile (R)
+    int pitch;                   // contiguous: tile row pitch in elements
+    int64_t ntiles;
+    int transpose;
+    int dbg;
+    unsigned long long* trace;   // profiling only (EDHIP_FILTER_TRACE): phase timestamps of workgroup 0
+    double z, h0;
+};
+
+// (32-bit decomposition: a 64-bit integer division costs ~1 us on this machine, and the persistent
+// kernels do one or two per tile; the host only takes this path for fewer than 2^31 lines)
+__device__ __forceinline__ void tile_offsets(const LineTile& p, int64_t idx, int64_t& in_off,
+                                             int64_t& out_off)
+{
+    in_off = 0;
+    out_off = 0;
+    uint32_t r = (uint32_t)idx;
+    for (int d = p.nouter - 1; d > 0; --d) {
+        const uint32_t len = (uint32_t)p.outer_len[d];
+        const uint32_t q = r / len;
+        const uint32_t c = r - q * len;
+        in_off += (int64_t)c * p.in_outer_stride[d];
+        out_off += (int64_t)c * p.out_outer_stride[d];
+        r = q;
+    }
+    if (p.nouter > 0) {
+        in_off += (int64_t)r * p.in_outer_stride[0];
+        out_off += (int64_t)r * p.out_outer_stride[0];
+    }
+}
+
+// transpose: fold the two tails of the zero-extended result back into block b (see header).
+// A = arithmetic type of the tile kernels (see TileArith).
+template <typename A, typename SLast>
+__device__ __forceinline__ void fold_tails(A (&o)[kB], int b, int n, A z, A h0, SLast s_last_fn)
+{
+    if (b + kB > n - 1 - kK) {
+        const A s_last = h0 * s_last_fn();      // s[n-1] = h0 * sum_k z^k x[n-1-k]
+        A zp = 1;              // z^(n-1-i), built upwards from i = n-1
+        for (int i = n - 1; i > b + kB - 1; --i)
+            zp *= z;
+#pragma unroll
+        for (int k = kB - 1; k >= 0; --k) {
+            const int i = b + k;
+            if (i <= n - 1) {
+                if (i > 0 && i < n - 1)
+                    o[k] += zp * s_last;
+                zp *= z;
+            }
+        }
+    }
+    if (b == 0) {
+        const A s0 = o[0];
+        A zp = z;
+#pragma unroll
+        for (int k = 1; k < kB; ++k) {
+            if (k < n - 1)
+                o[k] += zp * s0;
+            zp *= z;
+        }
+    }
+}
+
+// one independent block: rd(j) = boundary-extended sample j (as A), j in [b - kK, b + kB + kK)
+template <typename A, typename Rd>
+__device__ __forceinline__ void block_from_reader(Rd rd, int b, A z, A h0, A (&o)[kB])
+{
+    // (warm-ups only partly unrolled: full unrolling makes the compiler hoist every LDS read and spill)
+    A ya = 0;
+#pragma unroll 8
+    for (int k = kK - 1; k >= 0; --k)
+        ya = fma(z, ya, rd(b + kB + k));
+    A yc = 0;
+#pragma unroll 8
+    for (int k = 0; k < kK; ++k)
+        yc = fma(z, yc, rd(b - kK + k));
+#pragma unroll
+    for (int k = 0; k < kB; ++k) {
+        yc = fma(z, yc, rd(b + k));
+        o[k] = yc;
+    }
+#pragma unroll
+    for (int k = kB - 1; k >= 0; --k) {
+        const A x = rd(b + k);
+        ya = fma(z, ya, x);
+        o[k] = h0 * (o[k] + ya - x);
+    }
+}
+
+// Arithmetic of the whole-line tile kernels = the storage type.  float32 volumes are filtered in
+// float32: the recursions are contractions (|z| < 0.27 for orders 2 / 3), rounding noise does not
+// build up -- measured <= 3e-7 of the line's maximum against the fp64 recursion, an order of
+// magnitude inside the 1e-5 float32 budget -- and v_cvt_f64_f32 / v_cvt_f32_f64 run at a quarter of
+// the FMA rate, which made the fp64 version of these kernels VALU-bound at two workgroups per CU.
+template <typename T>
+struct TileArith {
+    typedef T type;
+};
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<float> {
+    typedef float __attribute__((ext_vector_type(4))) type;
+    static constexpr int N = 4;
+};
+template <>
+struct VecOf<double> {
+    typedef double __attribute__((ext_vector_type(2))) type;
+    static constexpr int N = 2;
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// wait for the next tile's prefetch loads (and this tile's global stores) at every barrier.  The tile
+// kernels never communicate through global memory inside a launch, so LDS ordering is all they need.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- strided axis ----------------------------------------------------------------------------------
+// Persistent workgroups; with VEC the next tile's rows are already in flight (in registers) while
+// the current tile is filtered and stored.
+template <typename T, int C, bool VEC>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_strided_kernel(const LineTile p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* tile = reinterpret_cast<T*>(smem) + kK * C;     // [kK | n32 | kK][C]: sample j at row j
+    typedef typename VecOf<T>::type V;
+    constexpr int VN = VecOf<T>::N;
+    constexpr int CH = C / VN;                         // 16-byte chunks per row
+    constexpr int RP = kBlock / CH;                    // rows per pass of the vector loads
+    constexpr int NPF = VEC ? (C * (int)sizeof(T) == 256 ? 16 : 18) : 1;   // loads per thread per tile
+    const int tid = threadIdx.x;
+    const int n = p.n;
+    const int ch = tid % CH, r0 = tid / CH;
+    const bool tr = p.transpose != 0;
+    typedef typename TileArith<T>::type A;
+    const A z = (A)p.z, h0 = (A)p.h0;
+    const T* in_base = reinterpret_cast<const T*>(p.in);
+    T* out_base = reinterpret_cast<T*>(p.out);
+
+    struct Where {
+        int64_t in_off, out_off;
+        int ncols;
+    };
+    auto locate = [&](int64_t t) {
+        Where w;
+        const uint32_t grp = (uint32_t)t / (uint32_t)p.col_tiles;
+        const int col0 = (int)((uint32_t)t - grp * (uint32_t)p.col_tiles) * C;
+        w.ncols = p.ncol - col0 < C ? p.ncol - col0 : C;
+        tile_offsets(p, grp, w.in_off, w.out_off);
+        w.in_off += col0;
+        w.out_off += col0;
+        return w;
+    };
+    V v[NPF];
+    // (unconditional loads from clamped addresses: a predicated load sits in its own basic block
+    // and the compiler then drains vmcnt before each one, serialising the whole prefetch)
+    auto issue = [&](const Where& w) {
+        const T* src = in_base + w.in_off + (ch * VN < w.ncols ? ch * VN : 0);   // ncols % VN == 0 (host)
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int r = u * RP + r0;
+            v[u] = *reinterpret_cast<const V*>(src + (int64_t)(r < n ? r : n - 1) * p.in_axis_stride);
+        }
+    };
+
+    int64_t t = blockIdx.x;
+    if (t >= p.ntiles)
+        return;
+    Where cur = locate(t);
+    if (VEC)
+        issue(cur);
+    for (;;) {
+        if (VEC) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int r = u * RP + r0;
+                if (r < n)
+                    *reinterpret_cast<V*>(tile + r * C + ch * VN) = v[u];
+            }
+        } else {
+            constexpr int RS = kBlock / C;
+            const int c = tid % C, rr = tid / C;
+            const T* src = in_base + cur.in_off + c;
+            const bool ok = c < cur.ncols;
+            for (int rb = 0; rb < n; rb += RS * 8) {
+                T x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = rb + u * RS + rr;
+                    x[u] = (ok && r < n) ? src[(int64_t)r * p.in_axis_stride] : (T)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = rb + u * RS + rr;
+                    if (r < n)
+                        tile[r * C + c] = x[u];
+                }
+            }
+        }
+        lds_barrier();
+        // halo rows: samples -kK .. -1 and n .. n32 + kK - 1, mirrored (forward) or zero (transpose)
+        {
+            const int nh = kK + (p.nb * kB - n) + kK;
+            const int cc = tid % C;
+            for (int h0_ = tid / C; h0_ < nh; h0_ += 8 * (kBlock / C)) {
+                T x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {       // eight independent LDS reads, then the writes
+                    const int h = h0_ + u * (kBlock / C);
+                    const int j = h < kK ? h - kK : n + (h - kK);
+                    const int i = tr ? -1 : (j < 0 ? -j : 2 * n - 2 - j);
+                    x[u] = (h < nh && i >= 0) ? tile[i * C + cc] : (T)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int h = h0_ + u * (kBlock / C);
+                    const int j = h < kK ? h - kK : n + (h - kK);
+                    if (h < nh)
+                        tile[j * C + cc] = x[u];
+                }
+            }
+        }
+        const int64_t next = t + gridDim.x;
+        const bool has_next = next < p.ntiles;
+        Where nxt = cur;
+        if (has_next) {
+            nxt = locate(next);
+            if (VEC)
+                issue(nxt);            // in flight while this tile is filtered and stored
+        }
+        lds_barrier();
+
+        const int c = tid % C;
+        const T* col = tile + c;
+        T* dst = out_base + cur.out_off;
+        for (int blk = tid / C; blk < p.nb; blk += kBlock / C) {
+            const int b = blk * kB;
+            A o[kB];
+            block_from_reader([&](int j) { return (A)col[j * C]; }, b, z, h0, o);
+            if (tr)
+                fold_tails(o, b, n, z, h0, [&]() {
+                    A yc = 0;
+#pragma unroll 8
+                    for (int k = kK - 1; k >= 0; --k)
+                        yc = fma(z, yc, (A)col[(n - 1 - k) * C]);
+                    return yc;
+                });
+            if (c < cur.ncols) {
+                T* q = dst + (int64_t)b * p.out_axis_stride + c;
+                if (b + kB <= n) {
+#pragma unroll
+                    for (int k = 0; k < kB; ++k)
+                        q[(int64_t)k * p.out_axis_stride] = (T)o[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kB; ++k)
+                        if (b + k < n)
+                            q[(int64_t)k * p.out_axis_stride] = (T)o[k];
+                }
+            }
+        }
+        if (!has_next)
+            break;
+        lds_barrier();               // every thread is done reading the tile
+        t = next;
+        cur = nxt;
+    }
+}
+
+// ---- contiguous axis -------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_contig_kernel(const LineTile p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename VecOf<T>::type V;
+    typedef typename std::conditional<VEC, V, T>::type W;
+    constexpr int VN = VEC ? VecOf<T>::N : 1;
+    // chunk loads per thread per tile: R * n <= 8192 samples (host)
+    constexpr int NPF = VEC ? 8192 / (kBlock * VN) : 1;
+    int64_t* row_off = reinterpret_cast<int64_t*>(smem);          // [parity][in / out][32]
+    T* tile = reinterpret_cast<T*>(smem + 1024);                  // [R][pitch], sample j at [kK + j]
+    const int tid = threadIdx.x;
+    const int n = p.n, R = p.rows, pitch = p.pitch;
+    const int n32 = p.nb * kB;
+    const bool tr = p.transpose != 0;
+    typedef typename TileArith<T>::type A;
+    const A z = (A)p.z, h0 = (A)p.h0;
+    const T* in_base = reinterpret_cast<const T*>(p.in);
+    T* out_base = reinterpret_cast<T*>(p.out);
+    const int nc = n / VN;                 // n % VN == 0 (host)
+    const int total = R * nc;
+    const float inv_nc = 1.0f / (float)nc;
+
+    auto setup_rows = [&](int64_t t, int par) {
+        if (tid < R) {
+            const int64_t line0 = t * R;
+            const int nl = (int)(p.nlines - line0 < R ? p.nlines - line0 : R);
+            int64_t a, b;
+            tile_offsets(p, line0 + (tid < nl ? tid : nl - 1), a, b);
+            row_off[par * 64 + tid] = a;
+            row_off[par * 64 + 32 + tid] = b;
+        }
+    };
+    W v[NPF];
+    auto issue = [&](int par) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            // unconditional, clamped (see the strided kernel)
+            const int idx = u * kBlock + tid < total ? u * kBlock + tid : total - 1;
+            const int r = (int)(((float)idx + 0.5f) * inv_nc), ch = idx - r * nc;
+            v[u] = *reinterpret_cast<const W*>(in_base + row_off[par * 64 + r] + ch * VN);
+        }
+    };
+
+    int64_t t = blockIdx.x;
+    if (t >= p.ntiles)
+        return;
+    int tslot = 0;
+    auto stamp = [&]() {
+        if (p.trace && blockIdx.x == 0 && tid == 0 && tslot < 64)
+            p.trace[tslot++] = clock64();
+    };
+    stamp();
+    int par = 0;
+    setup_rows(t, 0);
+    lds_barrier();
+        stamp();
+    if (VEC)
+        issue(0);
+    for (;;) {
+        if (VEC) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int idx = u * kBlock + tid;
+                if (idx < total) {
+                    const int r = (int)(((float)idx + 0.5f) * inv_nc), ch = idx - r * nc;
+                    *reinterpret_cast<W*>(tile + r * pitch + kK + ch * VN) = v[u];
+                }
+            }
+        } else {
+            for (int base = 0; base < total; base += kBlock * 8) {
+                T x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * kBlock + tid;
+                    if (idx < total) {
+                        const int r = (int)(((float)idx + 0.5f) * inv_nc), ch = idx - r * nc;
+                        x[u] = in_base[row_off[par * 64 + r] + ch];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * kBlock + tid;
+                    if (idx < total) {
+                        const int r = (int)(((float)idx + 0.5f) * inv_nc), ch = idx - r * nc;
+                        tile[r * pitch + kK + ch] = x[u];
+                    }
+                }
+            }
+        }
+        const int64_t next = t + gridDim.x;
+        const bool has_next = next < p.ntiles;
+        if (has_next)
+            setup_rows(next, par ^ 1);
+        lds_barrier();
+        stamp();
+        // halo: positions -kK .. -1 and n .. n32 + kK - 1, mirrored (forward) or zero (transpose)
+        {
+            // kBlock / R threads per line, each 8 halo samples per pass: independent reads first
+            const int nh = kK + (n32 - n) + kK;
+            const int tpr = kBlock / R;
+            const int hr = tid / tpr;
+            T* hrow = tile + hr * pitch + kK;
+            for (int h0_ = tid % tpr; h0_ < nh; h0_ += 8 * tpr) {
+                T x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int h = h0_ + u * tpr;
+                    const int j = h < kK ? h - kK : n + (h - kK);
+                    const int i = tr ? -1 : (j < 0 ? -j : 2 * n - 2 - j);
+                    x[u] = (h < nh && i >= 0) ? hrow[i] : (T)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int h = h0_ + u * tpr;
+                    const int j = h < kK ? h - kK : n + (h - kK);
+                    if (h < nh)
+                        hrow[j] = x[u];
+                }
+            }
+        }
+        if (VEC && has_next)
+            issue(par ^ 1);            // in flight while this tile is filtered and stored
+        lds_barrier();
+        stamp();
+
+        // one (line, block) item per thread
+        const int r = tid % R, blk = tid / R;
+        const bool have = blk < p.nb;
+        A o[kB];
+        const int b = blk * kB;
+        if (have) {
+            const T* row = tile + r * pitch + kK;
+            if (VEC) {
+                // vector reads, VN samples at a time (pitch / VN is odd: conflict-free across lanes)
+                auto rdv = [&](int j) { return *reinterpret_cast<const V*>(row + j); };
+                A ya = 0;
+#pragma unroll 4
+                for (int k = kK - VN; k >= 0; k -= VN) {
+                    const V x = rdv(b + kB + k);
+#pragma unroll
+                    for (int e = VN - 1; e >= 0; --e)
+                        ya = fma(z, ya, (A)x[e]);
+                }
+                A yc = 0;
+#pragma unroll 4
+                for (int k = 0; k < kK; k += VN) {
+                    const V x = rdv(b - kK + k);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e)
+                        yc = fma(z, yc, (A)x[e]);
+                }
+                T xs[kB];
+#pragma unroll
+                for (int k = 0; k < kB; k += VN) {
+                    const V x = rdv(b + k);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) {
+                        xs[k + e] = x[e];
+                        yc = fma(z, yc, (A)x[e]);
+                        o[k + e] = yc;
+                    }
+                }
+#pragma unroll
+                for (int k = kB - 1; k >= 0; --k) {
+                    const A x = (A)xs[k];
+                    ya = fma(z, ya, x);
+                    o[k] = h0 * (o[k] + ya - x);
+                }
+            } else {
+                block_from_reader([&](int j) { return (A)row[j]; }, b, z, h0, o);
+            }
+            if (tr)
+                fold_tails(o, b, n, z, h0, [&]() {
+                    A yc = 0;
+                    if (VEC) {      // vector reads here too: scalar ones are 8-way bank conflicted
+#pragma unroll 4
+                        for (int k = n - kK; k < n; k += VN) {
+                            const V x = *reinterpret_cast<const V*>(row + k);
+#pragma unroll
+                            for (int e = 0; e < VN; ++e)
+                                yc = fma(z, yc, (A)x[e]);
+                        }
+                    } else {
+#pragma unroll 8
+                        for (int k = kK - 1; k >= 0; --k)
+                            yc = fma(z, yc, (A)row[n - 1 - k]);
+                    }
+                    return yc;
+                });
+        }
+        lds_barrier();
+        stamp();          // every thread is done reading the input tile
+        if (have) {
+            T* row = tile + r * pitch + kK + b;
+            if (VEC) {
+#pragma unroll
+                for (int k = 0; k < kB; k += VN) {
+                    V x;
+#pragma unroll
+                    for (int e = 0; e < VN; ++e)
+                        x[e] = (T)o[k + e];
+                    *reinterpret_cast<V*>(row + k) = x;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kB; ++k)
+                    row[k] = (T)o[k];
+            }
+        }
+        lds_barrier();
+        stamp();
+        {
+            const int64_t line0 = t * R;
+            const int nl = (int)(p.nlines - line0 < R ? p.nlines - line0 : R);
+            constexpr int NST = 8192 / (kBlock * VN);
+#pragma unroll
+            for (int u = 0; u < NST; ++u) {
+                const int idx = u * kBlock + tid;
+                const int ic = idx < total ? idx : total - 1;
+                const int rr = (int)(((float)ic + 0.5f) * inv_nc), ch = ic - rr * nc;
+                const W x = *reinterpret_cast<const W*>(tile + rr * pitch + kK + ch * VN);
+                if (idx < total && rr < nl)
+                    *reinterpret_cast<W*>(out_base + row_off[par * 64 + 32 + rr] + ch * VN) = x;
+            }
+        }
+        if (!has_next)
+            break;
+        lds_barrier();
+        stamp();          // the tile is free for the next lines
+        t = next;
+        par ^= 1;
+    }
+}
+
+constexpr size_t kTileLdsBudget = 80 * 1024;      // two workgroups per CU
+
+template <typename K>
+hipError_t allow_large_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024)
+        return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLdsBudget);
+}
+
+// returns hipErrorNotSupported when no whole-line tile fits
+template <typename T>
+hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
+{
+    constexpr int VN = VecOf<T>::N;
+    constexpr int CW = 256 / (int)sizeof(T);       // widest tile: 256-byte rows
+    if (f.len > 0x3fffffff || f.nlines > 0x7fffffffLL)
+        return hipErrorNotSupported;
+    LineTile p;
+    memset(&p, 0, sizeof(p));
+    p.in = f.in;
+    p.out = f.out;
+    p.n = (int)f.len;
+    p.nb = (p.n + kB - 1) / kB;
+    p.in_axis_stride = f.in_axis_stride;
+    p.out_axis_stride = f.out_axis_stride;
+    p.transpose = f.transpose;
+    p.z = f.z;
+    p.h0 = f.h0;
+    if (const char* d = getenv("EDHIP_FILTER_DBG"))
+        p.dbg = atoi(d);
+    // persistent grid: two workgroups per CU for float32 (LDS and registers are budgeted for exactly
+    // that), one for float64 (its fp64 state does not fit 256 registers next to the prefetch)
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        ncu = 256;
+    int wgs_per_cu = sizeof(T) == 8 ? 1 : 2;
+    if (const char* w = getenv("EDHIP_TILE_WGS"))
+        wgs_per_cu = atoi(w) > 0 ? atoi(w) : wgs_per_cu;
+    const int64_t resident = (int64_t)ncu * wgs_per_cu;
+    const bool aligned16 = ((uintptr_t)f.in % 16 == 0) && ((uintptr_t)f.out % 16 == 0);
+    auto strides_vec = [&](int skip) {
+        for (int d = 0; d < f.nouter; ++d)
+            if (d != skip && (f.in_outer_stride[d] % VN || f.out_outer_stride[d] % VN))
+                return false;
+        return true;
+    };
+    const bool contig = f.in_axis_stride == 1 && f.out_axis_stride == 1 && f.nouter > 0;
+    if (contig) {
+        const bool vec = aligned16 && p.n % VN == 0 && strides_vec(-1);
+        p.pitch = 2 * kK + p.nb * kB + (vec ? VN : 1);
+        int R = 32;
+        while (R >= 8 && (R * p.nb > kBlock || 1024 + (size_t)R * p.pitch * sizeof(T) > kTileLdsBudget))
+            R /= 2;
+        if (R < 8)
+            return hipErrorNotSupported;
+        p.rows = R;
+        p.nlines = f.nlines;
+        p.nouter = f.nouter;
+        for (int d = 0; d < f.nouter; ++d) {
+            p.outer_len[d] = f.outer_len[d];
+            p.in_outer_stride[d] = f.in_outer_stride[d];
+            p.out_outer_stride[d] = f.out_outer_stride[d];
+        }
+        const size_t lds = 1024 + (size_t)R * p.pitch * sizeof(T);
+        p.ntiles = (f.nlines + R - 1) / R;
+        const int64_t nblk = p.ntiles < resident ? p.ntiles : resident;
+        if (lds > kTileLdsBudget)
+            return hipErrorNotSupported;
+        if (vec) {
+            static const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, true>, kTileLdsBudget);
+            if (attr != hipSuccess)
+                return hipErrorNotSupported;
+            if (getenv("EDHIP_FILTER_TRACE")) {
+                static unsigned long long* buf = nullptr;
+                if (!buf)
+                    (void)hipMalloc((void**)&buf, 64 * 8);
+                (void)hipMemsetAsync(buf, 0, 64 * 8, stream);
+                p.trace = buf;
+                hipLaunchKernelGGL((prefilter_tile_contig_kernel<T, true>), dim3((unsigned)nblk), dim3(kBlock),
+                                   lds, stream, p);
+                unsigned long long h[64];
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);
+                fprintf(stderr, "trace:");
+                for (int i = 1; i < 64 && h[i]; ++i)
+                    fprintf(stderr, " %llu", h[i] - h[i - 1]);
+                fprintf(stderr, "\n");
+                return hipGetLastError();
+            }
+            hipLaunchKernelGGL((prefilter_tile_contig_kernel<T, true>), dim3((unsigned)nblk), dim3(kBlock),
+                               lds, stream, p);
+        } else {
+            static const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, false>, kTileLdsBudget);
+            if (attr != hipSuccess)
+                return hipErrorNotSupported;
+            hipLaunchKernelGGL((prefilter_tile_contig_kernel<T, false>), dim3((unsigned)nblk), dim3(kBlock),
+                               lds, stream, p);
+        }
+        return hipGetLastError();
+    }
+    // strided: the column axis is an outer axis with unit stride in and out
+    int cax = -1;
+    for (int d = f.nouter - 1; d >= 0; --d)
+        if (f.in_outer_stride[d] == 1 && f.out_outer_stride[d] == 1 && f.outer_len[d] > 1) {
+            cax = d;
+            break;
+        }
+    if (cax < 0 || f.outer_len[cax] > 0x3fffffff)
+        return hipErrorNotSupported;
+    int C = CW;
+    const size_t tile_rows = (size_t)(2 * kK + p.nb * kB);
+    if (tile_rows * C * sizeof(T) > kTileLdsBudget || f.outer_len[cax] <= C / 2)
+        C = CW / 2;
+    if (tile_rows * C * sizeof(T) > kTileLdsBudget)
+        return hipErrorNotSupported;
+    p.ncol = (int)f.outer_len[cax];
+    p.col_tiles = (p.ncol + C - 1) / C;
+    int64_t groups = 1;
+    for (int d = 0; d < f.nouter; ++d) {
+        if (d == cax)
+            continue;
+        p.outer_len[p.nouter] = f.outer_len[d];
+        p.in_outer_stride[p.nouter] = f.in_outer_stride[d];
+        p.out_outer_stride[p.nouter] = f.out_outer_stride[d];
+        groups *= f.outer_len[d];
+        p.nouter++;
+    }
+    p.ntiles = groups * p.col_tiles;
+    const int64_t nblk = p.ntiles < resident ? p.ntiles : resident;
+    const bool vec = aligned16 && p.ncol % VN == 0 && strides_vec(cax) &&
+                     f.in_axis_stride % VN == 0 && f.out_axis_stride % VN == 0;
+    const size_t lds = tile_rows * C * sizeof(T);
+#define EDHIP_TILE_STRIDED(CC, VV)                                                                   \
+    do {                                                                                             \
+        static const hipError_t attr =                                                               \
+            allow_large_lds(prefilter_tile_strided_kernel<T, CC, VV>, kTileLdsBudget);              \
+        if (attr != hipSuccess)                                                                      \
+            return hipErrorNotSupported;                                                             \
+        hipLaunchKernelGGL((prefilter_tile_strided_kernel<T, CC, VV>), dim3((unsigned)nblk),         \
+                           dim3(kBlock), lds, stream, p);                                            \
+    } while (0)
+    if (C == CW) {
+        if (vec)
+            EDHIP_TILE_STRIDED(CW, true);
+        else
+            EDHIP_TILE_STRIDED(CW, false);
+    } else {
+        if (vec)
+            EDHIP_TILE_STRIDED(CW / 2, true);
+        else
+            EDHIP_TILE_STRIDED(CW / 2, false);
+    }
+#undef EDHIP_TILE_STRIDED
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // host entry: returns hipErrorNotSupported when the case is outside the fast envelope
@@ -421,6 +1120,13 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
     p.seg_len = seg_blocks * kB;
     p.nseg = (int)((nblocks_line + seg_blocks - 1) / seg_blocks);
 
+    if (!getenv("EDHIP_NO_LINE_TILES")) {
+        const hipError_t e = fp.in_dtype == EDHIP_F32 ? launch_line_tiles<float>(p, stream)
+                                                      : launch_line_tiles<double>(p, stream);
+        if (e != hipErrorNotSupported)
+            return e;
+        (void)hipGetLastError();
+    }
     if (contig && !getenv("EDHIP_CONTIG_LDS")) {
         const int64_t threads = p.nlines * p.nseg;
         const int64_t nblk = (threads + kBlock - 1) / kBlock;

@@ -27,10 +27,11 @@
  * cvals, affine, output_offset) are HOST pointers, read before the call returns.
  *
  * Ownership: the caller allocates every array; the library borrows them for the duration of the
- * enqueued work and allocates only stream-ordered scratch.  Calls are asynchronous with respect
- * to the host: work is enqueued on `hip_stream` and the function returns; there is no implicit
- * device synchronisation.  The library keeps no mutable global state, so it is re-entrant and
- * may be called concurrently from several host threads on different streams / devices
+ * enqueued work and owns only a small scratch workspace per (device, stream), grown on demand.
+ * Calls are asynchronous with respect to the host: work is enqueued on `hip_stream` and the
+ * function returns; there is no implicit device synchronisation.  Apart from that mutex-guarded
+ * workspace cache the library keeps no mutable global state, so it is re-entrant and may be
+ * called concurrently from several host threads on different streams / devices
  * (reference: single-threaded, GIL released for the whole call, deform.c:377-379).
  *
  * Error convention (reference: return 0 with a Python exception set, deform.c:1042,

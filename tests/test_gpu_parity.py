@@ -10,6 +10,8 @@ exact kernels (bit equality, incl. order-0 label resampling); with arithmetic 'e
 float32 outputs are compared for bit equality too.  Float gradients (atomics reorder the
 additions): 1e-5 (f32) / 1e-11 (f64), scaled by the transposed prefilter's gain where it applies.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -321,7 +323,16 @@ def test_fast_prefilter_kernels():
     dev = torch.device("cuda", torch.cuda.current_device())
     rng = np.random.default_rng(21)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    for shape in ((64,), (70, 3, 97), (129, 200), (5, 64, 7), (3, 100, 65), (300, 70)):
+    shapes = ((64,), (70, 3, 97), (129, 200), (5, 64, 7), (3, 100, 65), (300, 70),
+              # 16-byte-aligned extents (vector tiles), half-width tiles, lines too long for a tile
+              (128, 64, 96), (96, 8, 256), (500, 4, 64), (2000, 8), (8, 2000), (40, 1100))
+    for shape, tiles in [(s, t) for s in shapes for t in (True, False)]:
+        # EDHIP_NO_LINE_TILES: the block-recompute kernels that serve lines too long for an LDS tile
+        os.environ.pop("EDHIP_NO_LINE_TILES", None)
+        if not tiles:
+            if len(shape) == 3 and shape[0] > 100:
+                continue
+            os.environ["EDHIP_NO_LINE_TILES"] = "1"
         for order in (2, 3):
             for dtype, flag, tol in ((np.float32, _lib.FLAG_AUTO, 2e-6), (np.float64, _lib.FLAG_AUTO, 1e-13)):
                 x = rng.standard_normal(shape).astype(dtype)
@@ -352,6 +363,7 @@ def test_fast_prefilter_kernels():
                     want = scipy.ndimage.spline_filter1d(x.T.astype(np.float64), order=order, axis=1)
                     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0,
                                                atol=tol * np.abs(want).max())
+    os.environ.pop("EDHIP_NO_LINE_TILES", None)
 
 
 def test_raw_displacement_flag_equals_explicit_prefilter():
