@@ -207,3 +207,63 @@ class Plan(object):
         inv = inverse_of_affine(affine, self.naxis)
         self.inverse_affine = compose_rotation_zoom(
             rotate, zoom, inv, [self.output_shapes[0][d] for d in self.axis[0]])
+
+
+# ---- crop-aware prefilter --------------------------------------
+# With a crop only a box of the source volume is ever read.  The B-spline prefilter is an
+# exponentially decaying filter (|pole|^k), so filtering that box plus a margin gives the same
+# coefficients inside the box as filtering the whole volume, to below fp64 rounding.
+
+# margin (samples) after which a cut in the line is invisible: |z|^m < 1e-18 for the largest pole
+PREFILTER_MARGIN = {2: 24, 3: 32, 4: 56, 5: 64}
+
+
+def source_box(plan, i, in_shape, cbox):
+    """Inclusive index range [lo, hi] along every deformed axis of input `i` that contains every
+    source sample a tap of the output can touch.  `cbox[h] = (floor(min c_h), ceil(max c_h))` is
+    the range of the source coordinate before the boundary map (edhip_source_box); the tap window
+    of deform.c:783-813 is added here.  Where the range leaves the array the boundary map
+    decides: 'nearest' / 'constant' clip it, the folding modes fall back to the whole axis."""
+    ax = plan.axis[i]
+    order = int(plan.order[i])
+    mode = int(plan.mode[i])
+    box = []
+    for h in range(plan.naxis):
+        n = int(in_shape[ax[h]])
+        # one sample of slack: the kernels' own coordinate arithmetic may round differently
+        lo = int(cbox[h][0]) - order // 2 - 1
+        hi = int(cbox[h][1]) + order - order // 2 + 1
+        if lo < 0 or hi > n - 1:
+            if mode in (MODE_CODES['nearest'], MODE_CODES['constant']):
+                clipped_lo, clipped_hi = lo < 0, hi > n - 1
+                lo, hi = min(max(lo, 0), n - 1), max(min(hi, n - 1), 0)
+                # windows that stick out are mirror-indexed (deform.c:795-813): up to `order`
+                # samples inward of the edge
+                if clipped_lo:
+                    hi = max(hi, min(order, n - 1))
+                if clipped_hi:
+                    lo = min(lo, max(n - 1 - order, 0))
+            else:
+                lo, hi = 0, n - 1
+        box.append((lo, hi))
+    return box
+
+
+def prefilter_window(box, in_shape, axes, order, slack_last=0):
+    """The box grown by the filter's decay margin, clipped to the array: slices over the deformed
+    axes, or None when that would not save at least 40 % of the volume.  `slack_last` extra
+    samples are kept after the box on the last axis (the staging loads of the tile kernels read
+    whole padded rows)."""
+    m = PREFILTER_MARGIN.get(int(order), 64)
+    win = []
+    sub = full = 1
+    for k, ((lo, hi), a) in enumerate(zip(box, axes)):
+        n = int(in_shape[a])
+        extra = slack_last if k == len(box) - 1 else 0
+        w0, w1 = max(0, lo - max(m, extra)), min(n, hi + 1 + max(m, extra))
+        win.append((w0, w1))
+        sub *= w1 - w0
+        full *= n
+    if sub > 0.6 * full:
+        return None
+    return win

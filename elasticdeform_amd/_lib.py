@@ -38,7 +38,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libedhip.so
 
 # every symbol include/edhip.h declares
 EXPORTS = ('edhip_version', 'edhip_status_string', 'edhip_device_count', 'edhip_deform',
-           'edhip_spline_filter1d')
+           'edhip_source_box', 'edhip_spline_filter1d')
 
 
 class EdhipArray(ctypes.Structure):
@@ -78,6 +78,12 @@ def load():
             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
             ctypes.POINTER(ctypes.c_double), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p,
+            ctypes.c_size_t]
+        L.edhip_source_box.restype = ctypes.c_int
+        L.edhip_source_box.argtypes = [
+            ctypes.POINTER(EdhipArray), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+            ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+            ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p,
             ctypes.c_size_t]
         L.edhip_spline_filter1d.restype = ctypes.c_int
         L.edhip_spline_filter1d.argtypes = [
@@ -143,6 +149,30 @@ def deform(gradient, in_descs, disp_desc, output_offset, out_descs, axis, orders
         cvals.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), aff, int(flags),
         ctypes.c_void_p(stream), buf, 256)
     raise_for_status(status, buf)
+
+
+def source_box(disp_desc, in_len, out_len, output_offset, inverse_affine, flags, stream):
+    """edhip_source_box -> int64 array (naxis, 2): floor(min) / ceil(max) of the unmapped source
+    coordinate along every deformed axis.  Synchronises the stream."""
+    L = load()
+    in_len = numpy.ascontiguousarray(in_len, dtype=numpy.int64)
+    out_len = numpy.ascontiguousarray(out_len, dtype=numpy.int64)
+    naxis = len(in_len)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    off = aff = None
+    if output_offset is not None:
+        off_arr = numpy.ascontiguousarray(output_offset, dtype=numpy.int64)
+        off = off_arr.ctypes.data_as(p64)
+    if inverse_affine is not None:
+        aff_arr = numpy.ascontiguousarray(inverse_affine, dtype=numpy.float64)
+        aff = aff_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    box = numpy.zeros((naxis, 2), dtype=numpy.int64)
+    buf = ctypes.create_string_buffer(256)
+    status = L.edhip_source_box(ctypes.byref(disp_desc), in_len.ctypes.data_as(p64),
+                                out_len.ctypes.data_as(p64), off, naxis, aff, int(flags),
+                                ctypes.c_void_p(stream), box.ctypes.data_as(p64), buf, 256)
+    raise_for_status(status, buf)
+    return box
 
 
 def spline_filter1d(in_desc, out_desc, axis, order, transpose, flags, stream):

@@ -52,6 +52,160 @@ __device__ __forceinline__ void atomic_accumulate(char* p, int dt, double t)
     }
 }
 
+// displacement at output voxel o: cubic B-spline of the control grid, deform.c:650-758
+template <int NAXIS>
+__device__ __forceinline__ void eval_displacement(const GridGeom& g, const int64_t* o, double* displ)
+{
+    double dw[NAXIS][4];
+    int64_t dtap[NAXIS][4];   // byte offsets of the 4 taps on each grid axis
+#pragma unroll
+    for (int k = 0; k < NAXIS; ++k) {
+        const double cp = control_coordinate(g.ncp[k], o[k] + g.off[k], g.in_len[k]);
+        const int64_t start = window_start(cp, 3);
+        const bool edge = start < 0 || start + 3 >= g.ncp[k];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int64_t idx = edge ? mirror_index(start + l, g.ncp[k]) : start + l;
+            dtap[k][l] = idx * g.disp_stride[k + 1];
+        }
+        spline_weights(cp, 3, dw[k]);
+    }
+    constexpr int kDispTaps = 1 << (2 * NAXIS);
+#pragma unroll
+    for (int h = 0; h < NAXIS; ++h) {
+        const char* base = g.disp + g.disp_stride[0] * h;
+        double acc = 0.0;
+        for (int t = 0; t < kDispTaps; ++t) {   // lexicographic, last axis fastest (:623-636)
+            int64_t offs = 0;
+#pragma unroll
+            for (int k = 0; k < NAXIS; ++k)
+                offs += dtap[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
+            double coeff = load_as_double(base + offs, g.disp_dtype);
+#pragma unroll
+            for (int k = 0; k < NAXIS; ++k)
+                coeff *= dw[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
+            acc += coeff;
+        }
+        displ[h] = acc;
+    }
+}
+
+// source coordinate before the boundary map, deform.c:771-781
+template <int NAXIS>
+__device__ __forceinline__ double raw_coordinate(const GridGeom& g, const int64_t* o, int h, double displ)
+{
+    double cc;
+    if (g.has_affine) {
+        cc = 0.0;
+#pragma unroll
+        for (int l = 0; l < NAXIS; ++l)
+            cc += g.affine[h * (NAXIS + 1) + l] * (double)o[l];
+        cc += g.affine[h * (NAXIS + 1) + NAXIS];
+    } else {
+        cc = (double)o[h];
+    }
+    return cc + (double)g.off[h] + displ;
+}
+
+// edhip_source_box: floor(min) / ceil(max) of the raw source coordinates over all output voxels
+__global__ void source_box_init_kernel(int* box, int naxis)
+{
+    if ((int)threadIdx.x < 2 * naxis)
+        box[threadIdx.x] = (threadIdx.x & 1) ? (int)0x80000000 : 0x7fffffff;
+}
+
+// The control grid is first copied into LDS as doubles (component-major, C order): at 64 x naxis
+// dependent global loads per voxel the kernel was latency-bound (326 us for a 64^3 crop).
+template <int NAXIS>
+__global__ __launch_bounds__(256) void source_box_kernel(const GridGeom g, int* box)
+{
+    extern __shared__ double sgrid[];       // [NAXIS][ncp_0]...[ncp_{NAXIS-1}]
+    int cstride[NAXIS];                     // element strides of the LDS copy
+    int per = 1;
+#pragma unroll
+    for (int k = NAXIS - 1; k >= 0; --k) {
+        cstride[k] = per;
+        per *= (int)g.ncp[k];
+    }
+    for (int e = threadIdx.x; e < per * NAXIS; e += blockDim.x) {
+        int r = e % per;
+        int64_t offs = g.disp_stride[0] * (e / per);
+#pragma unroll
+        for (int k = 0; k < NAXIS; ++k) {
+            offs += g.disp_stride[k + 1] * (r / cstride[k]);
+            r %= cstride[k];
+        }
+        sgrid[e] = load_as_double(g.disp + offs, g.disp_dtype);
+    }
+    __syncthreads();
+
+    int lo[NAXIS], hi[NAXIS];
+#pragma unroll
+    for (int h = 0; h < NAXIS; ++h) {
+        lo[h] = 0x7fffffff;
+        hi[h] = (int)0x80000000;
+    }
+    for (int64_t kk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; kk < g.nvox;
+         kk += (int64_t)gridDim.x * blockDim.x) {
+        int64_t o[NAXIS];
+        int64_t r = kk;
+#pragma unroll
+        for (int k = NAXIS - 1; k >= 0; --k) {
+            const int64_t q = r / g.out_len[k];
+            o[k] = r - q * g.out_len[k];
+            r = q;
+        }
+        // same evaluation as eval_displacement (deform.c:650-758), taps from the LDS copy
+        double dw[NAXIS][4];
+        int dtap[NAXIS][4];
+#pragma unroll
+        for (int k = 0; k < NAXIS; ++k) {
+            const double cp = control_coordinate(g.ncp[k], o[k] + g.off[k], g.in_len[k]);
+            const int64_t start = window_start(cp, 3);
+            const bool edge = start < 0 || start + 3 >= g.ncp[k];
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                dtap[k][l] = (int)(edge ? mirror_index(start + l, g.ncp[k]) : start + l) * cstride[k];
+            spline_weights(cp, 3, dw[k]);
+        }
+        constexpr int kDispTaps = 1 << (2 * NAXIS);
+#pragma unroll
+        for (int h = 0; h < NAXIS; ++h) {
+            double acc = 0.0;
+#pragma unroll 16
+            for (int t = 0; t < kDispTaps; ++t) {
+                int offs = h * per;
+                double coeff = 1.0;
+#pragma unroll
+                for (int k = 0; k < NAXIS; ++k) {
+                    offs += dtap[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
+                    coeff *= dw[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
+                }
+                acc += sgrid[offs] * coeff;
+            }
+            double c = raw_coordinate<NAXIS>(g, o, h, acc);
+            if (!(c == c))
+                c = 0.0;                                        // NaN grid entries: no constraint
+            c = c < -1e9 ? -1e9 : (c > 1e9 ? 1e9 : c);
+            // (the product order differs from the deform kernels' in the last ulps: callers keep
+            // a sample of slack around the box)
+            lo[h] = min(lo[h], (int)floor(c));
+            hi[h] = max(hi[h], (int)ceil(c));
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NAXIS; ++h) {
+        for (int m = 32; m >= 1; m >>= 1) {
+            lo[h] = min(lo[h], __shfl_xor(lo[h], m));
+            hi[h] = max(hi[h], __shfl_xor(hi[h], m));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&box[2 * h], lo[h]);
+            atomicMax(&box[2 * h + 1], hi[h]);
+        }
+    }
+}
+
 template <int NAXIS>
 __global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, const IOView v,
                                                            const int gradient)
@@ -81,40 +235,8 @@ __global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, con
         }
     }
 
-    // ---- displacement: cubic B-spline of the control grid, deform.c:650-758 -------------------
-    double dw[NAXIS][4];
-    int64_t dtap[NAXIS][4];   // byte offsets of the 4 taps on each grid axis
-#pragma unroll
-    for (int k = 0; k < NAXIS; ++k) {
-        const double cp = control_coordinate(g.ncp[k], o[k] + g.off[k], g.in_len[k]);
-        const int64_t start = window_start(cp, 3);
-        const bool edge = start < 0 || start + 3 >= g.ncp[k];
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            const int64_t idx = edge ? mirror_index(start + l, g.ncp[k]) : start + l;
-            dtap[k][l] = idx * g.disp_stride[k + 1];
-        }
-        spline_weights(cp, 3, dw[k]);
-    }
     double displ[NAXIS];
-    constexpr int kDispTaps = 1 << (2 * NAXIS);
-#pragma unroll
-    for (int h = 0; h < NAXIS; ++h) {
-        const char* base = g.disp + g.disp_stride[0] * h;
-        double acc = 0.0;
-        for (int t = 0; t < kDispTaps; ++t) {   // lexicographic, last axis fastest (:623-636)
-            int64_t offs = 0;
-#pragma unroll
-            for (int k = 0; k < NAXIS; ++k)
-                offs += dtap[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
-            double coeff = load_as_double(base + offs, g.disp_dtype);
-#pragma unroll
-            for (int k = 0; k < NAXIS; ++k)
-                coeff *= dw[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
-            acc += coeff;
-        }
-        displ[h] = acc;
-    }
+    eval_displacement<NAXIS>(g, o, displ);
 
     // ---- source coordinate, boundary map, window + weights, deform.c:768-824 ------------------
     const int order = v.order;
@@ -123,17 +245,7 @@ __global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, con
     bool constant = false;
 #pragma unroll
     for (int h = 0; h < NAXIS; ++h) {
-        double cc;
-        if (g.has_affine) {
-            cc = 0.0;
-#pragma unroll
-            for (int l = 0; l < NAXIS; ++l)
-                cc += g.affine[h * (NAXIS + 1) + l] * (double)o[l];
-            cc += g.affine[h * (NAXIS + 1) + NAXIS];
-        } else {
-            cc = (double)o[h];
-        }
-        cc = map_coordinate(cc + (double)g.off[h] + displ[h], g.in_len[h], v.mode);
+        const double cc = map_coordinate(raw_coordinate<NAXIS>(g, o, h, displ[h]), g.in_len[h], v.mode);
         if (!constant && cc > -1.0) {
             const int64_t start = window_start(cc, order);
             const bool edge = start < 0 || start + order >= g.in_len[h];
@@ -247,6 +359,31 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
     case 2: hipLaunchKernelGGL(deform_exact_kernel<2>, grid, dim3(block), 0, stream, g, v, gradient); break;
     case 3: hipLaunchKernelGGL(deform_exact_kernel<3>, grid, dim3(block), 0, stream, g, v, gradient); break;
     case 4: hipLaunchKernelGGL(deform_exact_kernel<4>, grid, dim3(block), 0, stream, g, v, gradient); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream)
+{
+    hipLaunchKernelGGL(source_box_init_kernel, dim3(1), dim3(64), 0, stream, box, g.naxis);
+    if (g.nvox <= 0)
+        return hipGetLastError();
+    int64_t points = g.naxis;
+    for (int k = 0; k < g.naxis; ++k)
+        points *= g.ncp[k];
+    if (points > 7680)          // 60 KiB of LDS
+        return hipErrorNotSupported;
+    const size_t lds = (size_t)points * sizeof(double);
+    int64_t nblk = (g.nvox + 255) / 256;
+    if (nblk > 2048)
+        nblk = 2048;
+    const dim3 grid((unsigned)nblk);
+    switch (g.naxis) {
+    case 1: hipLaunchKernelGGL(source_box_kernel<1>, grid, dim3(256), lds, stream, g, box); break;
+    case 2: hipLaunchKernelGGL(source_box_kernel<2>, grid, dim3(256), lds, stream, g, box); break;
+    case 3: hipLaunchKernelGGL(source_box_kernel<3>, grid, dim3(256), lds, stream, g, box); break;
+    case 4: hipLaunchKernelGGL(source_box_kernel<4>, grid, dim3(256), lds, stream, g, box); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

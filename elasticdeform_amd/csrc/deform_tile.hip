@@ -277,6 +277,7 @@ struct TileGeom {
     int out_len[3];
     int tiles[3];         // number of tiles per axis
     int strips_x;         // strips per tile row
+    int strip_tiles;      // tiles per strip (8, or 4 / 2 for small outputs)
     int nstrips;
     int ncpx;             // control points along x = stride of one component row of Q
     int box_cap;          // elements per LDS copy
@@ -328,8 +329,8 @@ __device__ __forceinline__ bool strip_position(const TileGeom& tg, int work, Str
     s /= tg.strips_x;
     sp.ty = s % tg.tiles[1];
     sp.tz = s / tg.tiles[1];
-    sp.tx0 = sx * kStrip;
-    sp.ntile = min(kStrip, tg.tiles[2] - sp.tx0);
+    sp.tx0 = sx * tg.strip_tiles;
+    sp.ntile = min(tg.strip_tiles, tg.tiles[2] - sp.tx0);
     return true;
 }
 
@@ -1157,7 +1158,13 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         ve.in_step_stride[l] = v.in_step_stride[l] / (int64_t)sizeof(T);
         ve.out_step_stride[l] = v.out_step_stride[l] / (int64_t)sizeof(T);
     }
-    tg.strips_x = (tg.tiles[2] + kStrip - 1) / kStrip;
+    // strips of 8 tiles amortise the prologue; small outputs (crops) take shorter strips so that the
+    // launch still has a few workgroups per CU (even lengths: the gradient kernel walks 16-wide tiles)
+    tg.strip_tiles = kStrip;
+    while (tg.strip_tiles > 2 &&
+           (int64_t)tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles) < 1024)
+        tg.strip_tiles >>= 1;
+    tg.strips_x = (tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles;
     const int64_t nstrips = (int64_t)tg.tiles[0] * tg.tiles[1] * tg.strips_x;
     const int64_t ntiles = (int64_t)tg.tiles[0] * tg.tiles[1] * tg.tiles[2];
     if (nstrips <= 0)

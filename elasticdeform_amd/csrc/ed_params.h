@@ -48,6 +48,10 @@ struct IOView {
 // return the hipError_t of the launch.
 hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
 
+// edhip_source_box: box[2h] = floor(min), box[2h+1] = ceil(max) of the raw (unmapped) source
+// coordinate along axis h over every output voxel; `box` = 2 * naxis device ints
+hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream);
+
 // fast path: returns hipErrorNotSupported (without launching) when the case is outside its
 // envelope so that the caller can route it to the exact kernels instead.
 hipError_t launch_deform_fast(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);

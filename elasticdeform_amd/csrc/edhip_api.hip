@@ -46,6 +46,75 @@ int dtype_size(int dt)
 
 int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
 
+// Geometry shared by every input of a call (deform.c:381-391,439-451,771-776); with
+// EDHIP_FLAG_RAW_DISPLACEMENT the control grid is prefiltered into the head of the workspace.
+int make_geometry(const edhip_array* displacement, const int64_t* in_len, const int64_t* out_len,
+                  const int64_t* output_offset, int naxis, const double* affine, uint32_t flags,
+                  hipStream_t stream, ed::GridGeom& g, char* err, size_t errlen)
+{
+    using namespace ed;
+    memset(&g, 0, sizeof(g));
+    g.naxis = naxis;
+    g.has_affine = affine != nullptr;
+    g.disp_dtype = displacement->dtype;
+    g.disp = (const char*)displacement->data;
+    g.nvox = 1;
+    for (int k = 0; k < naxis; ++k) {
+        g.in_len[k] = in_len[k];
+        g.out_len[k] = out_len[k];
+        g.off[k] = output_offset ? output_offset[k] : 0;
+        g.ncp[k] = displacement->shape[k + 1];
+        g.nvox *= g.out_len[k];
+        if (g.out_len[k] > 0 && g.in_len[k] < 2)
+            // the reference divides by (I_k - 1) (deform.c:643,655): undefined there, refused here
+            return fail(err, errlen, EDHIP_ERR_INVALID,
+                        "deformed axes must have at least 2 elements");
+    }
+    for (int k = 0; k <= naxis; ++k)
+        g.disp_stride[k] = displacement->stride_bytes[k];
+    if (flags & EDHIP_FLAG_RAW_DISPLACEMENT) {
+        // prefilter the raw control grid into the head of the stream's workspace (one launch)
+        int64_t total = 1;
+        for (int k = 0; k <= naxis; ++k)
+            total *= displacement->shape[k];
+        if (total > 4096)
+            return fail(err, errlen, EDHIP_ERR_UNSUPPORTED,
+                        "raw displacement grids are limited to 4096 points");
+        // reserve everything this call can need now: a later, larger request would move the buffer
+        // and lose the grid
+        hipError_t e = hipSuccess;
+        void* ws = workspace_reserve(stream, deform_tile_workspace_bytes(g), &e);
+        if (!ws)
+            return hip_fail(err, errlen, e, "scratch allocation");
+        GridPrefilter gp;
+        memset(&gp, 0, sizeof(gp));
+        gp.in = (const char*)displacement->data;
+        gp.out = (char*)ws;
+        gp.dtype = displacement->dtype;
+        gp.elem_size = dtype_size(displacement->dtype);
+        gp.ndim = naxis + 1;
+        gp.total = (int)total;
+        gp.pole = -0.267949192431122706472553658494127633;      // order 3, SciPy's literal
+        gp.gain = (1.0 - gp.pole) * (1.0 - 1.0 / gp.pole);
+        int64_t stride = gp.elem_size;
+        for (int k = naxis; k >= 0; --k) {
+            gp.shape[k] = (int)displacement->shape[k];
+            gp.stride_bytes[k] = displacement->stride_bytes[k];
+            gp.pole_pow[k] = std::pow(gp.pole, (double)(gp.shape[k] - 1));
+            g.disp_stride[k] = stride;
+            stride *= gp.shape[k];
+        }
+        e = launch_grid_prefilter(gp, stream);
+        if (e != hipSuccess)
+            return hip_fail(err, errlen, e, "grid prefilter launch");
+        g.disp = (const char*)ws;
+    }
+    if (affine)
+        for (int k = 0; k < naxis * (naxis + 1); ++k)
+            g.affine[k] = affine[k];
+    return EDHIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -126,65 +195,17 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
 
     // ---- shared geometry ------------------------------------------------------------------------
     GridGeom g;
-    memset(&g, 0, sizeof(g));
-    g.naxis = naxis;
-    g.has_affine = affine != nullptr;
-    g.disp_dtype = displacement->dtype;
-    g.disp = (const char*)displacement->data;
-    g.nvox = 1;
-    for (int k = 0; k < naxis; ++k) {
-        g.in_len[k] = inputs[0].shape[axis[k]];
-        g.out_len[k] = outputs[0].shape[axis[k]];
-        g.off[k] = output_offset ? output_offset[k] : 0;
-        g.ncp[k] = displacement->shape[k + 1];
-        g.nvox *= g.out_len[k];
-        if (g.out_len[k] > 0 && g.in_len[k] < 2)
-            // the reference divides by (I_k - 1) (deform.c:643,655): undefined there, refused here
-            return fail(err, errlen, EDHIP_ERR_INVALID,
-                        "deformed axes must have at least 2 elements");
-    }
-    for (int k = 0; k <= naxis; ++k)
-        g.disp_stride[k] = displacement->stride_bytes[k];
-    if (flags & EDHIP_FLAG_RAW_DISPLACEMENT) {
-        // prefilter the raw control grid into the head of the stream's workspace (one launch)
-        int64_t total = 1;
-        for (int k = 0; k <= naxis; ++k)
-            total *= displacement->shape[k];
-        if (total > 4096)
-            return fail(err, errlen, EDHIP_ERR_UNSUPPORTED,
-                        "raw displacement grids are limited to 4096 points");
-        // reserve everything this call can need now: a later, larger request would move the buffer
-        // and lose the grid
-        hipError_t e = hipSuccess;
-        void* ws = workspace_reserve(stream, deform_tile_workspace_bytes(g), &e);
-        if (!ws)
-            return hip_fail(err, errlen, e, "scratch allocation");
-        GridPrefilter gp;
-        memset(&gp, 0, sizeof(gp));
-        gp.in = (const char*)displacement->data;
-        gp.out = (char*)ws;
-        gp.dtype = displacement->dtype;
-        gp.elem_size = dtype_size(displacement->dtype);
-        gp.ndim = naxis + 1;
-        gp.total = (int)total;
-        gp.pole = -0.267949192431122706472553658494127633;      // order 3, SciPy's literal
-        gp.gain = (1.0 - gp.pole) * (1.0 - 1.0 / gp.pole);
-        int64_t stride = gp.elem_size;
-        for (int k = naxis; k >= 0; --k) {
-            gp.shape[k] = (int)displacement->shape[k];
-            gp.stride_bytes[k] = displacement->stride_bytes[k];
-            gp.pole_pow[k] = std::pow(gp.pole, (double)(gp.shape[k] - 1));
-            g.disp_stride[k] = stride;
-            stride *= gp.shape[k];
+    {
+        int64_t in_len[kMaxAxes], out_len[kMaxAxes];
+        for (int k = 0; k < naxis; ++k) {
+            in_len[k] = inputs[0].shape[axis[k]];
+            out_len[k] = outputs[0].shape[axis[k]];
         }
-        e = launch_grid_prefilter(gp, stream);
-        if (e != hipSuccess)
-            return hip_fail(err, errlen, e, "grid prefilter launch");
-        g.disp = (const char*)ws;
+        const int st = make_geometry(displacement, in_len, out_len, output_offset, naxis, affine, flags,
+                                     stream, g, err, errlen);
+        if (st != EDHIP_OK)
+            return st;
     }
-    if (affine)
-        for (int k = 0; k < naxis * (naxis + 1); ++k)
-            g.affine[k] = affine[k];
     if (g.nvox <= 0)
         return EDHIP_OK;
 
@@ -248,6 +269,54 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         if (e != hipSuccess)
             return hip_fail(err, errlen, e, "deform kernel launch");
     }
+    return EDHIP_OK;
+}
+
+int edhip_source_box(const edhip_array* displacement, const int64_t* in_len, const int64_t* out_len,
+                     const int64_t* output_offset, int naxis, const double* affine, uint32_t flags,
+                     void* hip_stream, int64_t* box, char* err, size_t errlen)
+{
+    using namespace ed;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (err && errlen)
+        err[0] = 0;
+    if (!in_len || !out_len || !box || naxis < 1)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis list");
+    if (naxis > kMaxAxes)
+        return fail(err, errlen, EDHIP_ERR_UNSUPPORTED,
+                    "more than %d deformed axes are not supported on the GPU", kMaxAxes);
+    if (!displacement || displacement->ndim != naxis + 1 || displacement->shape[0] != naxis)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid displacement shape");
+    if (!dtype_ok(displacement->dtype))
+        return fail(err, errlen, EDHIP_ERR_DTYPE, "data type not supported");
+    for (int k = 0; k <= naxis; ++k)
+        if (displacement->shape[k] <= 0)
+            return fail(err, errlen, EDHIP_ERR_INVALID, "invalid displacement shape");
+    GridGeom g;
+    const int st = make_geometry(displacement, in_len, out_len, output_offset, naxis, affine, flags,
+                                 stream, g, err, errlen);
+    if (st != EDHIP_OK)
+        return st;
+    hipError_t e = hipSuccess;
+    // the box lives in the last bytes of the workspace head (the control grid uses at most 32 KiB)
+    char* ws = (char*)workspace_reserve(stream, deform_tile_workspace_bytes(g), &e);
+    if (!ws)
+        return hip_fail(err, errlen, e, "scratch allocation");
+    int* dbox = (int*)(ws + kWorkspaceGridBytes - 64);
+    e = launch_source_box(g, dbox, stream);
+    if (e == hipErrorNotSupported)
+        return fail(err, errlen, EDHIP_ERR_UNSUPPORTED,
+                    "edhip_source_box: control grids are limited to 7680 values");
+    if (e != hipSuccess)
+        return hip_fail(err, errlen, e, "source box launch");
+    int hbox[2 * kMaxAxes];
+    e = hipMemcpyAsync(hbox, dbox, sizeof(int) * 2 * naxis, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(stream);
+    if (e != hipSuccess)
+        return hip_fail(err, errlen, e, "source box read-back");
+    for (int k = 0; k < 2 * naxis; ++k)
+        box[k] = hbox[k];
     return EDHIP_OK;
 }
 

@@ -126,6 +126,75 @@ def _filter_axes(x, axes, order, transpose, device):
     return src
 
 
+# Crop-aware prefilter: engaged when it saves at least this many voxels per filter pass (summed
+# over the inputs).  Finding the window costs a stream synchronisation (edhip_source_box hands the
+# box to the host), which exposes ~0.25 ms of host-side launch latency: about what filtering
+# 48M float32 voxels along three axes costs on an MI355X.
+CROP_WINDOW_MIN_SAVING = 48e6
+
+
+def _crop_windows(plan, shapes, dtypes, disp_desc, dflag, crop, prefilter, device):
+    """Crop-aware prefilter: per input, the window (start, stop) along
+    every deformed axis that has to be filtered, or None for 'the whole array'.  Only for floating
+    point volumes outside 'exact' arithmetic: the window's coefficients equal the whole-volume
+    ones to below fp64 rounding, not bit for bit."""
+    n = len(shapes)
+    wins = [None] * n
+    if crop is None or not prefilter or (_flags & _lib.FLAG_EXACT) or os.environ.get('EDHIP_NO_CROP_WINDOW'):
+        return wins
+    todo = [i for i in range(n) if plan.order[i] > 1 and dtypes[i] in ('float32', 'float64')]
+    if not todo:
+        return wins
+    if disp_desc.ndim < 2 or numpy.prod(list(disp_desc.shape)[:disp_desc.ndim]) > 7680:
+        return wins                 # edhip_source_box keeps the control grid in LDS
+    ax0 = plan.axis[0]
+    in_len = [int(shapes[0][a]) for a in ax0]
+    out_len = [int(plan.output_shapes[0][a]) for a in ax0]
+
+    def volume(i, lens):            # voxels of input i when its deformed axes have extents `lens`
+        v = float(numpy.prod([int(d) for d in shapes[i]], dtype=numpy.float64))
+        for a, l in zip(plan.axis[i], lens):
+            v *= float(l) / float(shapes[i][a])
+        return v
+    # upper bound of the saving: no window is smaller than the output box plus the filter margins
+    def at_least(i):
+        m = _host.PREFILTER_MARGIN.get(int(plan.order[i]), 64)
+        return [min(n_in, n_out + 2 * m) for n_in, n_out in zip(in_len, out_len)]
+    if sum(volume(i, in_len) - volume(i, at_least(i)) for i in todo) < CROP_WINDOW_MIN_SAVING:
+        return wins
+    cbox = _lib.source_box(disp_desc, in_len, out_len, plan.output_offset, plan.inverse_affine,
+                           _flags | dflag, _stream(device))
+    saving = 0.0
+    for i in todo:
+        box = _host.source_box(plan, i, shapes[i], cbox)
+        # the float32 tile kernel stages whole padded rows (up to 49 samples past a window start)
+        wins[i] = _host.prefilter_window(box, shapes[i], plan.axis[i], plan.order[i], slack_last=52)
+        if wins[i] is not None:
+            saving += volume(i, in_len) - volume(i, [w1 - w0 for w0, w1 in wins[i]])
+    if saving < CROP_WINDOW_MIN_SAVING:
+        return [None] * n
+    return wins
+
+
+def _window_view(x, axes, win):
+    sl = [slice(None)] * x.dim()
+    for a, (w0, w1) in zip(axes, win):
+        sl[a] = slice(w0, w1)
+    return x[tuple(sl)]
+
+
+def _windowed_desc(sub, full_shape, axes, win):
+    """Descriptor of the full-size array whose samples inside the window live in `sub` (a tensor
+    of the window's shape): same strides, base pointer moved back by the window's start.  The
+    kernels only ever touch samples inside the window (source_box is conservative)."""
+    es = sub.element_size()
+    ptr = sub.data_ptr()
+    for a, (w0, _) in zip(axes, win):
+        ptr -= w0 * sub.stride(a) * es
+    return _lib.describe(ptr, _dtype_name(sub), tuple(int(v) for v in full_shape),
+                         tuple(st * es for st in sub.stride()))
+
+
 def _prefilter_displacement(displacement, device):
     """Order-3 prefilter of the control grid along every grid axis (deform_grid.py:166-169,
     :269-272); the output keeps the displacement's dtype like numpy.zeros_like there.
@@ -177,17 +246,31 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
         Xd = [_to_device(x, device) for x in Xs]
         dd = _to_device(displacement, device)
 
-        # prefilter the inputs along their deformed axes (deform_grid.py:155-164) ...
-        Xf = [(_filter_axes(x, plan.axis[i], int(plan.order[i]), False, device)
-               if prefilter and plan.order[i] > 1 else x) for i, x in enumerate(Xd)]
-        # ... and always the displacement (deform_grid.py:166-169)
+        # the displacement is always prefiltered (deform_grid.py:166-169); the inputs along their
+        # deformed axes (deform_grid.py:155-164): the whole array, or -- with a crop -- only the
+        # window of it that the cropped output can reach
         df, dflag = _prefilter_displacement(dd, device)
+        wins = _crop_windows(plan, [tuple(x.shape) for x in Xd], [_dtype_name(x) for x in Xd],
+                             _desc(df), dflag, crop, prefilter, device)
+        Xf, in_descs = [], []
+        for i, x in enumerate(Xd):
+            if not (prefilter and plan.order[i] > 1):
+                xf = x
+                in_descs.append(_desc(x))
+            elif wins[i] is None:
+                xf = _filter_axes(x, plan.axis[i], int(plan.order[i]), False, device)
+                in_descs.append(_desc(xf))
+            else:
+                xf = _filter_axes(_window_view(x, plan.axis[i], wins[i]), plan.axis[i],
+                                  int(plan.order[i]), False, device)
+                in_descs.append(_windowed_desc(xf, x.shape, plan.axis[i], wins[i]))
+            Xf.append(xf)                  # keeps the buffers alive until the launch is enqueued
 
         # every output element is written by the kernel (value or cval), so no zero fill is needed
         outs = [torch.empty(tuple(int(s) for s in shape), dtype=x.dtype, device=device)
                 for shape, x in zip(plan.output_shapes, Xd)]
 
-        _lib.deform(False, [_desc(x) for x in Xf], _desc(df), plan.output_offset,
+        _lib.deform(False, in_descs, _desc(df), plan.output_offset,
                     [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
                     plan.inverse_affine, _flags | dflag, _stream(device))
         res = [_from_device(o, x) for o, x in zip(outs, Xs)]
@@ -232,8 +315,21 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
                     [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
                     plan.inverse_affine, _flags | dflag, _stream(device))
 
-        # gradient of the prefilter: its transpose along each deformed axis (deform_grid.py:276-286)
-        dXf = [(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device)
-                if prefilter and plan.order[i] > 1 else x) for i, x in enumerate(dXs)]
+        # gradient of the prefilter: its transpose along each deformed axis (deform_grid.py:276-286).
+        # With a crop the scatter only touched a box of dX: the transposed filter runs on that box
+        # plus its decay margin and the result replaces the box (the rest stays exactly zero, where
+        # the whole-volume filter would leave values below 1e-18 of the gradient's scale).
+        wins = _crop_windows(plan, [tuple(x.shape) for x in dXs], [_dtype_name(x) for x in dXs],
+                             _desc(df), dflag, crop, prefilter, device)
+        dXf = []
+        for i, x in enumerate(dXs):
+            if not (prefilter and plan.order[i] > 1):
+                dXf.append(x)
+            elif wins[i] is None:
+                dXf.append(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device))
+            else:
+                view = _window_view(x, plan.axis[i], wins[i])
+                view.copy_(_filter_axes(view, plan.axis[i], int(plan.order[i]), True, device))
+                dXf.append(x)
         res = [_from_device(x, dy) for x, dy in zip(dXf, dYs)]
     return res if isinstance(dY, list) else res[0]

@@ -157,6 +157,26 @@ int edhip_deform(int gradient, int ninputs,
                  char* err, size_t errlen);
 
 /*
+ * Bounding box of the source coordinates of a call: for every deformed axis h,
+ *   box[2h]   = floor(min c_h),   box[2h+1] = ceil(max c_h)
+ * over all output voxels, where c_h = affine(o)_h + offset_h + displacement_h(o) is the source
+ * coordinate of deform.c:771-781 BEFORE the boundary map (values are clamped to +-1e9).  The
+ * arguments have the meaning they have in edhip_deform; in_len / out_len (host int64[naxis]) are
+ * the deformed extents of inputs[0] / outputs[0].  The box is returned to the host, so this call
+ * SYNCHRONISES `hip_stream`.  Control grids of more than 7680 values (naxis * prod ncp) are
+ * refused with EDHIP_ERR_UNSUPPORTED.
+ *
+ * No counterpart in the reference.  It lets the host layer restrict the input prefilter
+ * (deform_grid.py:155-164) to the part of a volume that a cropped output can reach.
+ */
+int edhip_source_box(const edhip_array* displacement,
+                     const int64_t* in_len, const int64_t* out_len,
+                     const int64_t* output_offset, int naxis, const double* affine,
+                     uint32_t flags, void* hip_stream,
+                     int64_t* box,
+                     char* err, size_t errlen);
+
+/*
  * One-dimensional B-spline prefilter along `axis`, mirror boundary.
  *   transpose == 0 : scipy.ndimage.spline_filter1d(input, order, axis, output, mode='mirror')
  *                    (call sites deform_grid.py:160,168,271)

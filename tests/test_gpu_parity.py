@@ -385,3 +385,95 @@ def test_raw_displacement_flag_equals_explicit_prefilter():
     disp = (rng.standard_normal((2, 4, 3)) * 3).astype(np.float32)
     np.testing.assert_allclose(ed.deform_grid(Y, disp, order=3), orc.deform_grid(Y, disp, order=3),
                                **F32_TOL)
+
+
+# ---- crop-aware prefilter ------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["constant", "nearest", "mirror", "wrap"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_crop_aware_prefilter_matches_whole_volume(mode, dtype):
+    """With a crop only a window of the volume is prefiltered (edhip_source_box + decay margin).
+    The result must agree with the oracle (which filters the whole volume) to the same tolerance
+    as the plain path -- forward and gradient, with and without an affine map, 2-D / 3-D / a
+    channel axis -- and the windows must actually engage for the small crops."""
+    import importlib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    rng = np.random.default_rng(91)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == np.float32 else dict(rtol=1e-10, atol=1e-10)
+    engaged = []
+    orig = dgm._crop_windows
+    saving = dgm.CROP_WINDOW_MIN_SAVING
+    dgm.CROP_WINDOW_MIN_SAVING = 0.0        # small test volumes: engage regardless of the pay-off
+
+    def spy(*a, **k):
+        w = orig(*a, **k)
+        engaged.append(any(x is not None for x in w))
+        return w
+    dgm._crop_windows = spy
+    try:
+        cases = [
+            # shape, axis, points, sigma, crop, affine
+            ((150, 160, 170), None, (3, 3, 3), 3.0, (slice(60, 84), slice(70, 90), slice(80, 110)), None),
+            ((2, 140, 150, 160), (1, 2, 3), (4, 3, 3), 2.0, (slice(5, 30), slice(100, 130), slice(60, 90)), "rot"),
+            ((700, 900), None, (3, 3), 6.0, (slice(300, 360), slice(400, 480)), None),
+            ((150, 160, 170), None, (3, 3, 3), 3.0, (slice(0, 20), slice(140, 160), slice(75, 95)), None),
+        ]
+        for shape, axis, points, sigma, crop, aff in cases:
+            X = rng.random(shape).astype(dtype)
+            naxis = len(points)
+            disp = rng.standard_normal((naxis,) + points) * sigma
+            kw = dict(order=3, mode=mode, cval=0.25, crop=crop, axis=axis)
+            if aff == "rot":
+                th = np.radians(8.0)
+                M = np.array([[1.05, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+                c = np.array([12.0, 15.0, 15.0])
+                kw["affine"] = np.concatenate([M, (c - M.dot(c))[:, None]], axis=1)
+            want = orc.deform_grid(X, disp, **kw)
+            got = ed.deform_grid(X, disp, **kw)
+            np.testing.assert_allclose(got, want, **tol)
+            dY = rng.random(want.shape).astype(dtype)
+            gw = orc.deform_grid_gradient(dY, disp, X_shape=X.shape, **kw)
+            gg = ed.deform_grid_gradient(dY, disp, X_shape=X.shape, **kw)
+            eps = 1e-5 if dtype == np.float32 else 1e-10
+            np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * 8.0 ** naxis * np.abs(gw).max())
+        if mode in ("constant", "nearest"):
+            assert all(engaged), engaged
+        else:
+            assert engaged[0] and engaged[1], engaged      # interior crops engage in every mode
+        # exact arithmetic keeps the whole-volume prefilter (bit-comparable promise)
+        ed.set_arithmetic("exact")
+        del engaged[:]
+        shape, axis, points, sigma, crop, aff = cases[0]
+        X = rng.random(shape).astype(dtype)
+        disp = rng.standard_normal((3,) + points) * sigma
+        np.testing.assert_array_equal(ed.deform_grid(X, disp, order=3, mode=mode, crop=crop),
+                                      orc.deform_grid(X, disp, order=3, mode=mode, crop=crop))
+        assert not any(engaged)
+    finally:
+        dgm._crop_windows = orig
+        dgm.CROP_WINDOW_MIN_SAVING = saving
+
+
+def test_source_box_kernel_vs_oracle_coordinates():
+    """edhip_source_box against a numpy evaluation of the raw source coordinates (the cubic
+    B-spline displacement through SciPy's map_coordinates on the prefiltered grid)."""
+    import importlib
+    import scipy.ndimage
+    from elasticdeform_amd import _lib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(5)
+    in_len, out_len, off = (90, 100, 80), (20, 30, 25), (40, 10, 50)
+    disp = rng.standard_normal((3, 4, 3, 5)) * 7
+    dd = torch.from_numpy(disp).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    A = np.array([[1.1, 0.05, 0, -3.0], [0, 0.9, 0.1, 2.0], [0.02, 0, 1.0, 1.0]])
+    for aff in (None, A):
+        box = _lib.source_box(dgm._desc(dd), in_len, out_len, off, aff, _lib.FLAG_RAW_DISPLACEMENT, stream)
+        o = np.stack(np.meshgrid(*[np.arange(n, dtype=np.float64) for n in out_len], indexing="ij"))
+        cp = [(disp.shape[k + 1] - 1) * (o[k] + off[k]) / (in_len[k] - 1) for k in range(3)]
+        for h in range(3):
+            d = scipy.ndimage.map_coordinates(disp[h], cp, order=3, mode="mirror")
+            base = o[h] if aff is None else sum(aff[h, l] * o[l] for l in range(3)) + aff[h, 3]
+            c = base + off[h] + d
+            assert box[h, 0] == np.floor(c.min()) and box[h, 1] == np.ceil(c.max()), (h, box[h], c.min(), c.max())

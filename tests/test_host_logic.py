@@ -136,3 +136,30 @@ def test_plan_matches_live_reference_helpers():
                 assert p.inverse_affine is None
             else:
                 np.testing.assert_array_equal(p.inverse_affine, inv)
+
+
+def test_crop_window_logic():
+    """Crop-aware prefilter: the host half -- tap window around the
+    coordinate range, boundary handling, decay margin, 'is it worth it'."""
+    X = np.zeros((3, 200, 210, 220), dtype=np.float32)
+    disp = np.zeros((3, 3, 3, 3))
+    plan = _host.Plan([X], disp, 3, 'constant', 0.0, (slice(80, 120),) * 3, [(1, 2, 3)], None, None, None)
+    cbox = [(70, 130), (75, 125), (60, 140)]
+    box = _host.source_box(plan, 0, X.shape, cbox)
+    assert box == [(70 - 2, 130 + 3), (75 - 2, 125 + 3), (60 - 2, 140 + 3)]
+    win = _host.prefilter_window(box, X.shape, (1, 2, 3), 3, slack_last=52)
+    m = _host.PREFILTER_MARGIN[3]
+    assert win == [(68 - m, 134 + m), (73 - m, 129 + m), (58 - 52, 144 + 52)]
+    # a range that leaves the array: clipped for 'constant' / 'nearest' (keeping the mirror taps
+    # of windows that stick out), whole axis for the folding modes
+    cbox = [(-30, 20), (75, 125), (150, 260)]
+    assert _host.source_box(plan, 0, X.shape, cbox) == [(0, 23), (73, 128), (148, 219)]
+    cbox = [(-30, -10), (75, 125), (230, 260)]
+    assert _host.source_box(plan, 0, X.shape, cbox) == [(0, 3), (73, 128), (216, 219)]
+    plan_m = _host.Plan([X], disp, 3, 'mirror', 0.0, (slice(80, 120),) * 3, [(1, 2, 3)], None, None, None)
+    assert _host.source_box(plan_m, 0, X.shape, cbox) == [(0, 199), (73, 128), (0, 219)]
+    # a window that covers most of the volume is not worth a separate pass
+    assert _host.prefilter_window([(0, 199), (0, 209), (10, 200)], X.shape, (1, 2, 3), 3) is None
+    # even orders: floor(c + 0.5) - order // 2 .. + order
+    plan2 = _host.Plan([X], disp, 2, 'constant', 0.0, (slice(80, 120),) * 3, [(1, 2, 3)], None, None, None)
+    assert _host.source_box(plan2, 0, X.shape, [(70, 130)] * 3)[0] == (70 - 2, 130 + 2)

@@ -58,4 +58,11 @@ res["cfg4_multi_crop64_affine_noprefilter_ms"] = timed(lambda: ed.deform_grid(Xs
 # channels (step axis): 4 x 128^3 with shared displacement
 Xc = T(rng.random((4, 128, 128, 128), dtype=np.float32))
 res["4ch_128_axis123_fwd_ms"] = timed(lambda: ed.deform_grid(Xc, da, order=3, mode="mirror", axis=(1, 2, 3)), 5)
+# cfg4-like crop out of a 512^3 volume (crop-aware prefilter pays off with the volume size)
+if os.environ.get("BIG"):
+    Xb = T(rng.random((512, 512, 512), dtype=np.float32))
+    cropb = (slice(224, 288),) * 3
+    res["512_crop64_o3_fwd_ms"] = timed(lambda: ed.deform_grid(Xb, d3, order=3, mode="constant", crop=cropb), 5)
+    dYb = T(rng.random((64, 64, 64), dtype=np.float32))
+    res["512_crop64_o3_grad_ms"] = timed(lambda: ed.deform_grid_gradient(dYb, d3, order=3, mode="constant", crop=cropb, X_shape=(512, 512, 512)), 5)
 print(json.dumps(res, indent=1))
