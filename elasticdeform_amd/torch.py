@@ -57,3 +57,38 @@ def deform_grid(X, displacement, *args, **kwargs):
         return y
     else:
         return y[0]
+
+
+def random_displacement(naxis, points=3, sigma=25, batch=None, device=None, dtype=torch.float64,
+                        generator=None):
+    """
+    Random control-point displacements drawn ON THE DEVICE: ``randn(naxis, *points) * sigma``, the
+    distribution of ``deform_random_grid`` (/root/reference/elasticdeform/deform_grid.py:42-48),
+    from torch's device generator (Philox) instead of NumPy's host RNG -- no host round trip and
+    no H2D copy per sample.  With ``batch=B`` the result has a leading batch axis: one grid per
+    sample of a batch.
+    """
+    if not isinstance(points, (list, tuple)):
+        points = [points] * naxis
+    assert len(points) == naxis
+    shape = (naxis,) + tuple(int(p) for p in points)
+    if batch is not None:
+        shape = (int(batch),) + shape
+    return torch.randn(shape, device=device, dtype=dtype, generator=generator) * sigma
+
+
+def deform_random_grid(X, sigma=25, points=3, order=3, mode='constant', cval=0.0, crop=None,
+                       prefilter=True, axis=None, affine=None, rotate=None, zoom=None,
+                       generator=None):
+    """
+    ``elasticdeform.deform_random_grid`` (deform_grid.py:6-49) for tensors that live on the GPU:
+    same arguments and meaning, but the random grid is drawn on the device of ``X``
+    (:func:`random_displacement`) and the result stays there, with the autograd contract of
+    :func:`deform_grid`.  ``generator``: an optional ``torch.Generator`` of that device.
+    """
+    from . import _host
+    Xs = list(X) if isinstance(X, (list, tuple)) else [X]
+    _, deform_shape = _host.normalize_axis_list(axis, Xs)
+    displacement = random_displacement(len(deform_shape), points, sigma, device=Xs[0].device,
+                                       generator=generator)
+    return deform_grid(X, displacement, order, mode, cval, crop, prefilter, axis, affine, rotate, zoom)

@@ -477,3 +477,29 @@ def test_source_box_kernel_vs_oracle_coordinates():
             base = o[h] if aff is None else sum(aff[h, l] * o[l] for l in range(3)) + aff[h, 3]
             c = base + off[h] + d
             assert box[h, 0] == np.floor(c.min()) and box[h, 1] == np.ceil(c.max()), (h, box[h], c.min(), c.max())
+
+
+def test_device_side_random_grid():
+    """elasticdeform_amd.torch.deform_random_grid: the grid is drawn on the device (Philox) and the
+    call equals deform_grid with that grid; batches of grids come out of one randn."""
+    import elasticdeform_amd.torch as et
+    dev = torch.device("cuda", torch.cuda.current_device())
+    X = torch.rand((40, 50, 30), device=dev, dtype=torch.float32)
+    g = torch.Generator(device=dev)
+    g.manual_seed(123)
+    y = et.deform_random_grid(X, sigma=3, points=[3, 4, 3], order=3, mode="mirror", generator=g)
+    g.manual_seed(123)
+    disp = et.random_displacement(3, [3, 4, 3], 3, device=dev, generator=g)
+    assert disp.shape == (3, 3, 4, 3) and disp.is_cuda and disp.dtype == torch.float64
+    want = orc.deform_grid(X.cpu().numpy(), disp.cpu().numpy(), order=3, mode="mirror")
+    assert y.is_cuda
+    np.testing.assert_allclose(y.cpu().numpy(), want, **F32_TOL)
+    # per-sample grids for a batch; a list input shares one grid and returns a tuple
+    batch = et.random_displacement(2, 3, 5.0, batch=4, device=dev, generator=g)
+    assert batch.shape == (4, 2, 3, 3)
+    imgs = [torch.rand((32, 48), device=dev), torch.rand((32, 48), device=dev)]
+    outs = et.deform_random_grid(imgs, sigma=2, points=3, generator=g)
+    assert isinstance(outs, tuple) and len(outs) == 2 and outs[0].shape == (32, 48)
+    # channel axis
+    C = torch.rand((3, 20, 24), device=dev)
+    assert et.deform_random_grid(C, sigma=2, points=3, axis=(1, 2), generator=g).shape == (3, 20, 24)
