@@ -38,7 +38,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libedhip.so
 
 # every symbol include/edhip.h declares
 EXPORTS = ('edhip_version', 'edhip_status_string', 'edhip_device_count', 'edhip_deform',
-           'edhip_source_box', 'edhip_spline_filter1d')
+           'edhip_source_box', 'edhip_spline_filter1d', 'edhip_profile_dominant',
+           'edhip_profile_last_us')
 
 
 class EdhipArray(ctypes.Structure):
@@ -79,6 +80,10 @@ def load():
             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
             ctypes.POINTER(ctypes.c_double), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p,
             ctypes.c_size_t]
+        L.edhip_profile_dominant.restype = ctypes.c_int
+        L.edhip_profile_dominant.argtypes = [ctypes.c_int]
+        L.edhip_profile_last_us.restype = ctypes.c_double
+        L.edhip_profile_last_us.argtypes = []
         L.edhip_source_box.restype = ctypes.c_int
         L.edhip_source_box.argtypes = [
             ctypes.POINTER(EdhipArray), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),

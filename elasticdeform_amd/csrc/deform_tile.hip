@@ -38,6 +38,7 @@
 // HBM traffic: each source voxel is fetched ~3.5x per launch but from L2 / Infinity Cache
 // (neighbouring tiles overlap; strips are dealt to the 8 XCDs in contiguous chunks so that the
 // overlap stays inside one L2); algorithmic bytes are 4 read + 4 written per voxel (float32).
+#include <atomic>
 #include <cstdlib>
 
 #include "ed_device.h"
@@ -1132,6 +1133,27 @@ inline size_t q_global_bytes(const GridGeom& g)
     return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 3 * (size_t)g.ncp[2];
 }
 
+// edhip_profile_*: HIP events around the level-1 launch only (the dominant kernel of a call),
+// recorded on the stream the kernel is launched on.  Off unless bench.py asks for it.
+std::atomic<int> g_profile{0};
+thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+thread_local bool t_ev_pending = false;
+
+void profile_mark(bool after, hipStream_t stream)
+{
+    if (!g_profile.load(std::memory_order_relaxed))
+        return;
+    if (!t_ev0) {
+        if (hipEventCreate(&t_ev0) != hipSuccess || hipEventCreate(&t_ev1) != hipSuccess) {
+            t_ev0 = t_ev1 = nullptr;
+            return;
+        }
+    }
+    (void)hipEventRecord(after ? t_ev1 : t_ev0, stream);
+    if (after)
+        t_ev_pending = true;
+}
+
 template <typename T, int ORDER, bool PAIR, bool GRAD>
 hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
 {
@@ -1229,6 +1251,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         return e;
     }
     // ---- level 1: strips, small boxes, highest occupancy ------------------------------------------
+    profile_mark(false, stream);
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
         constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
@@ -1253,6 +1276,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
                                lds, stream, g, ve, tg);
         e = hipGetLastError();
     }
+    profile_mark(true, stream);
     // ---- level 2: the tiles level 1 could not hold, one 8^3 tile per work item, a 48 KiB box
     //      (single copy, 24- / 56-wide rows), grid-stride over the worklist --------------------------
     TileGeom t2 = tg;
@@ -1286,6 +1310,19 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
 }
 
 }  // namespace
+
+void tile_profile_enable(int enable) { g_profile.store(enable ? 1 : 0); }
+
+double tile_profile_last_us()
+{
+    if (!t_ev_pending || !t_ev0)
+        return -1.0;
+    float ms = 0.f;
+    if (hipEventSynchronize(t_ev1) != hipSuccess || hipEventElapsedTime(&ms, t_ev0, t_ev1) != hipSuccess)
+        return -1.0;
+    t_ev_pending = false;
+    return (double)ms * 1e3;
+}
 
 size_t deform_tile_workspace_bytes(const GridGeom& g)
 {

@@ -61,6 +61,8 @@ bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient);
 hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient);
 size_t deform_tile_workspace_bytes(const GridGeom& g);   // scratch the tile path will ask for
+void tile_profile_enable(int enable);                    // edhip_profile_dominant
+double tile_profile_last_us();                           // edhip_profile_last_us
 
 struct FilterParams {
     const char* in;

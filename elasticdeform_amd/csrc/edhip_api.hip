@@ -272,6 +272,14 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
     return EDHIP_OK;
 }
 
+int edhip_profile_dominant(int enable)
+{
+    ed::tile_profile_enable(enable);
+    return EDHIP_OK;
+}
+
+double edhip_profile_last_us(void) { return ed::tile_profile_last_us(); }
+
 int edhip_source_box(const edhip_array* displacement, const int64_t* in_len, const int64_t* out_len,
                      const int64_t* output_offset, int naxis, const double* affine, uint32_t flags,
                      void* hip_stream, int64_t* box, char* err, size_t errlen)

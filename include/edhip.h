@@ -157,6 +157,16 @@ int edhip_deform(int gradient, int ninputs,
                  char* err, size_t errlen);
 
 /*
+ * Measurement aid (bench.py): with profiling enabled, edhip_deform brackets the launch of its
+ * dominant kernel -- the LDS-tiled forward / gradient kernel over all strips, without the tables
+ * kernel and the spill passes -- with HIP events recorded on `hip_stream`.
+ * edhip_profile_last_us() waits for the most recent such launch of the calling thread and returns
+ * its duration in microseconds (-1 if there is none).  Off by default; no effect on results.
+ */
+int edhip_profile_dominant(int enable);
+double edhip_profile_last_us(void);
+
+/*
  * Bounding box of the source coordinates of a call: for every deformed axis h,
  *   box[2h]   = floor(min c_h),   box[2h+1] = ceil(max c_h)
  * over all output voxels, where c_h = affine(o)_h + offset_h + displacement_h(o) is the source
