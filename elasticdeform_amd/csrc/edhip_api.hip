@@ -419,7 +419,7 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
     // scratch, ~1e-16 relative to the sequential recursion (see spline_fast.hip)
     const bool want_fast = !(flags & EDHIP_FLAG_EXACT) &&
                            (input->dtype == EDHIP_F32 || input->dtype == EDHIP_F64);
-    if (want_fast && p.npoles == 1) {
+    if (want_fast && p.npoles >= 1) {
         const hipError_t e = launch_spline_filter_fast(p, order, input->ndim, axis, input->shape,
                                                        input->stride_bytes, output->stride_bytes,
                                                        stream);

@@ -1,5 +1,6 @@
 // spline_fast.hip -- K3 / K4, fast path: B-spline prefilter (mirror boundary) and its transpose for
-// float32 / float64 arrays, spline orders 2 and 3 (one pole), lines of at least 64 samples.
+// float32 / float64 arrays, spline orders 2 and 3 (one pole; float32 also orders 4 and 5 as a
+// cascade of two one-pole passes), lines of at least 64 samples.
 //
 // Same linear operator as scipy.ndimage.spline_filter1d(mode='mirror') (call sites
 // deform_grid.py:160,168,271) and as NI_SplineFilter1DGrad (deform.c:1049-1168), evaluated in a
@@ -1067,10 +1068,32 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
                                      const int64_t* shape, const int64_t* in_stride_bytes,
                                      const int64_t* out_stride_bytes, hipStream_t stream)
 {
-    if (order != 2 && order != 3)
+    if (order < 2 || order > 5)
         return hipErrorNotSupported;
     if (fp.in_dtype != fp.out_dtype || (fp.in_dtype != EDHIP_F32 && fp.in_dtype != EDHIP_F64))
         return hipErrorNotSupported;
+    if (order >= 4) {
+        // Two poles = a cascade of two one-pole filters (mirror-boundary filters commute: both are
+        // diagonal in the DCT-I basis; the transposes cascade the same way).  |z_1|^32 = 2e-12
+        // (order 5): far below float32 rounding, not below float64's -- float32 only.  The second
+        // pass runs in place on the output.
+        if (fp.in_dtype != EDHIP_F32 || fp.npoles != 2)
+            return hipErrorNotSupported;
+        FilterParams a = fp;
+        a.npoles = 1;
+        a.gain = (1.0 - fp.pole[0]) * (1.0 - 1.0 / fp.pole[0]);
+        hipError_t e = launch_spline_filter_fast(a, 3, ndim, axis, shape, in_stride_bytes,
+                                                 out_stride_bytes, stream);
+        if (e != hipSuccess)
+            return e;
+        FilterParams b = fp;
+        b.npoles = 1;
+        b.in = fp.out;
+        b.pole[0] = fp.pole[1];
+        b.gain = (1.0 - fp.pole[1]) * (1.0 - 1.0 / fp.pole[1]);
+        return launch_spline_filter_fast(b, 3, ndim, axis, shape, out_stride_bytes, out_stride_bytes,
+                                         stream);
+    }
     if (fp.len < 64)
         return hipErrorNotSupported;
     const int64_t esz = fp.in_dtype == EDHIP_F32 ? 4 : 8;

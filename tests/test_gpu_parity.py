@@ -333,8 +333,9 @@ def test_fast_prefilter_kernels():
             if len(shape) == 3 and shape[0] > 100:
                 continue
             os.environ["EDHIP_NO_LINE_TILES"] = "1"
-        for order in (2, 3):
-            for dtype, flag, tol in ((np.float32, _lib.FLAG_AUTO, 2e-6), (np.float64, _lib.FLAG_AUTO, 1e-13)):
+        for order in (2, 3, 4, 5):
+            for dtype, flag, tol in ((np.float32, _lib.FLAG_AUTO, 2e-6 if order < 4 else 4e-6),
+                                     (np.float64, _lib.FLAG_AUTO, 1e-13)):
                 x = rng.standard_normal(shape).astype(dtype)
                 xd = torch.from_numpy(x).to(dev)
                 for axis in range(len(shape)):
