@@ -39,9 +39,11 @@
 // (neighbouring tiles overlap; strips are dealt to the 8 XCDs in contiguous chunks so that the
 // overlap stays inside one L2); algorithmic bytes are 4 read + 4 written per voxel (float32).
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 #include "ed_device.h"
+#include "ed_exact_coord.h"
 #include "ed_params.h"
 #include "ed_workspace.h"
 
@@ -293,6 +295,8 @@ struct TileGeom {
     double affine[12];    // inverse map, 3 x 4
     int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
     int* spill_next;      // the second level's spill list (its count is reset by the tables kernel)
+    int* label_list;      // label kernel: [0] = count, [1..cap] = linear ids of near-tie voxels (or nullptr)
+    int label_cap;
     const int* worklist;  // second-level pass: [0] = count, [1..] = tile ids to process (else nullptr)
     const double* q_global;   // [O_z][O_y][3][ncpx]: displacement contracted over z and y
     const AxTab* xt_global;   // [O_x]: cubic weights / control indices along x
@@ -355,6 +359,8 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     if (oz == 0 && tid == 0) {      // reset both spill counters (saves two memset launches per call)
         tg.spill[0] = 0;
         tg.spill_next[0] = 0;
+        if (tg.label_list)
+            tg.label_list[0] = 0;
     }
     auto entry = [&](int a, int oi, AxTab& t) {
         const double cp = control_coordinate(g.ncp[a], (int64_t)oi + g.off[a], g.in_len[a]);
@@ -1128,9 +1134,159 @@ inline int ceil_log2(int64_t n)
 }
 
 inline size_t q_bytes(const GridGeom& g) { return 8 * (size_t)(kT * kT * 3) * (size_t)g.ncp[2]; }
+// near-tie list of the label kernel: up to 1M voxel ids (4 MiB), never more than the output has
+inline size_t label_list_bytes(const GridGeom& g)
+{
+    int64_t nvox = 1;
+    for (int k = 0; k < 3; ++k)
+        nvox *= g.out_len[k];
+    const int64_t cap = nvox < (1 << 20) ? nvox : (1 << 20);
+    return (size_t)(cap + 32) * sizeof(int) + 64;
+}
+
 inline size_t q_global_bytes(const GridGeom& g)
 {
     return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 3 * (size_t)g.ncp[2];
+}
+
+// ================================================================================================
+// label kernel: order 0, any dtype, input dtype == output dtype -- a resampled label map is a
+// COPY of source elements, so only the choice of the source index has to match the reference.
+// Coordinates come from the per-call tables like everywhere on the fast path (12 fp64 FMAs per
+// voxel); a voxel whose coordinate lies within 1e-6 of a decision boundary -- a half-integer (the
+// rounding floor(c + 0.5)), or an integer once it is outside the array (the break points of the
+// boundary maps, the constant test) -- is re-evaluated in the reference's own evaluation order
+// (ed_exact_coord.h, FMA contraction off), which is bit-comparable.  The fast coordinate is within
+// ~1e-11 of that, so every other voxel decides identically: the output is bit-equal to the exact
+// kernel's at ~20x its speed (a few voxels per million take the slow path).
+// ================================================================================================
+template <typename W>
+__global__ __launch_bounds__(kBlock) void deform_tile3_label_kernel(const GridGeom g, const IOView v,
+                                                                    const TileGeom tg)
+{
+    const W* inp = reinterpret_cast<const W*>(v.in);
+    W* outp = reinterpret_cast<W*>(v.out);
+    const int ntile_total = tg.tiles[0] * tg.tiles[1] * tg.tiles[2];
+    const int tid = threadIdx.x;
+    const int xx = tid & 7, yy = (tid >> 3) & 7, zq = tid >> 6;
+    constexpr double kEps = 1e-6;
+    for (int s = blockIdx.x; s < ntile_total; s += gridDim.x) {
+        int t = s;
+        const int tx = t % tg.tiles[2];
+        t /= tg.tiles[2];
+        const int ty = t % tg.tiles[1];
+        const int tz = t / tg.tiles[1];
+        const int ox = tx * kT + xx, oy = ty * kT + yy;
+        if (ox >= tg.out_len[2] || oy >= tg.out_len[1])
+            continue;
+        const AxTab tx_ = tg.xt_global[ox];
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            const int oz = tz * kT + zq + 4 * i;
+            if (oz >= tg.out_len[0])
+                continue;
+            const int o[3] = {oz, oy, ox};
+            const double* qrow0 = tg.q_global + ((int64_t)oz * tg.out_len[1] + oy) * 3 * tg.ncpx;
+            double raw[3];
+            bool tie = false;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                const double* qrow = qrow0 + h * tg.ncpx;
+                double d = 0.0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    d = fma(tx_.w[l], qrow[tx_.idx[l]], d);
+                double b;
+                if (tg.has_affine) {
+                    b = tg.affine[h * 4 + 3];
+#pragma unroll
+                    for (int l = 0; l < 3; ++l)
+                        b = fma(tg.affine[h * 4 + l], (double)o[l], b);
+                    b += (double)tg.off[h];
+                } else {
+                    b = (double)(o[h] + tg.off[h]);
+                }
+                raw[h] = b + d;
+                const double fr = raw[h] - floor(raw[h]);
+                const bool outside = !(raw[h] >= kEps && raw[h] <= (double)(tg.in_len[h] - 1) - kEps);
+                tie = tie || fabs(fr - 0.5) < kEps || (outside && (fr < kEps || fr > 1.0 - kEps)) ||
+                      !(raw[h] == raw[h]);
+            }
+            if (tie) {
+                // left to the tie kernel (the reference's own arithmetic for this voxel)
+                const int slot = atomicAdd(&tg.label_list[0], 1);
+                if (slot < tg.label_cap)
+                    tg.label_list[1 + slot] = (oz * tg.out_len[1] + oy) * tg.out_len[2] + ox;
+                continue;
+            }
+            int src_idx = 0;
+            bool cst = false;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                const double c = map_coordinate_fast(raw[h], tg.in_len[h], tg.mode, tg.period[h],
+                                                     tg.inv_period[h]);
+                cst = cst || !(c > -1.0);
+                const int st = (int)floor(c + 0.5);
+                src_idx += mirror_i32(cst ? 0 : st, tg.in_len[h]) * tg.in_stride[h];
+            }
+            const int obase = o[0] * tg.out_stride[0] + o[1] * tg.out_stride[1] + o[2] * tg.out_stride[2];
+            for (int64_t ss = 0; ss < v.nsteps; ++ss) {
+                int64_t in_off, out_off;
+                step_offsets(v, ss, in_off, out_off);
+                if (cst)
+                    store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype, v.cval);
+                else
+                    __builtin_nontemporal_store(inp[in_off + src_idx], outp + (out_off + obase));
+            }
+        }
+    }
+}
+
+// the near-tie voxels of the label kernel, in the reference's evaluation order (deform.c:650-758,
+// 771-813; ed_exact_coord.h).  If the list overflowed (adversarial inputs: every coordinate a
+// half-integer) every voxel is redone this way -- correct, at the exact kernel's speed.
+template <typename W>
+__global__ __launch_bounds__(kBlock) void deform_tile3_label_tie_kernel(const GridGeom g, const IOView v,
+                                                                        const TileGeom tg)
+{
+    const W* inp = reinterpret_cast<const W*>(v.in);
+    W* outp = reinterpret_cast<W*>(v.out);
+    const int count = tg.label_list[0];
+    const bool all = count > tg.label_cap;
+    const int64_t n = all ? (int64_t)tg.out_len[0] * tg.out_len[1] * tg.out_len[2] : count;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+        int id = all ? (int)e : tg.label_list[1 + e];
+        int64_t o64[3];
+        o64[2] = id % tg.out_len[2];
+        id /= tg.out_len[2];
+        o64[1] = id % tg.out_len[1];
+        o64[0] = id / tg.out_len[1];
+        double displ[3];
+        eval_displacement<3>(g, o64, displ);
+        int src_idx = 0;
+        bool cst = false;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const double c = map_coordinate(raw_coordinate<3>(g, o64, h, displ[h]), g.in_len[h], tg.mode);
+            if (!cst && c > -1.0) {
+                const int64_t st = window_start(c, 0);
+                const bool edge = st < 0 || st >= g.in_len[h];
+                src_idx += (int)(edge ? mirror_index(st, g.in_len[h]) : st) * tg.in_stride[h];
+            } else {
+                cst = true;
+            }
+        }
+        const int obase = (int)o64[0] * tg.out_stride[0] + (int)o64[1] * tg.out_stride[1] +
+                          (int)o64[2] * tg.out_stride[2];
+        for (int64_t ss = 0; ss < v.nsteps; ++ss) {
+            int64_t in_off, out_off;
+            step_offsets(v, ss, in_off, out_off);
+            if (cst)
+                store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype, v.cval);
+            else
+                outp[out_off + obase] = inp[in_off + src_idx];
+        }
+    }
 }
 
 // edhip_profile_*: HIP events around the level-1 launch only (the dominant kernel of a call),
@@ -1224,7 +1380,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     hipError_t e = hipSuccess;
     // (edhip_deform reserved deform_tile_workspace_bytes() up front, so this does not move the
     // prefiltered control grid that may sit in the head of the workspace)
-    void* ws = workspace_reserve(stream, kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q_global_bytes(g), &e);
+    void* ws = workspace_reserve(stream, kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q_global_bytes(g) +
+                                             label_list_bytes(g), &e);
     if (!ws)
         return e;
     ws = (char*)ws + kWorkspaceGridBytes;
@@ -1235,11 +1392,26 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     tg.worklist = nullptr;
     tg.spill = list_a;
     tg.spill_next = list_b;
+    tg.label_list = nullptr;
+    tg.label_cap = 0;
+    if (std::is_integral<T>::value) {
+        tg.label_list = (int*)((char*)ws + 2 * list_bytes + xt_bytes + ((q_global_bytes(g) + 63) & ~(size_t)63));
+        tg.label_cap = (int)(label_list_bytes(g) / sizeof(int)) - 32;
+    }
     {
         hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0]), dim3(kBlock),
                            sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
         e = hipGetLastError();
     }
+    if constexpr (std::is_integral<T>::value) {
+        if (e == hipSuccess) {
+            const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
+            hipLaunchKernelGGL(deform_tile3_label_kernel<T>, dim3(nblk), dim3(kBlock), 0, stream, g, ve, tg);
+            hipLaunchKernelGGL(deform_tile3_label_tie_kernel<T>, dim3(1024), dim3(kBlock), 0, stream, g, ve, tg);
+            e = hipGetLastError();
+        }
+        return e;
+    } else {
     if (ORDER < 2) {
         // 1 / 8 taps per voxel: no source box, straight from global memory
         if (e == hipSuccess) {
@@ -1307,6 +1479,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         e = hipGetLastError();
     }
     return e;
+    }   // floating point T
 }
 
 }  // namespace
@@ -1336,7 +1509,7 @@ size_t deform_tile_workspace_bytes(const GridGeom& g)
     const size_t q = q_global_bytes(g);
     if (q > ((size_t)512 << 20))
         return kWorkspaceGridBytes;
-    return kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q;
+    return kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q + label_list_bytes(g);
 }
 
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
@@ -1365,6 +1538,55 @@ bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
     if (q_global_bytes(g) > ((size_t)512 << 20) || 24 * (size_t)g.ncp[1] * (size_t)g.ncp[2] > 48 * 1024)
         return false;
     return true;
+}
+
+static int label_elem_size(int dt)
+{
+    switch (dt) {
+    case EDHIP_BOOL: case EDHIP_U8: case EDHIP_I8: return 1;
+    case EDHIP_U16: case EDHIP_I16: return 2;
+    case EDHIP_U32: case EDHIP_I32: case EDHIP_F32: return 4;
+    default: return 8;
+    }
+}
+
+bool deform_label_supported(const GridGeom& g, const IOView& v, int gradient)
+{
+    if (g.naxis != 3 || gradient || v.order != 0 || v.in_dtype != v.out_dtype)
+        return false;
+    const int64_t esz = label_elem_size(v.in_dtype);
+    if (((uintptr_t)v.in % esz) || ((uintptr_t)v.out % esz))
+        return false;
+    int64_t in_span = 0, out_span = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (g.in_len[k] >= 0x3fffffff || g.out_len[k] >= 0x3fffffff || g.ncp[k] > 1024)
+            return false;
+        if (v.in_stride[k] % esz || v.out_stride[k] % esz)
+            return false;
+        const int64_t si = v.in_stride[k] / esz, so = v.out_stride[k] / esz;
+        in_span += (si < 0 ? -si : si) * (g.in_len[k] - 1);
+        out_span += (so < 0 ? -so : so) * (g.out_len[k] - 1);
+    }
+    for (int l = 0; l < v.nstep; ++l)
+        if (v.in_step_stride[l] % esz || v.out_step_stride[l] % esz)
+            return false;
+    if (in_span >= 0x7fffffffLL || out_span >= 0x7fffffffLL)
+        return false;
+    if (q_global_bytes(g) > ((size_t)512 << 20) || 24 * (size_t)g.ncp[1] * (size_t)g.ncp[2] > 48 * 1024)
+        return false;
+    return true;
+}
+
+hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream)
+{
+    if (!deform_label_supported(g, v, 0))
+        return hipErrorNotSupported;
+    switch (label_elem_size(v.in_dtype)) {
+    case 1: return launch_tile<uint8_t, 0, false, false>(g, v, stream);
+    case 2: return launch_tile<uint16_t, 0, false, false>(g, v, stream);
+    case 4: return launch_tile<uint32_t, 0, false, false>(g, v, stream);
+    default: return launch_tile<uint64_t, 0, false, false>(g, v, stream);
+    }
 }
 
 hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)

@@ -112,6 +112,8 @@ __device__ __forceinline__ void store_forward(char* p, int dt, double t)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double map_coordinate(double c, int64_t len, int mode)
 {
+    // reference arithmetic (x86-64, no FMA): keep the products and sums separate in every TU
+#pragma clang fp contract(off)
     if (c < 0) {
         switch (mode) {
         case EDHIP_MODE_MIRROR:
@@ -202,6 +204,8 @@ __device__ __forceinline__ int64_t mirror_index(int64_t idx, int64_t len)
 // first tap of the (order+1)-wide window around c -- deform.c:657-661,784-788
 __device__ __forceinline__ int64_t window_start(double c, int order)
 {
+    // reference arithmetic (x86-64, no FMA): keep the products and sums separate in every TU
+#pragma clang fp contract(off)
     return (int64_t)((order & 1) ? floor(c) : floor(c + 0.5)) - order / 2;
 }
 
@@ -209,6 +213,8 @@ __device__ __forceinline__ int64_t window_start(double c, int order)
 // of the others" rule -- deform.c:160-268.  w must hold order+1 doubles; order 0 writes nothing.
 __device__ __forceinline__ void spline_weights(double x, int order, double* w)
 {
+    // reference arithmetic (x86-64, no FMA): keep the products and sums separate in every TU
+#pragma clang fp contract(off)
     x -= floor((order & 1) ? x : x + 0.5);
     double y = x, z = 1.0 - x, t;
     switch (order) {
@@ -257,6 +263,8 @@ __device__ __forceinline__ void spline_weights(double x, int order, double* w)
 // control-point coordinate of output index o on one axis -- deform.c:643,655
 __device__ __forceinline__ double control_coordinate(int64_t ncp, int64_t o_plus_off, int64_t in_len)
 {
+    // reference arithmetic (x86-64, no FMA): keep the products and sums separate in every TU
+#pragma clang fp contract(off)
     return (double)(ncp - 1) * (double)o_plus_off / (double)(in_len - 1);
 }
 

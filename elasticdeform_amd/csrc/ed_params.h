@@ -61,6 +61,11 @@ bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient);
 hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient);
 size_t deform_tile_workspace_bytes(const GridGeom& g);   // scratch the tile path will ask for
+
+// order-0 resampling of label maps (any dtype, 3 deformed axes, forward): bit-equal to the exact
+// kernel (fast coordinates, exact re-evaluation of near-tie voxels), see deform_tile.hip
+hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream);
+bool deform_label_supported(const GridGeom& g, const IOView& v, int gradient);
 void tile_profile_enable(int enable);                    // edhip_profile_dominant
 double tile_profile_last_us();                           // edhip_profile_last_us
 

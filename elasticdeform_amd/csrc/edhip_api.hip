@@ -259,8 +259,13 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         else
             use_fast = (in.dtype == EDHIP_F32 || in.dtype == EDHIP_F64) && out.dtype == in.dtype &&
                        deform_fast_supported(g, v, gradient);
+        // order-0 label maps of any dtype: bit-equal to the exact kernels, so AUTO takes it too
+        const bool use_label = !(flags & EDHIP_FLAG_EXACT) && !use_fast && in.dtype != EDHIP_F32 &&
+                               in.dtype != EDHIP_F64 && deform_label_supported(g, v, gradient);
         hipError_t e;
-        if (!use_fast)
+        if (use_label)
+            e = launch_deform_label(g, v, stream);
+        else if (!use_fast)
             e = launch_deform_exact(g, v, gradient != 0, stream);
         else if (deform_tile_supported(g, v, gradient != 0))
             e = launch_deform_tile(g, v, gradient != 0, stream);
