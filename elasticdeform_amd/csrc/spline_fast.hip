@@ -20,8 +20,9 @@
 //     per output -- the result agrees with the sequential reference recursion to ~1e-16 relative
 //     (not bit-for-bit: the exact kernels in spline_filter.hip remain the bit-comparable path).
 //   * lines along a strided axis: adjacent lanes own adjacent lines, so every load / store of a
-//     wave is one contiguous row segment.  Lines along the contiguous axis: a wave owns 64 lines
-//     and moves 64 x 64 tiles through LDS (padded pitch) so that global accesses stay row-contiguous.
+//     wave is one contiguous row segment.  Lines along the contiguous axis: a lane owns a line and
+//     moves its samples as 16-byte vectors.  (These block-recompute kernels serve the lines that
+//     are too long for an LDS tile; the default is the whole-line tile kernels further down.)
 //   * in place (input == output, how the reference chains the axes, deform_grid.py:158-161): one
 //     segment per line; every block only reads samples at or below its own outputs plus the mirror
 //     of the line's tail, which is read before anything is written.
@@ -222,149 +223,6 @@ __global__ __launch_bounds__(kBlock) void prefilter_fast_strided_kernel(const Fa
     }
 }
 
-// ---- lines along the contiguous axis: a wave owns 64 lines, tiles go through LDS --------------------
-template <typename T>
-constexpr int contig_waves()
-{
-    return sizeof(T) == 4 ? 2 : 1;       // 64 x 65 x sizeof(T) bytes of LDS per wave, <= 33 KiB per block
-}
-
-template <typename T>
-__global__ __launch_bounds__(64 * contig_waves<T>()) void prefilter_fast_contig_kernel(
-    const FastFilter p)
-{
-    constexpr int kPitch = kK + kB + 1;                 // 65: conflict-free column reads
-    constexpr int kWaves = contig_waves<T>();
-    __shared__ T tile[kWaves][64 * kPitch];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T* tl = tile[wave];
-    const int64_t wid = (int64_t)blockIdx.x * kWaves + wave;
-    const int64_t groups = (p.nlines + 63) / 64;
-    if (wid >= groups * p.nseg)
-        return;
-    const int64_t seg = wid / groups, line0 = (wid - seg * groups) * 64;
-    const int64_t n = p.len;
-    const int64_t a = seg * p.seg_len;
-    int64_t e = a + p.seg_len;
-    if (e > n)
-        e = ((n + kB - 1) / kB) * kB;
-    const double z = p.z, h0 = p.h0;
-    const bool tr = p.transpose != 0;
-    const int nl = (int)((p.nlines - line0) < 64 ? (p.nlines - line0) : 64);   // lines in this group
-
-    // lane r holds the base offsets of line r of the group; the row loops fetch them with readlane
-    int64_t my_in, my_out;
-    line_offsets(p, line0 + (lane < nl ? lane : nl - 1), my_in, my_out);
-    const T* in_base = reinterpret_cast<const T*>(p.in);
-    T* out_base = reinterpret_cast<T*>(p.out);
-    auto row_offset = [&](int64_t v, int r) -> int64_t {
-        const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffff), r);
-        const int hi = __builtin_amdgcn_readlane((int)(v >> 32), r);
-        return ((int64_t)hi << 32) | (uint32_t)lo;
-    };
-    auto load_tile = [&](int64_t j0, int count) {
-        // rows r = 0..nl-1, columns j0 .. j0 + count - 1 (count <= 64): lane <-> column
-        const int64_t i = lane < count ? ext_index(j0 + lane, n, tr) : -1;
-        const int64_t col = i * p.in_axis_stride;
-        // all row loads of a batch are issued before the first LDS write (fixed trip counts so
-        // that the loops unroll; rows beyond nl re-read the last line, harmlessly)
-#pragma unroll 1
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-            T v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t off = row_offset(my_in, r0 + r);
-                v[r] = i >= 0 ? in_base[off + col] : (T)0;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                tl[(r0 + r) * kPitch + lane] = v[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    auto wave_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-
-    double ya_next;
-    {
-        load_tile(e, kK);
-        T xs[kK];
-#pragma unroll
-        for (int k = 0; k < kK; ++k)
-            xs[k] = tl[lane * kPitch + k];
-        ya_next = warm_anticausal(xs, z);
-        wave_sync();
-    }
-    double s_last = 0.0;
-    if (tr && e > n - 1 - kK) {
-        load_tile(n - kK, kK);
-        double yc = 0.0;
-#pragma unroll
-        for (int k = 0; k < kK; ++k)
-            yc = (double)tl[lane * kPitch + k] + z * yc;
-        s_last = h0 * yc;
-        wave_sync();
-    }
-    for (int64_t b = e - kB; b >= a; b -= kB) {
-        load_tile(b - kK, kK + kB);
-        T xs[kK + kB];
-#pragma unroll
-        for (int k = 0; k < kK + kB; ++k)
-            xs[k] = tl[lane * kPitch + k];
-        double o[kB];
-        filter_block(xs, z, h0, ya_next, o);
-        if (tr) {
-            if (b + kB > n - 1 - kK) {
-                double zp = 1.0;
-                for (int64_t i = n - 1; i > b + kB - 1; --i)
-                    zp *= z;
-#pragma unroll
-                for (int k = kB - 1; k >= 0; --k) {
-                    const int64_t i = b + k;
-                    if (i <= n - 1) {
-                        if (i > 0 && i < n - 1)
-                            o[k] += zp * s_last;
-                        zp *= z;
-                    }
-                }
-            }
-            if (b == 0) {
-                const double s0 = o[0];
-                double zp = z;
-#pragma unroll
-                for (int k = 1; k < kB; ++k) {
-                    if (k < n - 1)
-                        o[k] += zp * s0;
-                    zp *= z;
-                }
-            }
-        }
-        wave_sync();          // every lane is done reading its row of the input tile
-#pragma unroll
-        for (int k = 0; k < kB; ++k)
-            tl[lane * kPitch + k] = (T)o[k];
-        wave_sync();
-        // store rows: two lines per instruction, 32 contiguous outputs each
-        const int half = lane >> 5, col = lane & 31;
-#pragma unroll 8
-        for (int r0 = 0; r0 < 64; r0 += 2) {
-            // rows r0 (lanes 0-31) and r0 + 1 (lanes 32-63)
-            const int64_t o0 = row_offset(my_out, r0);
-            const int64_t o1 = row_offset(my_out, r0 + 1);
-            const int r = r0 + half;
-            if (r < nl && b + col < n)
-                out_base[(half ? o1 : o0) + (b + col) * p.out_axis_stride] = tl[r * kPitch + col];
-        }
-        wave_sync();
-    }
-}
-
-
 // ================================================================================================
 // Whole-line tiles (the default whenever a tile of complete lines fits the LDS): a workgroup loads
 // C (or R) complete lines into LDS with row-contiguous 16-byte loads -- every sample is read from
@@ -398,7 +256,6 @@ struct LineTile {
     int pitch;                   // contiguous: tile row pitch in elements
     int64_t ntiles;
     int transpose;
-    int dbg;
     unsigned long long* trace;   // profiling only (EDHIP_FILTER_TRACE): phase timestamps of workgroup 0
     double z, h0;
 };
@@ -932,8 +789,6 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
     p.transpose = f.transpose;
     p.z = f.z;
     p.h0 = f.h0;
-    if (const char* d = getenv("EDHIP_FILTER_DBG"))
-        p.dbg = atoi(d);
     // persistent grid: two workgroups per CU for float32 (LDS and registers are budgeted for exactly
     // that), one for float64 (its fp64 state does not fit 256 registers next to the prefetch)
     int dev = 0, ncu = 256;
@@ -1150,41 +1005,27 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
             return e;
         (void)hipGetLastError();
     }
-    if (contig && !getenv("EDHIP_CONTIG_LDS")) {
+    {
+        // block-recompute kernels: lane <-> line (UNIT: the filtered axis itself is contiguous)
         const int64_t threads = p.nlines * p.nseg;
         const int64_t nblk = (threads + kBlock - 1) / kBlock;
         if (nblk > 0x7fffffffLL)
             return hipErrorNotSupported;
-        if (fp.in_dtype == EDHIP_F32)
-            hipLaunchKernelGGL((prefilter_fast_strided_kernel<float, true>), dim3((unsigned)nblk),
-                               dim3(kBlock), 0, stream, p);
-        else
-            hipLaunchKernelGGL((prefilter_fast_strided_kernel<double, true>), dim3((unsigned)nblk),
-                               dim3(kBlock), 0, stream, p);
-    } else if (contig) {
-        const int64_t groups = (p.nlines + 63) / 64;
-        const int64_t waves = groups * p.nseg;
-        const int wpb = fp.in_dtype == EDHIP_F32 ? contig_waves<float>() : contig_waves<double>();
-        const int64_t nblk = (waves + wpb - 1) / wpb;
-        if (nblk > 0x7fffffffLL)
-            return hipErrorNotSupported;
-        if (fp.in_dtype == EDHIP_F32)
-            hipLaunchKernelGGL(prefilter_fast_contig_kernel<float>, dim3((unsigned)nblk),
-                               dim3(64 * wpb), 0, stream, p);
-        else
-            hipLaunchKernelGGL(prefilter_fast_contig_kernel<double>, dim3((unsigned)nblk),
-                               dim3(64 * wpb), 0, stream, p);
-    } else {
-        const int64_t threads = p.nlines * p.nseg;
-        const int64_t nblk = (threads + kBlock - 1) / kBlock;
-        if (nblk > 0x7fffffffLL)
-            return hipErrorNotSupported;
-        if (fp.in_dtype == EDHIP_F32)
-            hipLaunchKernelGGL((prefilter_fast_strided_kernel<float, false>), dim3((unsigned)nblk),
-                               dim3(kBlock), 0, stream, p);
-        else
-            hipLaunchKernelGGL((prefilter_fast_strided_kernel<double, false>), dim3((unsigned)nblk),
-                               dim3(kBlock), 0, stream, p);
+        if (contig) {
+            if (fp.in_dtype == EDHIP_F32)
+                hipLaunchKernelGGL((prefilter_fast_strided_kernel<float, true>), dim3((unsigned)nblk),
+                                   dim3(kBlock), 0, stream, p);
+            else
+                hipLaunchKernelGGL((prefilter_fast_strided_kernel<double, true>), dim3((unsigned)nblk),
+                                   dim3(kBlock), 0, stream, p);
+        } else {
+            if (fp.in_dtype == EDHIP_F32)
+                hipLaunchKernelGGL((prefilter_fast_strided_kernel<float, false>), dim3((unsigned)nblk),
+                                   dim3(kBlock), 0, stream, p);
+            else
+                hipLaunchKernelGGL((prefilter_fast_strided_kernel<double, false>), dim3((unsigned)nblk),
+                                   dim3(kBlock), 0, stream, p);
+        }
     }
     return hipGetLastError();
 }
