@@ -107,22 +107,19 @@ def raise_for_status(status, errbuf):
     raise _STATUS_EXC.get(status, RuntimeError)(msg)
 
 
+_I64x8 = ctypes.c_int64 * MAX_DIMS
+
+
 def describe(data_ptr, dtype_name, shape, strides_bytes):
     """Build a struct edhip_array from raw parts."""
-    if dtype_name not in DTYPE_CODES:
+    code = DTYPE_CODES.get(dtype_name)
+    if code is None:
         # float16 / complex / ...: what the reference answers for them (deform.c:744,891)
         raise RuntimeError('data type not supported')
     nd = len(shape)
     if nd < 1 or nd > MAX_DIMS:
         raise RuntimeError('arrays must have 1..%d dimensions' % MAX_DIMS)
-    d = EdhipArray()
-    d.data = data_ptr
-    d.dtype = DTYPE_CODES[dtype_name]
-    d.ndim = nd
-    for i in range(nd):
-        d.shape[i] = int(shape[i])
-        d.stride_bytes[i] = int(strides_bytes[i])
-    return d
+    return EdhipArray(data_ptr, code, nd, _I64x8(*shape), _I64x8(*strides_bytes))
 
 
 def deform(gradient, in_descs, disp_desc, output_offset, out_descs, axis, orders, modes, cvals,

@@ -934,7 +934,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
             // so scale = (2^31 - 2^10) / (wmax * sum|dY|) cannot overflow an int32; for white-noise
             // dY that is a resolution of ~3e-8 of max|dY| per contribution -- the level of the
             // float32 rounding in the reference's own `+=` (deform.c:309-312).
-            constexpr float kWmax = ORDER == 2 ? 0.4219f : (ORDER == 3 ? 0.2963f
+            constexpr float kWmax = ORDER == 1 ? 1.0f : ORDER == 2 ? 0.4219f : (ORDER == 3 ? 0.2963f
                                     : (ORDER == 4 ? 0.2150f : 0.1664f));
             const float scale = (2147483648.0f - 1024.0f) / (kWmax * 1.001f * gtot);
             const float inv_scale = 1.0f / scale;
@@ -1009,8 +1009,10 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
 // the per-axis mirror map of deform.c:791-813.  Two uses:
 //   WORKLIST = true : finishes the tiles the LDS kernels could not hold (strong folding, 'wrap'
 //                     seams) from the spill worklist;
-//   WORKLIST = false: the whole volume, for spline orders 0 and 1 (1 / 8 taps per voxel: staging a
-//                     source box would cost more than it saves).
+//   WORKLIST = false: the whole volume, for spline order 0 (one tap per voxel: nothing to stage)
+//                     and for the float64 order-1 gradient.  Order 1 otherwise runs on the LDS
+//                     kernels: 256^3 float32 forward 0.27 -> 0.20 ms, gradient 2.1 -> 0.27 ms (eight
+//                     global float atomics per voxel were the cost).
 // ================================================================================================
 template <typename T, int ORDER, bool GRAD, bool WORKLIST>
 __global__ __launch_bounds__(kBlock) void deform_tile3_direct_kernel(const GridGeom g, const IOView v,
@@ -1412,8 +1414,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         }
         return e;
     } else {
-    if (ORDER < 2) {
-        // 1 / 8 taps per voxel: no source box, straight from global memory
+    if (ORDER < 1 || (ORDER < 2 && GRAD && !std::is_same<T, float>::value)) {
+        // order 0 (one tap per voxel: no source box, straight from / to global memory) and the
+        // float64 order-1 gradient (the LDS scatter kernel is float32)
         if (e == hipSuccess) {
             const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
             hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, false>), dim3(nblk),
@@ -1428,7 +1431,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
         constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
         if (GRAD)
-            hipLaunchKernelGGL((deform_tile3_grad_kernel<(ORDER < 2 ? 2 : ORDER), 16>), dim3(nblk),
+            hipLaunchKernelGGL((deform_tile3_grad_kernel<(ORDER < 1 ? 2 : ORDER), 16>), dim3(nblk),
                                dim3(kBlock), lds, stream, g, ve, tg);
         else if (kBenchKernel && tg.dbg) {
             if constexpr (kBenchKernel) {
@@ -1462,7 +1465,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     const unsigned n2 = (unsigned)(ntiles < 512 ? ntiles : 512);
     if (e == hipSuccess) {
         if (GRAD)
-            hipLaunchKernelGGL((deform_tile3_grad_kernel<(ORDER < 2 ? 2 : ORDER), 8>), dim3(n2),
+            hipLaunchKernelGGL((deform_tile3_grad_kernel<(ORDER < 1 ? 2 : ORDER), 8>), dim3(n2),
                                dim3(kBlock), lds2, stream, g, ve, t2);
         else
             hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, false>), dim3(n2), dim3(kBlock), lds2,
@@ -1605,7 +1608,7 @@ hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, 
         }
         if (f32)
             return v.order == 0 ? launch_tile<float, 0, false, false>(g, v, stream)
-                                : launch_tile<float, 1, false, false>(g, v, stream);
+                                : launch_tile<float, 1, true, false>(g, v, stream);
         return v.order == 0 ? launch_tile<double, 0, false, false>(g, v, stream)
                             : launch_tile<double, 1, false, false>(g, v, stream);
     }

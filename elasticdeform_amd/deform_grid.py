@@ -99,8 +99,7 @@ def _from_device(t, like):
 
 def _desc(t):
     es = t.element_size()
-    return _lib.describe(t.data_ptr(), _dtype_name(t), tuple(t.shape),
-                         tuple(s * es for s in t.stride()))
+    return _lib.describe(t.data_ptr(), _dtype_name(t), t.shape, [s * es for s in t.stride()])
 
 
 def _stream(device):
