@@ -36,6 +36,7 @@
 
 #include "ed_device.h"
 #include "ed_params.h"
+#include "ed_workspace.h"
 
 namespace ed {
 
@@ -937,15 +938,41 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
         FilterParams a = fp;
         a.npoles = 1;
         a.gain = (1.0 - fp.pole[0]) * (1.0 - 1.0 / fp.pole[0]);
+        FilterParams b = fp;
+        b.npoles = 1;
+        b.pole[0] = fp.pole[1];
+        b.gain = (1.0 - fp.pole[1]) * (1.0 - 1.0 / fp.pole[1]);
+        // Lines too long for an LDS tile are served by the block-recompute kernels, which can only
+        // split a line across lanes when they do not run in place: such arrays go through a dense
+        // temporary in the workspace (in -> tmp -> out) instead of (in -> out, out -> out in place).
+        int64_t count = 1;
+        for (int d = 0; d < ndim; ++d)
+            count *= shape[d];
+        if (fp.len > 576 && count > 0 && (uint64_t)count * 4 <= ((uint64_t)1 << 30)) {
+            hipError_t e = hipSuccess;
+            char* ws = (char*)workspace_reserve(stream, kWorkspaceGridBytes + (size_t)count * 4, &e);
+            if (ws) {
+                int64_t tmp_stride[EDHIP_MAX_DIMS];
+                int64_t st = 4;
+                for (int d = ndim - 1; d >= 0; --d) {
+                    tmp_stride[d] = st;
+                    st *= shape[d];
+                }
+                a.out = ws + kWorkspaceGridBytes;
+                b.in = ws + kWorkspaceGridBytes;
+                e = launch_spline_filter_fast(a, 3, ndim, axis, shape, in_stride_bytes, tmp_stride, stream);
+                if (e != hipSuccess)
+                    return e;
+                return launch_spline_filter_fast(b, 3, ndim, axis, shape, tmp_stride, out_stride_bytes,
+                                                 stream);
+            }
+            (void)hipGetLastError();
+        }
         hipError_t e = launch_spline_filter_fast(a, 3, ndim, axis, shape, in_stride_bytes,
                                                  out_stride_bytes, stream);
         if (e != hipSuccess)
             return e;
-        FilterParams b = fp;
-        b.npoles = 1;
         b.in = fp.out;
-        b.pole[0] = fp.pole[1];
-        b.gain = (1.0 - fp.pole[1]) * (1.0 - 1.0 / fp.pole[1]);
         return launch_spline_filter_fast(b, 3, ndim, axis, shape, out_stride_bytes, out_stride_bytes,
                                          stream);
     }
