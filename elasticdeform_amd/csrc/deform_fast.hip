@@ -25,6 +25,8 @@
 // Differences from the reference are rounding only (summation order, fp32 tap arithmetic); the
 // parity tests bound them at 1e-5 (float32) / 1e-11 (float64).  Integer and bool volumes never
 // come here: they take the exact kernels (deform_exact.hip).
+#include <cstdlib>
+
 #include "ed_device.h"
 #include "ed_params.h"
 
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
     // ---- block prologue: slow-axis displacement tables for this block's rows -----------------
     if (NS > 0) {
         for (int t = tid; t < kRows * NS; t += kBlock) {
-            const int rr = t / NS, k = t - rr * NS;
+            const int rr = t / NSD, k = t - rr * NSD;
             int64_t row = rb * kRows + rr;
             if (row < nrows) {
                 // decompose row -> o_k (last slow axis fastest)
@@ -321,6 +323,320 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
     }
 }
 
+// B-spline basis weights from the fractional offset in the data's width (closed forms of
+// deform.c:160-268, last weight = 1 - sum of the others) -- same as the tile kernels use.
+template <typename T, int ORDER>
+__device__ __forceinline__ void weights_from_frac2(T x, T* w)
+{
+    const T z = (T)1 - x;
+    if (ORDER == 1) {
+        w[0] = z;
+    } else if (ORDER == 2) {
+        w[1] = (T)0.75 - x * x;
+        const T y = (T)0.5 - x;
+        w[0] = (T)0.5 * y * y;
+    } else if (ORDER == 3) {
+        w[1] = (x * x * (x - (T)2) * (T)3 + (T)4) * (T)(1.0 / 6.0);
+        w[2] = (z * z * (z - (T)2) * (T)3 + (T)4) * (T)(1.0 / 6.0);
+        w[0] = z * z * z * (T)(1.0 / 6.0);
+    } else if (ORDER == 4) {
+        T t = x * x;
+        w[2] = t * (t * (T)0.25 - (T)0.625) + (T)(115.0 / 192.0);
+        T y = (T)1 + x;
+        w[1] = y * (y * (y * ((T)5 - y) * (T)(1.0 / 6.0) - (T)1.25) + (T)(5.0 / 24.0)) + (T)(55.0 / 96.0);
+        w[3] = z * (z * (z * ((T)5 - z) * (T)(1.0 / 6.0) - (T)1.25) + (T)(5.0 / 24.0)) + (T)(55.0 / 96.0);
+        y = (T)0.5 - x;
+        t = y * y;
+        w[0] = t * t * (T)(1.0 / 24.0);
+    } else {
+        T t = x * x;
+        w[2] = t * (t * ((T)0.25 - x * (T)(1.0 / 12.0)) - (T)0.5) + (T)0.55;
+        t = z * z;
+        w[3] = t * (t * ((T)0.25 - z * (T)(1.0 / 12.0)) - (T)0.5) + (T)0.55;
+        T y = x + (T)1;
+        w[1] = y * (y * (y * (y * (y * (T)(1.0 / 24.0) - (T)0.375) + (T)1.25) - (T)1.75) + (T)0.625) + (T)0.425;
+        const T zz = z + (T)1;
+        w[4] = zz * (zz * (zz * (zz * (zz * (T)(1.0 / 24.0) - (T)0.375) + (T)1.25) - (T)1.75) + (T)0.625) + (T)0.425;
+        y = (T)1 - x;
+        t = y * y;
+        w[0] = y * t * t * (T)(1.0 / 120.0);
+    }
+    T last = (T)1;
+#pragma unroll
+    for (int i = 0; i < ORDER; ++i)
+        last -= w[i];
+    w[ORDER] = last;
+}
+
+// ================================================================================================
+// K2 in 2-D with an LDS accumulator (float32 / float64, orders 1-5).  The generic kernel above
+// sends every tap to global memory as a float atomic: (order+1)^2 of them per pixel, 268M for a
+// 4096^2 image at order 3.  Here a block of kRows2 x 64 output pixels first finds the bounding box
+// of all its tap windows (unmapped tap-index space, like the 3-D tile kernel), scatters into a
+// fixed-point LDS box with integer atomics (ds_add_u32 / _u64: ~40x the rate of ds_add_f32 on this
+// machine) and flushes every touched source element with ONE global atomic, mirror-mapped the way
+// deform.c:795-813 maps the taps of a window that sticks out.  The per-block scale
+// (2^31 - 2^10) / (w_max * sum |dY|) cannot overflow: |sum into one cell| <= w_max * sum |dY|.
+// Blocks whose box does not fit (strong folding, wrap seams) and non-finite gradients fall back to
+// direct global atomics.
+// ================================================================================================
+constexpr int kRows2 = 16;          // output rows per block: 4 per wave, state kept in registers
+constexpr int kBoxCap2 = 6144;      // accumulator cells
+
+template <typename T>
+struct Fixed;
+template <>
+struct Fixed<float> {
+    typedef int acc_t;
+    typedef unsigned int uacc_t;
+    static constexpr double kRange = 2147483648.0 - 1024.0;
+    __device__ static acc_t round(float x) { return __float2int_rn(x); }
+};
+template <>
+struct Fixed<double> {
+    typedef long long acc_t;
+    typedef unsigned long long uacc_t;
+    static constexpr double kRange = 4611686018427387904.0;       // 2^62
+    __device__ static acc_t round(double x) { return __double2ll_rn(x); }
+};
+
+template <typename T, int ORDER>
+__global__ __launch_bounds__(kBlock) void deform_fast2_grad_kernel(const GridGeom g, const IOView v,
+                                                                   const FastView<2> fv,
+                                                                   const int64_t nrows, const int xblocks)
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int NP = kRows2 / kWaves;            // pixels per lane
+    typedef typename Fixed<T>::acc_t acc_t;
+    typedef typename Fixed<T>::uacc_t uacc_t;
+    __shared__ double s_w[kRows2][4];              // displacement weights along y per row
+    __shared__ int s_i[kRows2][4];
+    __shared__ double s_E[kWaves][kMaxE];
+    __shared__ int s_red[4];                       // lo_y, lo_x, hi_y, hi_x
+    __shared__ T s_sum[kWaves];
+    __shared__ __attribute__((aligned(16))) acc_t s_box[kBoxCap2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xb = blockIdx.x % xblocks;
+    const int64_t rb = blockIdx.x / xblocks;
+    const int64_t ncpx = g.ncp[1];
+
+    for (int t = tid; t < kRows2; t += kBlock) {
+        const int64_t row = rb * kRows2 + t;
+        if (row < nrows) {
+            const double cp = control_coordinate(g.ncp[0], row + g.off[0], g.in_len[0]);
+            const int64_t start = window_start(cp, 3);
+            const bool edge = start < 0 || start + 3 >= g.ncp[0];
+            double w[4];
+            spline_weights(cp, 3, w);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                s_w[t][l] = w[l];
+                s_i[t][l] = (int)(edge ? mirror_index(start + l, g.ncp[0]) : start + l);
+            }
+        }
+    }
+    if (tid < 4)
+        s_red[tid] = tid < 2 ? 0x7fffffff : (int)0x80000000;
+    const int64_t ox = (int64_t)xb * 64 + lane;
+    const bool xvalid = ox < g.out_len[1];
+    double wx[4];
+    int ix[4];
+    {
+        const double cp = control_coordinate(ncpx, (xvalid ? ox : 0) + g.off[1], g.in_len[1]);
+        const int64_t start = window_start(cp, 3);
+        const bool edge = start < 0 || start + 3 >= ncpx;
+        spline_weights(cp, 3, wx);
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            ix[l] = (int)(edge ? mirror_index(start + l, ncpx) : start + l);
+    }
+    __syncthreads();
+
+    T* dx = reinterpret_cast<T*>(const_cast<char*>(v.in));
+    const T* __restrict__ dy = reinterpret_cast<const T*>(v.out);
+    const int nE = 2 * (int)ncpx;
+
+    // ---- phase A: coordinates of this lane's NP pixels (rows wave, wave + 4, ...) --------------
+    int st[NP][2];
+    T fr[NP][2];
+    int64_t obase[NP];
+    bool act[NP];
+    int lo[2] = {0x7fffffff, 0x7fffffff}, hi[2] = {(int)0x80000000, (int)0x80000000};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int rr = wave + kWaves * i;
+        const int64_t row = rb * kRows2 + rr;
+        act[i] = false;
+        st[i][0] = st[i][1] = 0;
+        fr[i][0] = fr[i][1] = 0;
+        obase[i] = 0;
+        if (row < nrows) {                           // wave-uniform
+            for (int e = lane; e < nE; e += 64) {
+                const int h = e / (int)ncpx, j = e - h * (int)ncpx;
+                const char* base = g.disp + g.disp_stride[0] * h + g.disp_stride[2] * j;
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    acc += load_as_double(base + g.disp_stride[1] * s_i[rr][l], g.disp_dtype) * s_w[rr][l];
+                s_E[wave][e] = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (xvalid) {
+                const int64_t o[2] = {row, ox};
+                bool constant = false;
+                double cc[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double d = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 4; ++l)
+                        d += wx[l] * s_E[wave][h * (int)ncpx + ix[l]];
+                    double c;
+                    if (g.has_affine)
+                        c = g.affine[h * 3 + 2] + g.affine[h * 3] * (double)o[0] + g.affine[h * 3 + 1] * (double)o[1];
+                    else
+                        c = (double)o[h];
+                    c = map_coordinate(c + (double)g.off[h] + d, g.in_len[h], v.mode);
+                    constant = constant || !(c > -1.0);
+                    cc[h] = c;
+                }
+                if (!constant) {
+                    act[i] = true;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const double fl = floor((ORDER & 1) ? cc[h] : cc[h] + 0.5);
+                        st[i][h] = (int)fl - ORDER / 2;
+                        fr[i][h] = (T)(cc[h] - fl);
+                        lo[h] = min(lo[h], st[i][h]);
+                        hi[h] = max(hi[h], st[i][h] + ORDER);
+                    }
+                }
+                obase[i] = fv.out_stride[0] * row + fv.out_stride[1] * ox;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- the block's box -----------------------------------------------------------------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int l = lo[h], u = hi[h];
+        for (int m = 32; m >= 1; m >>= 1) {
+            l = min(l, __shfl_xor(l, m));
+            u = max(u, __shfl_xor(u, m));
+        }
+        if (lane == 0) {
+            atomicMin(&s_red[h], l);
+            atomicMax(&s_red[2 + h], u);
+        }
+    }
+    __syncthreads();
+    const int b0[2] = {s_red[0], s_red[1]};
+    const bool any = s_red[2] >= s_red[0];
+    const int ext0 = any ? s_red[2] - s_red[0] + 1 : 0, ext1 = any ? s_red[3] - s_red[1] + 1 : 0;
+    const int pitch = ext1 | 1;                    // odd: rows of neighbouring waves spread over banks
+    const bool fits = any && ext0 > 0 && ext1 > 0 && ext1 < 4096 && (int64_t)ext0 * pitch <= kBoxCap2;
+    const int nbox = fits ? ext0 * pitch : 0;
+    if (!any)
+        return;                                    // nothing to scatter (uniform)
+
+    constexpr double kW1 = ORDER == 1 ? 1.0 : ORDER == 2 ? 0.75 : ORDER == 3 ? 2.0 / 3.0
+                           : ORDER == 4 ? 115.0 / 192.0 : 0.55;
+
+    for (int64_t ss = 0; ss < v.nsteps; ++ss) {
+        int64_t in_off = 0, out_off = 0;
+        {
+            int64_t r = ss;
+            for (int l = 0; l < v.nstep; ++l) {
+                const int64_t q = r / v.step_len[l];
+                const int64_t c = r - q * v.step_len[l];
+                in_off += v.in_step_stride[l] * c;
+                out_off += v.out_step_stride[l] * c;
+                r = q;
+            }
+        }
+        T* dst = dx + in_off;
+        if (ss > 0)
+            __syncthreads();                       // previous step's flush is done with the box
+        for (int e = tid; e < nbox; e += kBlock)
+            s_box[e] = 0;
+        T gval[NP];
+        T gm = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            gval[i] = act[i] ? dy[out_off + obase[i]] : (T)0;
+            const bool finite = fabs((double)gval[i]) <= 1.7976931348623157e308 && gval[i] == gval[i];
+            if (!fits || !finite) {
+                // direct global atomics: blocks without a box, inf / NaN gradients
+                if (gval[i] != (T)0) {
+                    T w0[NT], w1[NT];
+                    weights_from_frac2<T, ORDER>(fr[i][0], w0);
+                    weights_from_frac2<T, ORDER>(fr[i][1], w1);
+#pragma unroll 1
+                    for (int t = 0; t < NT * NT; ++t) {
+                        const int l0 = t / NT, l1 = t % NT;
+                        T wa = w0[0], wb = w1[0];
+#pragma unroll
+                        for (int l = 1; l < NT; ++l) {
+                            wa = l0 == l ? w0[l] : wa;
+                            wb = l1 == l ? w1[l] : wb;
+                        }
+                        const int64_t ys = mirror_index(st[i][0] + l0, g.in_len[0]);
+                        const int64_t xs = mirror_index(st[i][1] + l1, g.in_len[1]);
+                        atomic_add(dst + (ys * fv.in_stride[0] + xs * fv.in_stride[1]), gval[i] * wa * wb);
+                    }
+                }
+                gval[i] = 0;
+            }
+            gm += fabs(gval[i]);
+        }
+        for (int m = 32; m >= 1; m >>= 1)
+            gm += __shfl_xor(gm, m);
+        if (lane == 0)
+            s_sum[wave] = gm;
+        __syncthreads();                           // box zeroed, sums known
+        const T gtot = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        if (!fits || gtot == (T)0)
+            continue;                              // (uniform)
+        const T scale = (T)(Fixed<T>::kRange / (kW1 * kW1 * 1.001 * (double)gtot));
+        const T inv_scale = (T)1 / scale;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (gval[i] == (T)0)
+                continue;
+            T w0[NT], w1[NT];
+            weights_from_frac2<T, ORDER>(fr[i][0], w0);
+            weights_from_frac2<T, ORDER>(fr[i][1], w1);
+            acc_t* bp = s_box + ((st[i][0] - b0[0]) * pitch + (st[i][1] - b0[1]));
+            const T gs = gval[i] * scale;
+#pragma unroll
+            for (int l0 = 0; l0 < NT; ++l0) {
+                const T g0 = gs * w0[l0];
+#pragma unroll
+                for (int l1 = 0; l1 < NT; ++l1)
+                    atomicAdd(reinterpret_cast<uacc_t*>(bp + l0 * pitch + l1),
+                              (uacc_t)Fixed<T>::round(g0 * w1[l1]));
+            }
+        }
+        __syncthreads();                           // all contributions are in
+        const float inv_pitch = 1.0f / (float)pitch;
+        for (int e = tid; e < nbox; e += kBlock) {
+            const acc_t a = s_box[e];
+            if (a != 0) {
+                const int yr = (int)(((float)e + 0.5f) * inv_pitch), xr = e - yr * pitch;
+                const int64_t ys = mirror_index(b0[0] + yr, g.in_len[0]);
+                const int64_t xs = mirror_index(b0[1] + xr, g.in_len[1]);
+                atomic_add(dst + (ys * fv.in_stride[0] + xs * fv.in_stride[1]), (T)a * inv_scale);
+            }
+        }
+    }
+}
+
 template <typename T, int NAXIS, int ORDER>
 hipError_t launch_typed(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
 {
@@ -345,6 +661,17 @@ hipError_t launch_typed(const GridGeom& g, const IOView& v, int gradient, hipStr
         return hipSuccess;
     if (nblk > 0x7fffffffLL || xblocks > 0x7fffffffLL)
         return hipErrorInvalidValue;
+    if constexpr (NAXIS == 2 && ORDER >= 1) {
+        if (gradient && !getenv("EDHIP_2D_DIRECT_GRAD")) {
+            const int64_t rblocks2 = (nrows + kRows2 - 1) / kRows2;
+            const int64_t nblk2 = xblocks * rblocks2;
+            if (nblk2 > 0x7fffffffLL)
+                return hipErrorInvalidValue;
+            hipLaunchKernelGGL((deform_fast2_grad_kernel<T, ORDER>), dim3((unsigned)nblk2), dim3(kBlock), 0,
+                               stream, g, ve, fv, nrows, (int)xblocks);
+            return hipGetLastError();
+        }
+    }
     if (gradient)
         hipLaunchKernelGGL((deform_fast_kernel<T, NAXIS, ORDER, true>), dim3((unsigned)nblk),
                            dim3(kBlock), 0, stream, g, ve, fv, nrows, (int)xblocks);
