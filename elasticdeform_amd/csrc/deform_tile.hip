@@ -783,14 +783,46 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
 }
 
 // ================================================================================================
-// K2: gradient (float32): integer LDS accumulation per tile, float atomics to flush
+// K2: gradient (float32 / float64): integer LDS accumulation per tile, float atomics to flush
 // ================================================================================================
-template <int ORDER, int TX>
-__global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const GridGeom g,
+// fixed-point accumulator of the data type: float32 -> int32, float64 -> int64 (ds_add_u64)
+template <typename T>
+struct GradFixed;
+template <>
+struct GradFixed<float> {
+    typedef int acc_t;
+    typedef unsigned int uacc_t;
+    static constexpr double kRange = 2147483648.0 - 1024.0;
+    __device__ static acc_t round(float x) { return __float2int_rn(x); }
+    __device__ static bool finite(float x) { return (__float_as_int(x) & 0x7f800000) != 0x7f800000; }
+};
+template <>
+struct GradFixed<double> {
+    typedef long long acc_t;
+    typedef unsigned long long uacc_t;
+    static constexpr double kRange = 4611686018427387904.0;      // 2^62
+    __device__ static acc_t round(double x) { return __double2ll_rn(x); }
+    __device__ static bool finite(double x)
+    {
+        return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ULL) != 0x7ff0000000000000ULL;
+    }
+};
+
+__device__ __forceinline__ double wave_sum(double f)
+{
+    for (int m = 32; m >= 1; m >>= 1)
+        f += __shfl_xor(f, m);
+    return f;
+}
+
+template <typename T, int ORDER, int TX>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 2 : 3) void deform_tile3_grad_kernel(const GridGeom g,
                                                                       const IOView v,
                                                                       const TileGeom tg)
 {
     constexpr int NT = ORDER + 1;
+    typedef typename GradFixed<T>::acc_t acc_t;
+    typedef typename GradFixed<T>::uacc_t uacc_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int phase = 0;      // parity of the per-wave |dY| sum slots
     for (int work = blockIdx.x;; work += gridDim.x) {
@@ -805,7 +837,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
     const double* sQ = reinterpret_cast<const double*>(smem + kOffQ);
     const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
-    int* box = reinterpret_cast<int*>(smem + tg.off_ov);
+    acc_t* box = reinterpret_cast<acc_t*>(smem + tg.off_ov);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -815,15 +847,15 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
     constexpr int ZSTEP = 8 / NV;
     const int xx = tid % TX, yy = (tid / TX) & 7, zq = tid / (TX * 8);
     const int ntile = (sp.ntile * kT + TX - 1) / TX;
-    float* dx = reinterpret_cast<float*>(const_cast<char*>(v.in));      // accumulated into
-    const float* __restrict__ dy = reinterpret_cast<const float*>(v.out);
+    T* dx = reinterpret_cast<T*>(const_cast<char*>(v.in));      // accumulated into
+    const T* __restrict__ dy = reinterpret_cast<const T*>(v.out);
 
     for (int ti = 0; ti < ntile; ++ti) {
         const int o0[3] = {sp.tz * kT, sp.ty * kT, sp.tx0 * kT + ti * TX};
         int* red = sred + (ti & 1) * 8;
 
         int start[NV][3];
-        float frac[NV][3];
+        T frac[NV][3];
         bool active[NV];
         int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
         int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
@@ -833,7 +865,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
             const int zi = zq + ZSTEP * i;
             const int o[3] = {o0[0] + zi, o0[1] + yy, o0[2] + xx};
             const bool valid = o[0] < tg.out_len[0] && o[1] < tg.out_len[1] && o[2] < tg.out_len[2];
-            const bool cst = voxel_coords<float, ORDER>(tg, hp, sQ, tabx[ti * TX + xx], zi, yy, o,
+            const bool cst = voxel_coords<T, ORDER>(tg, hp, sQ, tabx[ti * TX + xx], zi, yy, o,
                                                         start[i], frac[i]);
             active[i] = valid && !cst;       // constant-mapped voxels contribute nothing (:928)
             ooff[i] = o[0] * tg.out_stride[0] + o[1] * tg.out_stride[1] + o[2] * tg.out_stride[2];
@@ -884,28 +916,32 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
             if (ss > 0)
                 __syncthreads();         // previous step's flush is done with the box
             // zero the accumulators; tile maximum of |dY|
-            for (int e = tid * 4; e < nbox; e += kBlock * 4)
-                *reinterpret_cast<int4*>(box + e) = make_int4(0, 0, 0, 0);
-            float gval[NV];
-            float gm = 0.f;
-            float* dst = dx + in_off;
+            {
+                int* zb = reinterpret_cast<int*>(box);
+                const int nz = nbox * (int)(sizeof(acc_t) / sizeof(int));
+                for (int e = tid * 4; e < nz; e += kBlock * 4)
+                    *reinterpret_cast<int4*>(zb + e) = make_int4(0, 0, 0, 0);
+            }
+            T gval[NV];
+            T gm = 0;
+            T* dst = dx + in_off;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                gval[i] = active[i] ? dy[out_off + ooff[i]] : 0.f;
-                if ((__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000) {
+                gval[i] = active[i] ? dy[out_off + ooff[i]] : (T)0;
+                if (!GradFixed<T>::finite(gval[i])) {
                     // inf / NaN gradient: no fixed-point scale exists -- this voxel scatters its
                     // taps with float atomics straight to global memory (rare, rolled loops)
-                    float w0[NT], w1[NT], w2[NT];
-                    weights_from_frac<float, ORDER>(frac[i][0], w0);
-                    weights_from_frac<float, ORDER>(frac[i][1], w1);
-                    weights_from_frac<float, ORDER>(frac[i][2], w2);
+                    T w0[NT], w1[NT], w2[NT];
+                    weights_from_frac<T, ORDER>(frac[i][0], w0);
+                    weights_from_frac<T, ORDER>(frac[i][1], w1);
+                    weights_from_frac<T, ORDER>(frac[i][2], w2);
 #pragma unroll 1
                     for (int t = 0; t < NT * NT * NT; ++t) {
                         const int l0 = t / (NT * NT), l1 = (t / NT) % NT, l2 = t % NT;
                         const int zs = mirror_i32(start[i][0] + l0, tg.in_len[0]);
                         const int ys = mirror_i32(start[i][1] + l1, tg.in_len[1]);
                         const int xs = mirror_i32(start[i][2] + l2, tg.in_len[2]);
-                        float wp = w0[0], wq = w1[0], wr = w2[0];
+                        T wp = w0[0], wq = w1[0], wr = w2[0];
 #pragma unroll
                         for (int l = 1; l < NT; ++l) {
                             wp = l0 == l ? w0[l] : wp;
@@ -916,35 +952,38 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
                                                xs * tg.in_stride[2]),
                                         gval[i] * wp * wq * wr);
                     }
-                    gval[i] = 0.f;
+                    gval[i] = 0;
                 }
-                gm += fabsf(gval[i]);
+                gm += fabs(gval[i]);
             }
             // sum of |dY| over the tile: wave reduce, one slot per wave, combined after the barrier
             gm = wave_sum(gm);
-            float* gsum = reinterpret_cast<float*>(smem + kOffSum) + (phase & 1) * 4;
+            // per-wave sums: float32 in the fixed slot, float64 behind the box (the slot is 32 bytes)
+            T* gsum = (sizeof(T) == 4 ? reinterpret_cast<T*>(smem + kOffSum)
+                                      : reinterpret_cast<T*>(smem + tg.off_ov + (size_t)tg.box_cap * sizeof(acc_t))) +
+                      (phase & 1) * 4;
             if (lane == 0)
                 gsum[wave] = gm;
             __syncthreads();             // B2: box zeroed, sum known
-            const float gtot = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
-            if (gtot == 0.f)
+            const T gtot = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
+            if (gtot == (T)0)
                 continue;                // all-zero gradient tile (uniform)
             // fixed-point scale.  Rigorous bound on what can land in one accumulator:
             //   |sum| <= max tap weight * sum over the tile's voxels of |dY|   (+ 1/2 per rounding)
             // so scale = (2^31 - 2^10) / (wmax * sum|dY|) cannot overflow an int32; for white-noise
             // dY that is a resolution of ~3e-8 of max|dY| per contribution -- the level of the
             // float32 rounding in the reference's own `+=` (deform.c:309-312).
-            constexpr float kWmax = ORDER == 1 ? 1.0f : ORDER == 2 ? 0.4219f : (ORDER == 3 ? 0.2963f
-                                    : (ORDER == 4 ? 0.2150f : 0.1664f));
-            const float scale = (2147483648.0f - 1024.0f) / (kWmax * 1.001f * gtot);
-            const float inv_scale = 1.0f / scale;
+            constexpr double kWmax = ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : (ORDER == 3 ? 0.2963
+                                    : (ORDER == 4 ? 0.2150 : 0.1664));
+            const T scale = (T)(GradFixed<T>::kRange / (kWmax * 1.001 * (double)gtot));
+            const T inv_scale = (T)1 / scale;
 
             // one voxel at a time (rolled: four unrolled 64-tap scatters do not fit the register
             // budget); the voxel's state is picked out of the register arrays by select chains
 #pragma unroll 1
             for (int i = 0; i < NV; ++i) {
                 int st0 = start[0][0], st1 = start[0][1], st2 = start[0][2];
-                float f0 = frac[0][0], f1 = frac[0][1], f2 = frac[0][2], gv = gval[0];
+                T f0 = frac[0][0], f1 = frac[0][1], f2 = frac[0][2], gv = gval[0];
                 bool act = active[0];
 #pragma unroll
                 for (int k = 1; k < NV; ++k) {
@@ -958,25 +997,25 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
                     gv = sel ? gval[k] : gv;
                     act = sel ? active[k] : act;
                 }
-                if (!act || gv == 0.f || (tg.dbg & 128))
+                if (!act || gv == (T)0 || (tg.dbg & 128))
                     continue;
-                float w0[NT], w1[NT], w2[NT];
-                weights_from_frac<float, ORDER>(f0, w0);
-                weights_from_frac<float, ORDER>(f1, w1);
-                weights_from_frac<float, ORDER>(f2, w2);
+                T w0[NT], w1[NT], w2[NT];
+                weights_from_frac<T, ORDER>(f0, w0);
+                weights_from_frac<T, ORDER>(f1, w1);
+                weights_from_frac<T, ORDER>(f2, w2);
                 const int rz = st0 - b0[0], ry = st1 - b0[1], rx = st2 - b0[2];
-                int* bp = box + (rz * by + ry) * pitch + rx;
-                const float gs = gv * scale;
+                acc_t* bp = box + (rz * by + ry) * pitch + rx;
+                const T gs = gv * scale;
 #pragma unroll
                 for (int l0 = 0; l0 < NT; ++l0) {
-                    const float g0 = gs * w0[l0];
+                    const T g0 = gs * w0[l0];
 #pragma unroll
                     for (int l1 = 0; l1 < NT; ++l1) {
-                        const float g1 = g0 * w1[l1];
-                        int* rp = bp + (l0 * by + l1) * pitch;
+                        const T g1 = g0 * w1[l1];
+                        acc_t* rp = bp + (l0 * by + l1) * pitch;
 #pragma unroll
                         for (int l2 = 0; l2 < NT; ++l2)
-                            atomicAdd(rp + l2, __float2int_rn(g1 * w2[l2]));
+                            atomicAdd(reinterpret_cast<uacc_t*>(rp + l2), (uacc_t)GradFixed<T>::round(g1 * w2[l2]));
                     }
                 }
             }
@@ -986,7 +1025,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
             // elements are one contiguous run of float atomics
             const float inv_pitch = 1.0f / (float)pitch;
             for (int e = tid; e < ((tg.dbg & 64) ? 0 : nbox); e += kBlock) {
-                const int acc = box[e];
+                const acc_t acc = box[e];
                 if (acc != 0) {
                     const int r = (int)(((float)e + 0.5f) * inv_pitch), xi = e - r * pitch;
                     const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
@@ -995,7 +1034,7 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
                     const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, tg.in_len[2]);
                     unsafeAtomicAdd(dst + (zs * tg.in_stride[0] + ys * tg.in_stride[1] +
                                            xs * tg.in_stride[2]),
-                                    (float)acc * inv_scale);
+                                    (T)acc * inv_scale);
                 }
             }
         }
@@ -1009,9 +1048,8 @@ __global__ __launch_bounds__(kBlock, 3) void deform_tile3_grad_kernel(const Grid
 // the per-axis mirror map of deform.c:791-813.  Two uses:
 //   WORKLIST = true : finishes the tiles the LDS kernels could not hold (strong folding, 'wrap'
 //                     seams) from the spill worklist;
-//   WORKLIST = false: the whole volume, for spline order 0 (one tap per voxel: nothing to stage)
-//                     and for the float64 order-1 gradient.  Order 1 otherwise runs on the LDS
-//                     kernels: 256^3 float32 forward 0.27 -> 0.20 ms, gradient 2.1 -> 0.27 ms (eight
+//   WORKLIST = false: the whole volume, for spline order 0 (one tap per voxel: nothing to stage).
+//                     Order 1 runs on the LDS kernels: 256^3 float32 forward 0.27 -> 0.20 ms, gradient 2.1 -> 0.27 ms (eight
 //                     global float atomics per voxel were the cost).
 // ================================================================================================
 template <typename T, int ORDER, bool GRAD, bool WORKLIST>
@@ -1357,8 +1395,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     // elements; otherwise one copy (6144 x 4 bytes or 4096 x 8 bytes)
     size_t box;
     if (GRAD) {
-        tg.box_cap = 8192;
-        box = 8192 * 4;
+        // 32 KiB of fixed-point cells (int32 for float32, int64 for float64) + the float64 wave sums
+        tg.box_cap = (int)(32768 / sizeof(T));
+        box = 32768 + 64;
     } else if (PAIR) {
         tg.box_cap = 3704;      // 57 * 64 + 56; two copies + head + Q stay under 40 KiB -> 4 blocks per CU
         box = 2 * 3704 * sizeof(T);
@@ -1414,9 +1453,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         }
         return e;
     } else {
-    if (ORDER < 1 || (ORDER < 2 && GRAD && !std::is_same<T, float>::value)) {
-        // order 0 (one tap per voxel: no source box, straight from / to global memory) and the
-        // float64 order-1 gradient (the LDS scatter kernel is float32)
+    if (ORDER < 1) {
+        // order 0: one tap per voxel, no source box, straight from / to global memory
         if (e == hipSuccess) {
             const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
             hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, false>), dim3(nblk),
@@ -1431,7 +1469,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
         constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
         if (GRAD)
-            hipLaunchKernelGGL((deform_tile3_grad_kernel<(ORDER < 1 ? 2 : ORDER), 16>), dim3(nblk),
+            hipLaunchKernelGGL((deform_tile3_grad_kernel<T, (ORDER < 1 ? 2 : ORDER), 16>), dim3(nblk),
                                dim3(kBlock), lds, stream, g, ve, tg);
         else if (kBenchKernel && tg.dbg) {
             if constexpr (kBenchKernel) {
@@ -1460,12 +1498,12 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     size_t box2 = 48 * 1024;
     if (t2.off_ov + box2 > 64 * 1024)
         box2 = (64 * 1024 - t2.off_ov) & ~(size_t)63;
-    t2.box_cap = (int)(box2 / (GRAD ? 4 : sizeof(T)));
+    t2.box_cap = (int)((box2 - (GRAD ? 64 : 0)) / sizeof(T));      // gradient: cells of sizeof(T) + wave sums
     const size_t lds2 = t2.off_ov + box2;
     const unsigned n2 = (unsigned)(ntiles < 512 ? ntiles : 512);
     if (e == hipSuccess) {
         if (GRAD)
-            hipLaunchKernelGGL((deform_tile3_grad_kernel<(ORDER < 1 ? 2 : ORDER), 8>), dim3(n2),
+            hipLaunchKernelGGL((deform_tile3_grad_kernel<T, (ORDER < 1 ? 2 : ORDER), 8>), dim3(n2),
                                dim3(kBlock), lds2, stream, g, ve, t2);
         else
             hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, false>), dim3(n2), dim3(kBlock), lds2,
@@ -1518,8 +1556,6 @@ size_t deform_tile_workspace_bytes(const GridGeom& g)
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
 {
     if (g.naxis != 3)
-        return false;
-    if (gradient && v.order >= 2 && v.in_dtype != EDHIP_F32)
         return false;
     if (!deform_fast_supported(g, v, gradient))
         return false;
@@ -1613,11 +1649,20 @@ hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, 
                             : launch_tile<double, 1, false, false>(g, v, stream);
     }
     if (gradient) {
+        if (f32) {
+            switch (v.order) {
+            case 2: return launch_tile<float, 2, false, true>(g, v, stream);
+            case 3: return launch_tile<float, 3, false, true>(g, v, stream);
+            case 4: return launch_tile<float, 4, false, true>(g, v, stream);
+            case 5: return launch_tile<float, 5, false, true>(g, v, stream);
+            default: return hipErrorNotSupported;
+            }
+        }
         switch (v.order) {
-        case 2: return launch_tile<float, 2, false, true>(g, v, stream);
-        case 3: return launch_tile<float, 3, false, true>(g, v, stream);
-        case 4: return launch_tile<float, 4, false, true>(g, v, stream);
-        case 5: return launch_tile<float, 5, false, true>(g, v, stream);
+        case 2: return launch_tile<double, 2, false, true>(g, v, stream);
+        case 3: return launch_tile<double, 3, false, true>(g, v, stream);
+        case 4: return launch_tile<double, 4, false, true>(g, v, stream);
+        case 5: return launch_tile<double, 5, false, true>(g, v, stream);
         default: return hipErrorNotSupported;
         }
     }
