@@ -68,8 +68,8 @@ static_assert(sizeof(AxTab) == 48, "AxTab layout");
 
 // LDS carve (bytes)
 constexpr int kOffTabX = 0;                               // [kStrip][8] AxTab
-constexpr int kOffRed = kOffTabX + kStrip * kT * 48;      // int[2][8]: lo[3], hi[3], -, -
-constexpr int kOffSum = kOffRed + 64;                     // float[2][4]: per-wave sum |dY| (K2)
+constexpr int kOffRed = kOffTabX + kStrip * kT * 48;      // int[3][8]: lo[3], hi[3], -, - (triple-buffered)
+constexpr int kOffSum = kOffRed + 96;                     // float[2][4]: per-wave sum |dY| (K2)
 constexpr int kOffHot = kOffSum + 32;                     // HotParams (uniform values kept out of SGPRs)
 constexpr int kOffQ = kOffHot + 416;
 static_assert(kOffQ % 16 == 0, "LDS carve alignment");
@@ -439,7 +439,7 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& 
         for (int k = tid & 3; k < rowlen; k += 4)
             dst[k] = src[k];
     }
-    if (tid < 16) {
+    if (tid < 24) {
         const int k = tid & 7;
         sred[tid] = k < 3 ? 0x7fffffff : (int)0x80000000;
     }
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
 
     for (int ti = 0; ti < sp.ntile; ++ti) {
         const int o0[3] = {sp.tz * kT, sp.ty * kT, (sp.tx0 + ti) * kT};
-        int* red = sred + (ti & 1) * 8;
+        int* red = sred + (ti % 3) * 8;
 
         // ---- phase A: coordinates of this thread's two voxels ----------------------------------
         int start[2][3];
@@ -630,8 +630,14 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
         const int b0[3] = {red[0], red[1], red[2]};
         const int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
         const bool any = red[3] >= red[0];
-        if (tid < 6)       // re-arm the other buffer for the next tile
-            sred[((ti + 1) & 1) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
+        // Re-arm the buffer of tile ti + 2 (three buffers in rotation).  Not the next tile's: a tile
+        // that is handed to the spill list, or has no live voxel, has no second barrier, so a fast
+        // wave can already be reducing tile ti + 1 into its buffer while this store is pending.
+        // Tile ti + 2's buffer is safe: nobody gets to reduce into it before passing B1 of tile
+        // ti + 1, which this thread only reaches after the store; and its last readers (tile
+        // ti - 1, right after that tile's B1) are all past this tile's B1.
+        if (tid < 6)
+            sred[((ti + 2) % 3) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
         // row pitch: PAIR (ds_read_b64): 16 * odd puts 4 consecutive rows on 4 disjoint bank
         // groups; b32 / f64 reads: 8 or 24 (mod 32)
         int pitch;
@@ -852,7 +858,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 2 : 3) void deform_tile3_g
 
     for (int ti = 0; ti < ntile; ++ti) {
         const int o0[3] = {sp.tz * kT, sp.ty * kT, sp.tx0 * kT + ti * TX};
-        int* red = sred + (ti & 1) * 8;
+        int* red = sred + (ti % 3) * 8;
 
         int start[NV][3];
         T frac[NV][3];
@@ -890,8 +896,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 2 : 3) void deform_tile3_g
         const int b0[3] = {red[0], red[1], red[2]};
         const int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
         const bool any = red[3] >= red[0];
-        if (tid < 6)
-            sred[((ti + 1) & 1) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
+        if (tid < 6)       // tile ti + 2's buffer: see the forward kernel
+            sred[((ti + 2) % 3) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
         if (!any)
             continue;      // nothing to scatter (uniform)
         const int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
@@ -1501,7 +1507,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     t2.box_cap = (int)((box2 - (GRAD ? 64 : 0)) / sizeof(T));      // gradient: cells of sizeof(T) + wave sums
     const size_t lds2 = t2.off_ov + box2;
     const unsigned n2 = (unsigned)(ntiles < 512 ? ntiles : 512);
-    if (e == hipSuccess) {
+    const bool skip_l2 = getenv("EDHIP_SKIP_L2") != nullptr;      // debugging aid
+    if (e == hipSuccess && !skip_l2) {
         if (GRAD)
             hipLaunchKernelGGL((deform_tile3_grad_kernel<T, (ORDER < 1 ? 2 : ORDER), 8>), dim3(n2),
                                dim3(kBlock), lds2, stream, g, ve, t2);
@@ -1513,7 +1520,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     // ---- level 3: whatever is left goes straight through global memory ----------------------------
     if (e == hipSuccess) {
         TileGeom t3 = tg;
-        t3.spill = list_b;
+        t3.spill = skip_l2 ? list_a : list_b;
         const unsigned nsp = (unsigned)(ntiles < 512 ? ntiles : 512);
         hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, true>), dim3(nsp), dim3(kBlock),
                            0, stream, g, ve, t3);

@@ -560,3 +560,25 @@ def test_label_kernel_ties_and_dtypes_bit_exact(mode):
     got = ed.deform_grid([V, L], disp, **kw)
     for g_, w_ in zip(got, want):
         np.testing.assert_array_equal(g_, w_)
+
+
+@pytest.mark.parametrize("dtype,order", [(np.float64, 5), (np.float64, 4), (np.float32, 3)])
+def test_many_spilled_tiles_regression(dtype, order):
+    """Strong deformation of an odd-sized volume: many tiles overflow the first-level LDS box and
+    are handed to the spill passes.  Regression for a race found by tools/fuzz_parity.py: a tile
+    that is handed over has no second barrier, so the re-arm of the next tile's bounding-box slots
+    could land after a fast wave had already reduced into them (fixed by rotating three slots)."""
+    rng = np.random.default_rng(7)
+    X = rng.random((135, 61, 57)).astype(dtype)
+    disp = rng.standard_normal((3, 2, 3, 3)) * 8.0
+    tol = 1e-5 if dtype == np.float32 else 1e-10
+    for mode in ("mirror", "wrap"):
+        want = orc.deform_grid(X, disp, order=order, mode=mode, prefilter=False)
+        for _ in range(3):      # the failure was timing dependent
+            got = ed.deform_grid(X, disp, order=order, mode=mode, prefilter=False)
+            np.testing.assert_allclose(got, want, rtol=tol, atol=tol * 2)
+    dY = rng.random(X.shape).astype(dtype)
+    gw = orc.deform_grid_gradient(dY, disp, order=order, mode="mirror", prefilter=False)
+    for _ in range(2):
+        gg = ed.deform_grid_gradient(dY, disp, order=order, mode="mirror", prefilter=False)
+        np.testing.assert_allclose(gg, gw, rtol=tol, atol=tol * max(1.0, np.abs(gw).max()))
