@@ -66,23 +66,7 @@ template <int NAXIS>
 __global__ __launch_bounds__(256) void source_box_kernel(const GridGeom g, int* box)
 {
     extern __shared__ double sgrid[];       // [NAXIS][ncp_0]...[ncp_{NAXIS-1}]
-    int cstride[NAXIS];                     // element strides of the LDS copy
-    int per = 1;
-#pragma unroll
-    for (int k = NAXIS - 1; k >= 0; --k) {
-        cstride[k] = per;
-        per *= (int)g.ncp[k];
-    }
-    for (int e = threadIdx.x; e < per * NAXIS; e += blockDim.x) {
-        int r = e % per;
-        int64_t offs = g.disp_stride[0] * (e / per);
-#pragma unroll
-        for (int k = 0; k < NAXIS; ++k) {
-            offs += g.disp_stride[k + 1] * (r / cstride[k]);
-            r %= cstride[k];
-        }
-        sgrid[e] = load_as_double(g.disp + offs, g.disp_dtype);
-    }
+    const int per = stage_grid_lds<NAXIS>(g, sgrid);
     __syncthreads();
 
     int lo[NAXIS], hi[NAXIS];
@@ -101,40 +85,16 @@ __global__ __launch_bounds__(256) void source_box_kernel(const GridGeom g, int* 
             o[k] = r - q * g.out_len[k];
             r = q;
         }
-        // same evaluation as eval_displacement (deform.c:650-758), taps from the LDS copy
-        double dw[NAXIS][4];
-        int dtap[NAXIS][4];
-#pragma unroll
-        for (int k = 0; k < NAXIS; ++k) {
-            const double cp = control_coordinate(g.ncp[k], o[k] + g.off[k], g.in_len[k]);
-            const int64_t start = window_start(cp, 3);
-            const bool edge = start < 0 || start + 3 >= g.ncp[k];
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-                dtap[k][l] = (int)(edge ? mirror_index(start + l, g.ncp[k]) : start + l) * cstride[k];
-            spline_weights(cp, 3, dw[k]);
-        }
-        constexpr int kDispTaps = 1 << (2 * NAXIS);
+        double displ[NAXIS];
+        eval_displacement_lds<NAXIS>(g, sgrid, per, o, displ);
 #pragma unroll
         for (int h = 0; h < NAXIS; ++h) {
-            double acc = 0.0;
-#pragma unroll 16
-            for (int t = 0; t < kDispTaps; ++t) {
-                int offs = h * per;
-                double coeff = 1.0;
-#pragma unroll
-                for (int k = 0; k < NAXIS; ++k) {
-                    offs += dtap[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
-                    coeff *= dw[k][(t >> (2 * (NAXIS - 1 - k))) & 3];
-                }
-                acc += sgrid[offs] * coeff;
-            }
+            const double acc = displ[h];
             double c = raw_coordinate<NAXIS>(g, o, h, acc);
             if (!(c == c))
                 c = 0.0;                                        // NaN grid entries: no constraint
             c = c < -1e9 ? -1e9 : (c > 1e9 ? 1e9 : c);
-            // (the product order differs from the deform kernels' in the last ulps: callers keep
-            // a sample of slack around the box)
+            // (callers keep a sample of slack around the box)
             lo[h] = min(lo[h], (int)floor(c));
             hi[h] = max(hi[h], (int)ceil(c));
         }
@@ -152,10 +112,16 @@ __global__ __launch_bounds__(256) void source_box_kernel(const GridGeom g, int* 
     }
 }
 
-template <int NAXIS>
+template <int NAXIS, bool LDSGRID>
 __global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, const IOView v,
                                                            const int gradient)
 {
+    extern __shared__ double sgrid[];       // LDSGRID: the control grid as doubles
+    int per = 0;
+    if (LDSGRID) {
+        per = stage_grid_lds<NAXIS>(g, sgrid);
+        __syncthreads();
+    }
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = g.nvox * v.nsteps;
     if (tid >= total)
@@ -182,7 +148,10 @@ __global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, con
     }
 
     double displ[NAXIS];
-    eval_displacement<NAXIS>(g, o, displ);
+    if (LDSGRID)
+        eval_displacement_lds<NAXIS>(g, sgrid, per, o, displ);
+    else
+        eval_displacement<NAXIS>(g, o, displ);
 
     // ---- source coordinate, boundary map, window + weights, deform.c:768-824 ------------------
     const int order = v.order;
@@ -300,13 +269,29 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
     if (nblk > 0x7fffffffLL)
         return hipErrorInvalidValue;
     const dim3 grid((unsigned)nblk);
+    // small control grids (the normal case) are staged in LDS as doubles
+    int64_t points = g.naxis;
+    for (int k = 0; k < g.naxis; ++k)
+        points *= g.ncp[k];
+    const bool lds_grid = points <= 7680;
+    const size_t lds = lds_grid ? (size_t)points * sizeof(double) : 0;
+#define EDHIP_EXACT(N)                                                                                \
+    do {                                                                                              \
+        if (lds_grid)                                                                                 \
+            hipLaunchKernelGGL((deform_exact_kernel<N, true>), grid, dim3(block), lds, stream, g, v,  \
+                               gradient);                                                             \
+        else                                                                                          \
+            hipLaunchKernelGGL((deform_exact_kernel<N, false>), grid, dim3(block), 0, stream, g, v,   \
+                               gradient);                                                             \
+    } while (0)
     switch (g.naxis) {
-    case 1: hipLaunchKernelGGL(deform_exact_kernel<1>, grid, dim3(block), 0, stream, g, v, gradient); break;
-    case 2: hipLaunchKernelGGL(deform_exact_kernel<2>, grid, dim3(block), 0, stream, g, v, gradient); break;
-    case 3: hipLaunchKernelGGL(deform_exact_kernel<3>, grid, dim3(block), 0, stream, g, v, gradient); break;
-    case 4: hipLaunchKernelGGL(deform_exact_kernel<4>, grid, dim3(block), 0, stream, g, v, gradient); break;
+    case 1: EDHIP_EXACT(1); break;
+    case 2: EDHIP_EXACT(2); break;
+    case 3: EDHIP_EXACT(3); break;
+    case 4: EDHIP_EXACT(4); break;
     default: return hipErrorInvalidValue;
     }
+#undef EDHIP_EXACT
     return hipGetLastError();
 }
 
