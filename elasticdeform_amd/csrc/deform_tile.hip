@@ -558,6 +558,10 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                                                                      const TileGeom tg)
 {
     constexpr int NT = ORDER + 1;
+    // PAIR reads the x-taps as aligned pairs: even orders (an odd number of taps) read one padding
+    // element with weight zero, and the box is one element wider so that the read stays inside it
+    constexpr int kPadX = (PAIR && (NT & 1)) ? 1 : 0;
+    constexpr int NTX = NT + kPadX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int work = blockIdx.x;; work += gridDim.x) {
     StripPos sp;
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
                     lo[h] = min(lo[h], start[i][h]);
-                    hi[h] = max(hi[h], start[i][h] + ORDER);
+                    hi[h] = max(hi[h], start[i][h] + ORDER + (h == 2 ? kPadX : 0));
                 }
             }
         }
@@ -727,10 +731,12 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                 } else if (ABL & 2) {
                     val = frac[i][0] + frac[i][1] + frac[i][2] + (T)start[i][0];
                 } else {
-                    T w0[NT], w1[NT], w2[NT];
+                    T w0[NT], w1[NT], w2[NTX];
                     weights_from_frac<T, ORDER>(frac[i][0], w0);
                     weights_from_frac<T, ORDER>(frac[i][1], w1);
                     weights_from_frac<T, ORDER>(frac[i][2], w2);
+                    if (kPadX)
+                        w2[NT] = (T)0;
                     const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1],
                               rx = start[i][2] - b0[2];
                     const int rowbase = (rz * by + ry) * pitch;
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                                 const T* rp = bp + (l0 * by + l1) * pitch;
                                 T a2 = 0;
 #pragma unroll
-                                for (int l2 = 0; l2 < NT; l2 += 2) {
+                                for (int l2 = 0; l2 < NTX; l2 += 2) {
                                     const float2 pr = *reinterpret_cast<const float2*>(rp + l2);
                                     a2 = fmaf(w2[l2], pr.x, a2);
                                     a2 = fmaf(w2[l2 + 1], pr.y, a2);
@@ -1675,10 +1681,10 @@ hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, 
     }
     if (f32) {
         switch (v.order) {
-        case 2: return launch_tile<float, 2, false, false>(g, v, stream);
+        case 2: return launch_tile<float, 2, true, false>(g, v, stream);
         case 3: return launch_tile<float, 3, true, false>(g, v, stream);
-        case 4: return launch_tile<float, 4, false, false>(g, v, stream);
-        case 5: return launch_tile<float, 5, false, false>(g, v, stream);
+        case 4: return launch_tile<float, 4, true, false>(g, v, stream);
+        case 5: return launch_tile<float, 5, true, false>(g, v, stream);
         default: return hipErrorNotSupported;
         }
     }
