@@ -40,9 +40,10 @@ res["3d_256_f32_o3_mirror_sigma10_grad_ms"] = timed(lambda: ed.deform_grid_gradi
 L3 = T(rng.integers(0, 4, (256, 256, 256)).astype(np.int32))
 res["3d_256_i32_o0_nearest_fwd_ms"] = timed(lambda: ed.deform_grid(L3, d3, order=0, mode="nearest"), 5)
 X64 = X3.double()
-res["3d_256_f64_o3_exact_fwd_ms"] = timed(lambda: ed.deform_grid(X64, d3, order=3, mode="mirror"), 3)
-ed.set_arithmetic("fast")
 res["3d_256_f64_o3_fast_fwd_ms"] = timed(lambda: ed.deform_grid(X64, d3, order=3, mode="mirror"), 3)
+ed.set_arithmetic("exact")
+res["3d_256_f64_o3_exact_fwd_ms"] = timed(lambda: ed.deform_grid(X64, d3, order=3, mode="mirror"), 3)
+res["3d_256_f32_o3_exact_fwd_ms"] = timed(lambda: ed.deform_grid(X3, d3, order=3, mode="mirror"), 3)
 ed.set_arithmetic("auto")
 # cfg3 128^3 autograd
 import elasticdeform_amd.torch as et

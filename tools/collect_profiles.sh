@@ -9,3 +9,4 @@ bash tools/pmc_k1.sh
 python tools/pmc_summary.py gpurun_out/pmc0 > gpurun_out/pmc_summary.txt
 BIG=1 python tools/bench_misc.py > gpurun_out/bench_misc.json 2>/dev/null
 tail -1 gpurun_out/bench_r01.json
+python tools/bench_matrix.py > gpurun_out/bench_matrix.txt 2>/dev/null
