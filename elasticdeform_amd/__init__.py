@@ -11,8 +11,10 @@ elasticdeform/torch.py).
     Y = elasticdeform.deform_random_grid(X, sigma=25, points=3)
 
 As in the reference, the function ``deform_grid`` shadows the submodule of the same name.
+``deform_grid_batch`` / ``deform_grid_gradient_batch`` (no counterpart in the reference) take a
+batch of samples with one control grid each.
 """
 from .deform_grid import (deform_grid, deform_grid_gradient, deform_random_grid,  # noqa: F401
-                          set_arithmetic)
+                          deform_grid_batch, deform_grid_gradient_batch, set_arithmetic)
 
 __version__ = '0.1.0'

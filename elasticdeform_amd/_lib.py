@@ -38,7 +38,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libedhip.so
 
 # every symbol include/edhip.h declares
 EXPORTS = ('edhip_version', 'edhip_status_string', 'edhip_device_count', 'edhip_deform',
-           'edhip_source_box', 'edhip_spline_filter1d', 'edhip_profile_dominant',
+           'edhip_deform_batch', 'edhip_source_box', 'edhip_spline_filter1d', 'edhip_profile_dominant',
            'edhip_profile_last_us')
 
 
@@ -78,6 +78,13 @@ def load():
             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(EdhipArray), ctypes.c_int,
             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
+            ctypes.POINTER(ctypes.c_double), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p,
+            ctypes.c_size_t]
+        L.edhip_deform_batch.restype = ctypes.c_int
+        L.edhip_deform_batch.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.POINTER(EdhipArray), ctypes.POINTER(EdhipArray),
+            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(EdhipArray), ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
             ctypes.POINTER(ctypes.c_double), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p,
             ctypes.c_size_t]
         L.edhip_profile_dominant.restype = ctypes.c_int
@@ -150,6 +157,30 @@ def deform(gradient, in_descs, disp_desc, output_offset, out_descs, axis, orders
         modes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
         cvals.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), aff, int(flags),
         ctypes.c_void_p(stream), buf, 256)
+    raise_for_status(status, buf)
+
+
+def deform_batch(gradient, in_descs, disp_descs, output_offset, out_descs, axis, order, mode, cval,
+                 inverse_affine, flags, stream):
+    """edhip_deform_batch: one volume and one control grid per item, shared parameters."""
+    L = load()
+    n = len(in_descs)
+    axis = numpy.ascontiguousarray(axis, dtype=numpy.int32).reshape(-1)
+    ins = (EdhipArray * n)(*in_descs)
+    disps = (EdhipArray * n)(*disp_descs)
+    outs = (EdhipArray * n)(*out_descs)
+    off = aff = None
+    if output_offset is not None:
+        off_arr = numpy.ascontiguousarray(output_offset, dtype=numpy.int64)
+        off = off_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    if inverse_affine is not None:
+        aff_arr = numpy.ascontiguousarray(inverse_affine, dtype=numpy.float64)
+        aff = aff_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    buf = ctypes.create_string_buffer(256)
+    status = L.edhip_deform_batch(
+        int(bool(gradient)), n, ins, disps, off, outs, len(axis),
+        axis.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(order), int(mode), float(cval), aff,
+        int(flags), ctypes.c_void_p(stream), buf, 256)
     raise_for_status(status, buf)
 
 

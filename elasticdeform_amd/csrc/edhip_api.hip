@@ -277,6 +277,28 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
     return EDHIP_OK;
 }
 
+int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
+                       const edhip_array* displacements, const int64_t* output_offset,
+                       const edhip_array* outputs, int naxis, const int32_t* axis, int32_t order,
+                       int32_t mode, double cval, const double* affine, uint32_t flags,
+                       void* hip_stream, char* err, size_t errlen)
+{
+    if (err && errlen)
+        err[0] = 0;
+    if (nbatch < 0 || (nbatch > 0 && (!inputs || !displacements || !outputs)))
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid batch");
+    for (int b = 0; b < nbatch; ++b) {
+        // stream order keeps item b + 1's control grid / tables (which reuse the workspace) behind
+        // item b's kernels
+        const int st = edhip_deform(gradient, 1, inputs + b, displacements + b, output_offset, outputs + b,
+                                    naxis, axis, &order, &mode, &cval, affine, flags, hip_stream, err,
+                                    errlen);
+        if (st != EDHIP_OK)
+            return st;
+    }
+    return EDHIP_OK;
+}
+
 int edhip_profile_dominant(int enable)
 {
     ed::tile_profile_enable(enable);

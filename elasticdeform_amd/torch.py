@@ -15,6 +15,8 @@ import torch
 # the package re-exports the functions, and `deform_grid` the function shadows the submodule
 from . import deform_grid as _deform_grid_fn
 from . import deform_grid_gradient as _deform_grid_gradient_fn
+from . import deform_grid_batch as _deform_grid_batch_fn
+from . import deform_grid_gradient_batch as _deform_grid_gradient_batch_fn
 
 
 class ElasticDeform(torch.autograd.Function):
@@ -92,3 +94,42 @@ def deform_random_grid(X, sigma=25, points=3, order=3, mode='constant', cval=0.0
     displacement = random_displacement(len(deform_shape), points, sigma, device=Xs[0].device,
                                        generator=generator)
     return deform_grid(X, displacement, order, mode, cval, crop, prefilter, axis, affine, rotate, zoom)
+
+
+class ElasticDeformBatch(torch.autograd.Function):
+    """deform_grid_batch / deform_grid_gradient_batch as an autograd pair: gradients flow to X."""
+
+    @staticmethod
+    def forward(ctx, x, displacements, deform_kwargs):
+        ctx.save_for_backward(displacements)
+        ctx.deform_kwargs = deform_kwargs
+        ctx.x_shape = tuple(x.shape[1:])
+        return _deform_grid_batch_fn(x.detach(), displacements.detach(), **deform_kwargs)
+
+    @staticmethod
+    def backward(ctx, dy):
+        displacements, = ctx.saved_tensors
+        dx = _deform_grid_gradient_batch_fn(dy.detach(), displacements.detach(), X_shape=ctx.x_shape,
+                                            **ctx.deform_kwargs)
+        return dx, None, None
+
+
+def deform_grid_batch(X, displacements, **kwargs):
+    """
+    Batched :func:`deform_grid` with one control grid per sample: ``X`` is ``(B, ...)``,
+    ``displacements`` is ``(B, naxis, n_0, ...)`` (e.g. from :func:`random_displacement` with
+    ``batch=B``); keyword arguments as for ``elasticdeform_amd.deform_grid_batch``.  Differentiable
+    with respect to ``X``.
+    """
+    return ElasticDeformBatch.apply(X, torch.as_tensor(displacements, device=X.device), kwargs)
+
+
+def deform_random_grid_batch(X, sigma=25, points=3, axis=None, generator=None, **kwargs):
+    """Per-sample random deformation of a batch ``X`` of shape ``(B, ...)``: draws ``B`` grids on
+    the device and applies one to each sample (the augmentation step of a data loader, without a
+    host round trip).  ``axis`` counts the axes of one sample."""
+    from . import _host
+    _, deform_shape = _host.normalize_axis_list(axis, [X[0]])
+    disp = random_displacement(len(deform_shape), points, sigma, batch=X.shape[0], device=X.device,
+                               generator=generator)
+    return deform_grid_batch(X, disp, axis=axis, **kwargs)

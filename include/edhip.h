@@ -157,6 +157,26 @@ int edhip_deform(int gradient, int ninputs,
                  char* err, size_t errlen);
 
 /*
+ * A batch of independent volumes, each with its own control grid (per-sample augmentation:
+ * SURVEY.md section 8(f) rank 2): item b is exactly
+ *   edhip_deform(gradient, 1, &inputs[b], &displacements[b], output_offset, &outputs[b], naxis,
+ *                axis, &order, &mode, &cval, affine, flags, hip_stream, ...)
+ * -- same kernels, same results -- enqueued back to back from one host call.  `axis` (naxis
+ * entries), order, mode, cval, the crop offsets and the affine map are shared by the batch.
+ * The reference has no batched entry point; a host loop over its deform_grid is the equivalent.
+ */
+int edhip_deform_batch(int gradient, int nbatch,
+                       const edhip_array* inputs,
+                       const edhip_array* displacements,
+                       const int64_t* output_offset,
+                       const edhip_array* outputs,
+                       int naxis, const int32_t* axis,
+                       int32_t order, int32_t mode, double cval,
+                       const double* affine,
+                       uint32_t flags, void* hip_stream,
+                       char* err, size_t errlen);
+
+/*
  * Measurement aid (bench.py): with profiling enabled, edhip_deform brackets the launch of its
  * dominant kernel -- the LDS-tiled forward / gradient kernel over all strips, without the tables
  * kernel and the spill passes -- with HIP events recorded on `hip_stream`.

@@ -582,3 +582,49 @@ def test_many_spilled_tiles_regression(dtype, order):
     for _ in range(2):
         gg = ed.deform_grid_gradient(dY, disp, order=order, mode="mirror", prefilter=False)
         np.testing.assert_allclose(gg, gw, rtol=tol, atol=tol * max(1.0, np.abs(gw).max()))
+
+
+def test_batch_api_equals_per_sample_calls():
+    """deform_grid_batch / deform_grid_gradient_batch (one control grid per sample, one library
+    call per batch) give exactly what a loop over deform_grid / deform_grid_gradient gives; one
+    sample is also checked against the oracle.  Crop, channel axis, affine, numpy and CUDA inputs,
+    autograd."""
+    import elasticdeform_amd.torch as et
+    rng = np.random.default_rng(17)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cases = [
+        dict(shape=(5, 30, 34, 40), pts=(3, 3, 4), kw=dict(order=3, mode="mirror")),
+        dict(shape=(3, 2, 40, 50), pts=(3, 4), kw=dict(order=2, mode="constant", cval=0.5, axis=(1, 2),
+                                                         crop=(slice(4, 30), slice(10, 44)))),
+        dict(shape=(4, 36, 28, 30), pts=(2, 3, 3), kw=dict(order=1, mode="nearest",
+                                                           affine=np.eye(3, 4) + 0.03 * rng.standard_normal((3, 4)))),
+    ]
+    for c in cases:
+        X = rng.random(c["shape"]).astype(np.float32)
+        B = X.shape[0]
+        D = rng.standard_normal((B, len(c["pts"])) + c["pts"]) * 3
+        kw = c["kw"]
+        got = ed.deform_grid_batch(X, D, **kw)
+        loop = np.stack([ed.deform_grid(X[b], D[b], **kw) for b in range(B)])
+        np.testing.assert_array_equal(got, loop)
+        np.testing.assert_allclose(got[1], orc.deform_grid(X[1], D[1], **kw), **F32_TOL)
+        dY = rng.random(got.shape).astype(np.float32)
+        gg = ed.deform_grid_gradient_batch(dY, D, X_shape=X.shape[1:], **kw)
+        gl = np.stack([ed.deform_grid_gradient(dY[b], D[b], X_shape=X.shape[1:], **kw) for b in range(B)])
+        np.testing.assert_allclose(gg, gl, rtol=1e-5, atol=1e-5 * max(1.0, 64 * np.abs(gl).max()))
+        # CUDA tensors + autograd
+        Xt = torch.from_numpy(X).to(dev).requires_grad_()
+        Yt = et.deform_grid_batch(Xt, torch.from_numpy(D).to(dev), **kw)
+        assert Yt.is_cuda
+        np.testing.assert_array_equal(Yt.detach().cpu().numpy(), got)
+        Yt.backward(torch.from_numpy(dY).to(dev))
+        np.testing.assert_allclose(Xt.grad.cpu().numpy(), gl, rtol=1e-5, atol=1e-5 * max(1.0, 64 * np.abs(gl).max()))
+    # per-sample random grids drawn on the device
+    Xb = torch.rand((6, 24, 26, 28), device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    Yb = et.deform_random_grid_batch(Xb, sigma=2, points=3, generator=g, order=3, mode="mirror")
+    g.manual_seed(5)
+    Db = et.random_displacement(3, 3, 2, batch=6, device=dev, generator=g)
+    np.testing.assert_array_equal(Yb.cpu().numpy(), ed.deform_grid_batch(Xb, Db, order=3, mode="mirror").cpu().numpy())
+    assert not torch.equal(Yb[0], Yb[1])

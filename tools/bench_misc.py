@@ -66,4 +66,16 @@ if os.environ.get("BIG"):
     res["512_crop64_o3_fwd_ms"] = timed(lambda: ed.deform_grid(Xb, d3, order=3, mode="constant", crop=cropb), 5)
     dYb = T(rng.random((64, 64, 64), dtype=np.float32))
     res["512_crop64_o3_grad_ms"] = timed(lambda: ed.deform_grid_gradient(dYb, d3, order=3, mode="constant", crop=cropb, X_shape=(512, 512, 512)), 5)
+# cfg5-like: a batch of 128^3 volumes with one grid each, forward + gradient (per-GPU share 64)
+import elasticdeform_amd.torch as et2
+Xb = torch.rand((32, 128, 128, 128), device=dev)
+Db = et2.random_displacement(3, 5, 2.5, batch=32, device=dev)
+dYb = torch.rand_like(Xb)
+def loop_fg():
+    for b in range(32):
+        ed.deform_grid(Xb[b], Db[b], order=3, mode="mirror"); ed.deform_grid_gradient(dYb[b], Db[b], order=3, mode="mirror")
+def batch_fg():
+    ed.deform_grid_batch(Xb, Db, order=3, mode="mirror"); ed.deform_grid_gradient_batch(dYb, Db, order=3, mode="mirror")
+res["cfg5_32x128_fwd_grad_loop_ms"] = timed(loop_fg, 3)
+res["cfg5_32x128_fwd_grad_batch_ms"] = timed(batch_fg, 3)
 print(json.dumps(res, indent=1))
