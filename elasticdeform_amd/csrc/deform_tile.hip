@@ -1,43 +1,46 @@
 // deform_tile.hip -- K1 (forward gather) and K2 (gradient scatter-add), LDS-tiled: the hot kernels
-// of the benchmark workload (3 deformed axes, float32 / float64 volumes, spline order 2-5).
+// of the benchmark workload (3 deformed axes, float32 / float64 volumes, spline orders 1-5), plus
+// the order-0 direct kernel and the label kernel (order 0, every dtype, bit-equal to the exact path).
 //
 // Per-voxel pipeline of DeformGrid's hot loop (deform.c:649-1001), organised per OUTPUT TILE:
 //
-//   strip    a 256-thread workgroup (4 waves) owns a strip of up to 8 tiles along x; a tile is
-//            8 x 8 x 8 output voxels (cubic, so the source bounding box stays small under shear:
-//            SURVEY.md section 7 -- long-x tiles overfetch 6x, cubes 3.5x); a lane owns one (y, x)
-//            column of the tile and two of its z-slices.
-//   prologue (once per strip) displacement spline, separable, fp64, through LDS (deform.c:639-758):
-//            per-axis cubic weights + mirror-mapped control indices of the strip's 8 + 8 + 64
-//            output indices (the reference's `dsplvals` table, built per strip); the control grid
-//            D parked in LDS as doubles; contracted over z for the 8 slices (P), then over y for
-//            the 64 rows (Q).  Q stays resident for the whole strip, so a voxel is left with 4
+//   tables   (tile_tables_kernel, once per call) the displacement spline is a tensor product
+//            (deform.c:639-758), so it is contracted over z and y once per call, in fp64:
+//            Q[o_z][o_y][c][k_x] = sum w_z w_y D_f, plus the x-table XT[o_x] (cubic weights and
+//            mirror-mapped control indices -- the reference's `dsplvals`).  A voxel is left with 4
 //            x-taps per component: 12 fp64 FMAs instead of the reference's 192 multiply-adds.
+//   strip    a 256-thread workgroup (4 waves) owns a strip of up to 8 tiles along x (4 / 2 for small
+//            outputs); a tile is 8 x 8 x 8 output voxels (cubic, so the source bounding box stays
+//            small under shear: SURVEY.md section 7 -- long-x tiles overfetch 6x, cubes 3.5x); a lane
+//            owns one (y, x) column of the tile and two of its z-slices (K2: 8 x 8 x 16 tiles, four
+//            voxels per lane).  The strip prologue copies its 64 Q rows and 64 XT entries into LDS.
 //   phase A  per tile: displacement, affine, + offset, boundary map, floor -- all fp64 -- then the
 //            fractional offsets are handed to the data's width for the basis weights.
 //   phase B  bounding box of all tap windows of the tile in UNMAPPED tap-index space (wave
-//            min/max reduce, one LDS atomic per wave).
-//   K1 C/D   the source box is staged from HBM/L2 into LDS once (it overlays D/P, dead by then),
-//            rows coalesced along the fastest axis; every box index goes through the mirror map
-//            here, which is what the reference does with the taps of a window that sticks out
-//            (deform.c:791-813) -- the gather needs no edge handling.  float32: a second copy
-//            shifted by one element makes every x-run of taps aligned ds_read_b64 pairs.  Then the
-//            (order+1)^3 tap gather from LDS, accumulated separably (x, y, z) in the data's width.
-//   K2 C/D   (float32) the box is an accumulator: taps are scattered with INTEGER LDS atomics
-//            (ds_add_u32 sustains ~5 cycles per wave instruction on MI355X, ds_add_f32 ~195 --
-//            profiles/r01_ubench_lds.txt) in a per-tile fixed-point scale derived from max|dY| of
-//            the tile, which cannot overflow and rounds each contribution to 2^-22 of that
-//            maximum -- the same order as the float32 rounding of the reference's own `+=`
-//            (deform.c:309-312).  The box is then flushed with one float atomic per touched
-//            source element (mirror-mapped; dX must be zero on entry): ~3.5 global atomics per
-//            voxel instead of 64.
-//   spill    a tile whose box exceeds the LDS budget (strong folding, 'wrap' seams) is appended to
-//            a worklist and finished by the spill kernels straight from global memory with
-//            per-tap mirror mapping; the hot kernels carry no fallback code.
+//            min/max reduce, one LDS atomic per wave; three result slots in rotation).
+//   K1 C/D   the source box is staged from HBM/L2 into LDS once, rows coalesced along the fastest
+//            axis; every box index goes through the mirror map here, which is what the reference
+//            does with the taps of a window that sticks out (deform.c:791-813) -- the gather needs
+//            no edge handling.  float32: a second copy shifted by one element makes every x-run of
+//            taps aligned ds_read_b64 pairs (even orders pad a zero-weight tap).  Then the
+//            (order+1)^3 tap gather from LDS, accumulated separably (x, y, z) in the data's width;
+//            streaming output stores.
+//   K2 C/D   the box is an accumulator: taps are scattered with INTEGER LDS atomics (ds_add_u32
+//            sustains ~5 cycles per wave instruction on MI355X, ds_add_f32 ~195 --
+//            profiles/r01_ubench_lds.txt; float64 volumes use int64 cells) in a per-tile
+//            fixed-point scale derived from the tile's sum of |dY|, which cannot overflow and
+//            resolves each contribution far below the float rounding of the reference's own `+=`
+//            (deform.c:309-312).  The box is then flushed with one float atomic per touched source
+//            element (mirror-mapped; dX must be zero on entry): ~2.3 global atomics per voxel
+//            instead of 64.
+//   spill    a tile whose box exceeds the first-level LDS budget (strong folding, 'wrap' seams) is
+//            appended to a worklist: level 2 retries it alone with a 48 KiB box, level 3 (the
+//            direct kernel) finishes what is left straight from global memory with per-tap mirror
+//            mapping; the hot kernels carry no fallback code.
 //
-// HBM traffic: each source voxel is fetched ~3.5x per launch but from L2 / Infinity Cache
-// (neighbouring tiles overlap; strips are dealt to the 8 XCDs in contiguous chunks so that the
-// overlap stays inside one L2); algorithmic bytes are 4 read + 4 written per voxel (float32).
+// HBM traffic (256^3 float32, profiles/hbm_traffic.json): 61 MB fetched -- the source volume once;
+// neighbouring tiles overlap, but strips are dealt to the 8 XCDs in contiguous chunks so that the
+// overlap stays inside one L2 -- and 85 MB written; algorithmic bytes are 4 + 4 per voxel.
 #include <atomic>
 #include <type_traits>
 #include <cstdlib>
