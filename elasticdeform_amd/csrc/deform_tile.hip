@@ -374,7 +374,9 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             t.w[l] = w[l];
-            t.idx[l] = (int)(edge ? mirror_index(start + l, g.ncp[a]) : start + l);
+            // (32-bit mirror map: a 64-bit integer division costs ~1 us here, and with few control
+            // points most windows are edge windows)
+            t.idx[l] = edge ? mirror_i32((int)start + l, (int)g.ncp[a]) : (int)start + l;
         }
     };
     if (tid == 0)
