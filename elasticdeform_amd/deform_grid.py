@@ -375,8 +375,10 @@ def deform_grid_batch(X, displacements, order=3, mode='constant', cval=0.0, crop
         Xf = Xd
         if prefilter and o > 1:
             Xf = _filter_axes(Xd, [a + 1 for a in ax], o, False, device)
-        raw = dd[0].numel() <= _lib.RAW_DISPLACEMENT_MAX_POINTS
-        df = dd if raw else _filter_axes(dd, range(2, dd.ndim), 3, False, device)
+        # all B control grids are prefiltered together (three launches for the batch instead of one
+        # per sample inside edhip_deform; same values: tests pin RAW_DISPLACEMENT == per-axis filter)
+        raw = False
+        df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
         out = torch.empty((B,) + tuple(int(v) for v in plan.output_shapes[0]), dtype=Xd.dtype, device=device)
         _lib.deform_batch(False, [_desc(Xf[b]) for b in range(B)], [_desc(df[b]) for b in range(B)],
                           plan.output_offset, [_desc(out[b]) for b in range(B)], ax, o,
@@ -410,8 +412,8 @@ def deform_grid_gradient_batch(dY, displacements, order=3, mode='constant', cval
                              % (str(plan.output_shapes[0]), str(tuple(dYd.shape[1:]))))
         ax = plan.axis[0]
         o = int(plan.order[0])
-        raw = dd[0].numel() <= _lib.RAW_DISPLACEMENT_MAX_POINTS
-        df = dd if raw else _filter_axes(dd, range(2, dd.ndim), 3, False, device)
+        raw = False
+        df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
         _lib.deform_batch(True, [_desc(dX[b]) for b in range(B)], [_desc(df[b]) for b in range(B)],
                           plan.output_offset, [_desc(dYd[b]) for b in range(B)], ax, o,
                           int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine,
