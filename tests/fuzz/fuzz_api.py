@@ -2,9 +2,9 @@
 """Randomised sweep of the public API against the oracle, second part: multi-input lists with
 per-input order / mode / axis, 2-D rotate / zoom, large control grids, 4 deformed axes, CUDA tensor
 inputs (strided views stay on the device), crops with gradients.
-python tools/fuzz_api.py [seed] [cases]"""
+python tests/fuzz/fuzz_api.py [seed] [cases]"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import elasticdeform_amd as ed

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised sweep of edhip_spline_filter1d against SciPy (forward) and the oracle (transpose):
 shapes, axes, orders, dtypes, strided / transposed views, in place and out of place, both
-arithmetic modes.  python tools/fuzz_filter.py [seed] [cases]"""
+arithmetic modes.  python tests/fuzz/fuzz_filter.py [seed] [cases]"""
 import sys, os, importlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, scipy.ndimage, torch
 from elasticdeform_amd import _lib

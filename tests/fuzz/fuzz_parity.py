@@ -2,9 +2,9 @@
 """Randomised parity sweep: elasticdeform_amd (GPU) against the oracle on random configurations --
 dimensionality, shapes, control grids, orders, modes, crops, affine maps, dtypes, channel axes,
 strided / transposed inputs, multi-input lists.  Not part of the test suite (minutes of oracle
-time); run it on the GPU box:  python tools/fuzz_parity.py [seed] [cases]"""
+time); run it on the GPU box:  python tests/fuzz/fuzz_parity.py [seed] [cases]"""
 import sys, os, itertools, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import elasticdeform_amd as ed

@@ -565,7 +565,7 @@ def test_label_kernel_ties_and_dtypes_bit_exact(mode):
 @pytest.mark.parametrize("dtype,order", [(np.float64, 5), (np.float64, 4), (np.float32, 3)])
 def test_many_spilled_tiles_regression(dtype, order):
     """Strong deformation of an odd-sized volume: many tiles overflow the first-level LDS box and
-    are handed to the spill passes.  Regression for a race found by tools/fuzz_parity.py: a tile
+    are handed to the spill passes.  Regression for a race found by tests/fuzz/fuzz_parity.py: a tile
     that is handed over has no second barrier, so the re-arm of the next tile's bounding-box slots
     could land after a fast wave had already reduced into them (fixed by rotating three slots)."""
     rng = np.random.default_rng(7)
