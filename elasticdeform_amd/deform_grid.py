@@ -108,18 +108,22 @@ def _stream(device):
 
 def _filter_axes(x, axes, order, transpose, device):
     """Chain of 1-D spline filters over `axes` -- the reference's loop at deform_grid.py:157-162
-    (forward) / :279-284 (transpose).  The reference filters x -> x_f and then x_f in place; here
-    the passes ping-pong between two buffers (the caller's x is never written), which lets the
-    kernels split long lines across lanes; the values are the same."""
+    (forward) / :279-284 (transpose).  The reference filters x -> x_f and then x_f in place; so does
+    this chain for lines of up to 256 samples, and it ping-pongs between two buffers for longer ones
+    (the caller's x is never written); the values are the same."""
     torch = _torch()
     axes = list(axes)
     if not axes:
         return x
     stream = _stream(device)
-    bufs = [torch.empty_like(x), torch.empty_like(x) if len(axes) > 1 else None]
+    # Lines that fit the whole-line tile kernels are filtered in place from the second pass on
+    # (like the reference; one temporary instead of two keeps the step's working set smaller);
+    # longer lines ping-pong, because in place the block-recompute kernels cannot split a line.
+    inplace = all(int(x.shape[d]) <= 256 for d in axes) and not os.environ.get('EDHIP_FILTER_PINGPONG')
+    bufs = [torch.empty_like(x), torch.empty_like(x) if (len(axes) > 1 and not inplace) else None]
     src = x
     for i, d in enumerate(axes):
-        dst = bufs[i & 1]
+        dst = bufs[0] if inplace else bufs[i & 1]
         _lib.spline_filter1d(_desc(src), _desc(dst), d, order, transpose, _flags, stream)
         src = dst
     return src
