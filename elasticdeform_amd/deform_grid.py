@@ -106,7 +106,7 @@ def _stream(device):
     return _torch().cuda.current_stream(device).cuda_stream
 
 
-def _filter_axes(x, axes, order, transpose, device):
+def _filter_axes(x, axes, order, transpose, device, overwrite=False):
     """Chain of 1-D spline filters over `axes` -- the reference's loop at deform_grid.py:157-162
     (forward) / :279-284 (transpose).  The reference filters x -> x_f and then x_f in place; so does
     this chain for lines of up to 256 samples, and it ping-pongs between two buffers for longer ones
@@ -120,7 +120,10 @@ def _filter_axes(x, axes, order, transpose, device):
     # (like the reference; one temporary instead of two keeps the step's working set smaller);
     # longer lines ping-pong, because in place the block-recompute kernels cannot split a line.
     inplace = all(int(x.shape[d]) <= 256 for d in axes) and not os.environ.get('EDHIP_FILTER_PINGPONG')
-    bufs = [torch.empty_like(x), torch.empty_like(x) if (len(axes) > 1 and not inplace) else None]
+    if overwrite and inplace:
+        bufs = [x, None]            # x is the caller's own temporary (dX): every pass in place
+    else:
+        bufs = [torch.empty_like(x), torch.empty_like(x) if (len(axes) > 1 and not inplace) else None]
     src = x
     for i, d in enumerate(axes):
         dst = bufs[0] if inplace else bufs[i & 1]
@@ -329,7 +332,7 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
             if not (prefilter and plan.order[i] > 1):
                 dXf.append(x)
             elif wins[i] is None:
-                dXf.append(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device))
+                dXf.append(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device, overwrite=True))
             else:
                 view = _window_view(x, plan.axis[i], wins[i])
                 view.copy_(_filter_axes(view, plan.axis[i], int(plan.order[i]), True, device))
@@ -423,5 +426,5 @@ def deform_grid_gradient_batch(dY, displacements, order=3, mode='constant', cval
                           int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine,
                           _flags | (_lib.FLAG_RAW_DISPLACEMENT if raw else 0), _stream(device))
         if prefilter and o > 1:
-            dX = _filter_axes(dX, [a + 1 for a in ax], o, True, device)
+            dX = _filter_axes(dX, [a + 1 for a in ax], o, True, device, overwrite=True)
         return _from_device(dX, dY)
