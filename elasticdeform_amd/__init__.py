@@ -17,4 +17,6 @@ batch of samples with one control grid each.
 from .deform_grid import (deform_grid, deform_grid_gradient, deform_random_grid,  # noqa: F401
                           deform_grid_batch, deform_grid_gradient_batch, set_arithmetic)
 
+from ._lib import release_scratch  # noqa: F401,E402  (frees the library's cached device scratch)
+
 __version__ = '0.1.0'

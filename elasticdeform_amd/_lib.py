@@ -38,7 +38,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libedhip.so
 
 # every symbol include/edhip.h declares
 EXPORTS = ('edhip_version', 'edhip_status_string', 'edhip_device_count', 'edhip_deform',
-           'edhip_deform_batch', 'edhip_source_box', 'edhip_spline_filter1d', 'edhip_profile_dominant',
+           'edhip_deform_batch', 'edhip_source_box', 'edhip_spline_filter1d', 'edhip_release_scratch', 'edhip_profile_dominant',
            'edhip_profile_last_us')
 
 
@@ -80,6 +80,8 @@ def load():
             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
             ctypes.POINTER(ctypes.c_double), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p,
             ctypes.c_size_t]
+        L.edhip_release_scratch.restype = ctypes.c_int
+        L.edhip_release_scratch.argtypes = []
         L.edhip_deform_batch.restype = ctypes.c_int
         L.edhip_deform_batch.argtypes = [
             ctypes.c_int, ctypes.c_int, ctypes.POINTER(EdhipArray), ctypes.POINTER(EdhipArray),
@@ -216,3 +218,8 @@ def spline_filter1d(in_desc, out_desc, axis, order, transpose, flags, stream):
                                      int(order), int(bool(transpose)), int(flags),
                                      ctypes.c_void_p(stream), buf, 256)
     raise_for_status(status, buf)
+
+
+def release_scratch():
+    """edhip_release_scratch: free the library's cached per-stream workspaces."""
+    load().edhip_release_scratch()

@@ -6,7 +6,7 @@
 // scratch is kept: one buffer per (device, stream), grown on demand, reused by every later call on
 // that stream.  Work on one stream is ordered, so consecutive calls can share the buffer; growing
 // synchronises that stream once before the old buffer is released.  Buffers live until the
-// process exits.  The library stays re-entrant: the table is mutex-protected and calls on
+// process exits or workspace_release_all() (edhip_release_scratch) is called.  The library stays re-entrant: the table is mutex-protected and calls on
 // different streams never share a buffer.
 #pragma once
 
@@ -19,5 +19,8 @@ namespace ed {
 // Returns a device pointer to at least `bytes` bytes of scratch owned by (current device, stream),
 // or nullptr with *err set.  The contents are unspecified.
 void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err);
+
+// Drains the devices that own scratch and frees every cached buffer.
+void workspace_release_all();
 
 }  // namespace ed

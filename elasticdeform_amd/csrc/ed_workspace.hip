@@ -58,4 +58,27 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
     return b.ptr;
 }
 
+void workspace_release_all()
+{
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (auto& kv : g_buffers) {
+        if (!kv.second.ptr)
+            continue;
+        // everything enqueued on that device must be done with the buffer (the stream itself may
+        // already have been destroyed by its owner, so the whole device is drained)
+        if (hipSetDevice(kv.first.first) == hipSuccess) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(kv.second.ptr);
+        }
+        kv.second.ptr = nullptr;
+        kv.second.cap = 0;
+    }
+    g_buffers.clear();
+    if (have_cur)
+        (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+}
+
 }  // namespace ed

@@ -299,6 +299,12 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
     return EDHIP_OK;
 }
 
+int edhip_release_scratch(void)
+{
+    ed::workspace_release_all();
+    return EDHIP_OK;
+}
+
 int edhip_profile_dominant(int enable)
 {
     ed::tile_profile_enable(enable);

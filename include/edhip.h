@@ -177,6 +177,15 @@ int edhip_deform_batch(int gradient, int nbatch,
                        char* err, size_t errlen);
 
 /*
+ * Frees the scratch workspaces the library caches per (device, stream): per-call tables, spill
+ * lists, the fp64 line buffers of the exact prefilter and the dense temporary of the order-4/5
+ * cascade (up to the size of the largest array filtered that way).  Waits for the owning devices to
+ * go idle first.  Later calls allocate again on demand.  Must not run concurrently with other
+ * calls into the library.
+ */
+int edhip_release_scratch(void);
+
+/*
  * Measurement aid (bench.py): with profiling enabled, edhip_deform brackets the launch of its
  * dominant kernel -- the LDS-tiled forward / gradient kernel over all strips, without the tables
  * kernel and the spill passes -- with HIP events recorded on `hip_stream`.

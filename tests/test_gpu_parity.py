@@ -628,3 +628,16 @@ def test_batch_api_equals_per_sample_calls():
     Db = et.random_displacement(3, 3, 2, batch=6, device=dev, generator=g)
     np.testing.assert_array_equal(Yb.cpu().numpy(), ed.deform_grid_batch(Xb, Db, order=3, mode="mirror").cpu().numpy())
     assert not torch.equal(Yb[0], Yb[1])
+
+
+def test_release_scratch_then_reuse():
+    """edhip_release_scratch frees the cached workspaces; the next call allocates again."""
+    rng = np.random.default_rng(3)
+    X = rng.random((30, 40, 50)).astype(np.float32)
+    disp = rng.standard_normal((3, 3, 3, 3)) * 2
+    a = ed.deform_grid(X, disp, order=3, mode="mirror")
+    ed.release_scratch()
+    b = ed.deform_grid(X, disp, order=3, mode="mirror")
+    np.testing.assert_array_equal(a, b)
+    ed.release_scratch()
+    ed.release_scratch()        # idempotent
