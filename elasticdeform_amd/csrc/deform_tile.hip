@@ -1041,11 +1041,13 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 2 : 3) void deform_tile3_g
             // flush: one float atomic per touched source element, mirror-mapped (deform.c:791-813)
             // consecutive lanes walk consecutive elements of the padded rows: a row's touched
             // elements are one contiguous run of float atomics
-            const float inv_pitch = 1.0f / (float)pitch;
-            for (int e = tid; e < ((tg.dbg & 64) ? 0 : nbox); e += kBlock) {
-                const acc_t acc = box[e];
+            // (only the ext[2] live cells of each padded row are visited)
+            const float inv_ex = 1.0f / (float)ext[2];
+            const int ncell = nrows * ext[2];
+            for (int e = tid; e < ((tg.dbg & 64) ? 0 : ncell); e += kBlock) {
+                const int r = (int)(((float)e + 0.5f) * inv_ex), xi = e - r * ext[2];
+                const acc_t acc = box[r * pitch + xi];
                 if (acc != 0) {
-                    const int r = (int)(((float)e + 0.5f) * inv_pitch), xi = e - r * pitch;
                     const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                     const int zs = mirror_i32(b0[0] + zr, tg.in_len[0]);
                     const int ys = mirror_i32(b0[1] + yr, tg.in_len[1]);
