@@ -186,6 +186,16 @@ def compose_rotation_zoom(rotate, zoom, inverse_affine, out_deform_shape):
     return numpy.dot(m, base)[:2, :]
 
 
+class ShapeOnly(object):
+    """Stand-in for an array of which only the shape is known (the dX of a gradient call before it
+    is allocated): Plan inspects ``.shape`` / ``.ndim`` only."""
+    __slots__ = ("shape", "ndim")
+
+    def __init__(self, shape):
+        self.shape = tuple(int(v) for v in shape)
+        self.ndim = len(self.shape)
+
+
 class Plan(object):
     """The normalised, array-free part of one deform_grid / deform_grid_gradient call -- i.e. the
     non-array arguments of _deform_grid.deform_grid (_deform_grid.c:108-118)."""

@@ -1295,6 +1295,13 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_label_kernel(const GridGe
                 step_offsets(v, ss, in_off, out_off);
                 if (cst)
                     store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype, v.cval);
+                else if (sizeof(W) == 8)
+                    // 64-bit integers: the reference takes every value through a double and the
+                    // rounding / clamping store (deform.c:863-887,906-919), which changes labels
+                    // beyond 2^53 and near the type's limits -- reproduce that round trip
+                    store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype,
+                                  load_as_double(reinterpret_cast<const char*>(inp + (in_off + src_idx)),
+                                                 v.in_dtype));
                 else
                     __builtin_nontemporal_store(inp[in_off + src_idx], outp + (out_off + obase));
             }
@@ -1343,6 +1350,10 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_label_tie_kernel(const Gr
             step_offsets(v, ss, in_off, out_off);
             if (cst)
                 store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype, v.cval);
+            else if (sizeof(W) == 8)
+                store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype,
+                              load_as_double(reinterpret_cast<const char*>(inp + (in_off + src_idx)),
+                                             v.in_dtype));
             else
                 outp[out_off + obase] = inp[in_off + src_idx];
         }

@@ -23,4 +23,22 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err);
 // Drains the devices that own scratch and frees every cached buffer.
 void workspace_release_all();
 
+// Serialises the host side of API calls that target the same (device, stream): the workspace of a
+// stream is shared by consecutive calls (control grid, tables, spill lists), so two host threads
+// enqueueing on ONE stream -- torch's default stream is shared by all Python threads, and ctypes
+// drops the GIL -- must not interleave their launches (thread A's tables, thread B's tables, A's
+// tile kernel reading B's tables), nor may one grow the buffer while the other still holds the old
+// pointer.  Calls only enqueue work, so the lock is held for microseconds; calls on different
+// streams or devices never contend.  Re-entrant (edhip_deform_batch calls edhip_deform).
+class StreamGuard {
+public:
+    explicit StreamGuard(hipStream_t stream);
+    ~StreamGuard();
+    StreamGuard(const StreamGuard&) = delete;
+    StreamGuard& operator=(const StreamGuard&) = delete;
+
+private:
+    void* mutex_;
+};
+
 }  // namespace ed

@@ -1,6 +1,7 @@
 #include "ed_workspace.h"
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <utility>
 
@@ -13,7 +14,31 @@ struct Buffer {
 };
 std::mutex g_mutex;
 std::map<std::pair<int, hipStream_t>, Buffer> g_buffers;
+// one host-side lock per (device, stream); entries are never erased, so the pointers stay valid
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::recursive_mutex>> g_stream_locks;
 }  // namespace
+
+StreamGuard::StreamGuard(hipStream_t stream) : mutex_(nullptr)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::recursive_mutex* m;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        auto& slot = g_stream_locks[std::make_pair(dev, stream)];
+        if (!slot)
+            slot.reset(new std::recursive_mutex);
+        m = slot.get();
+    }
+    m->lock();
+    mutex_ = m;
+}
+
+StreamGuard::~StreamGuard()
+{
+    if (mutex_)
+        static_cast<std::recursive_mutex*>(mutex_)->unlock();
+}
 
 void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
 {

@@ -150,6 +150,7 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
 {
     using namespace ed;
     hipStream_t stream = (hipStream_t)hip_stream;
+    StreamGuard guard(stream);      // the stream's scratch is ours until every launch is enqueued
     if (err && errlen)
         err[0] = 0;
 
@@ -287,6 +288,7 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
         err[0] = 0;
     if (nbatch < 0 || (nbatch > 0 && (!inputs || !displacements || !outputs)))
         return fail(err, errlen, EDHIP_ERR_INVALID, "invalid batch");
+    ed::StreamGuard guard((hipStream_t)hip_stream);
     for (int b = 0; b < nbatch; ++b) {
         // stream order keeps item b + 1's control grid / tables (which reuse the workspace) behind
         // item b's kernels
@@ -319,6 +321,7 @@ int edhip_source_box(const edhip_array* displacement, const int64_t* in_len, con
 {
     using namespace ed;
     hipStream_t stream = (hipStream_t)hip_stream;
+    StreamGuard guard(stream);
     if (err && errlen)
         err[0] = 0;
     if (!in_len || !out_len || !box || naxis < 1)
@@ -366,6 +369,7 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
 {
     using namespace ed;
     hipStream_t stream = (hipStream_t)hip_stream;
+    StreamGuard guard(stream);
     if (err && errlen)
         err[0] = 0;
     if (!input || !output)

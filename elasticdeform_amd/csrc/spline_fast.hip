@@ -29,6 +29,7 @@
 //
 // Algorithmic bytes: 2 * sizeof(T) per sample per axis; the 32-sample warm-ups are re-reads that
 // hit L2.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -762,13 +763,27 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
 
 constexpr size_t kTileLdsBudget = 80 * 1024;      // two workgroups per CU
 
+// hipFuncSetAttribute is per device (the attribute lives with the device's code object): one
+// process may drive several GPUs, so the result is cached per kernel instantiation AND device
 template <typename K>
 hipError_t allow_large_lds(K kernel, size_t bytes)
 {
     if (bytes <= 64 * 1024)
         return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLdsBudget);
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> state[kMaxDev];      // 0 unknown, 1 ok, 2 failed (one array per K)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLdsBudget);
+    const int st = state[dev].load(std::memory_order_acquire);
+    if (st)
+        return st == 1 ? hipSuccess : hipErrorNotSupported;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)kTileLdsBudget);
+    state[dev].store(e == hipSuccess ? 1 : 2, std::memory_order_release);
+    return e;
 }
 
 // returns hipErrorNotSupported when no whole-line tile fits
@@ -830,7 +845,7 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
         if (lds > kTileLdsBudget)
             return hipErrorNotSupported;
         if (vec) {
-            static const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, true>, kTileLdsBudget);
+            const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, true>, kTileLdsBudget);
             if (attr != hipSuccess)
                 return hipErrorNotSupported;
             if (getenv("EDHIP_FILTER_TRACE")) {
@@ -853,7 +868,7 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
             hipLaunchKernelGGL((prefilter_tile_contig_kernel<T, true>), dim3((unsigned)nblk), dim3(kBlock),
                                lds, stream, p);
         } else {
-            static const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, false>, kTileLdsBudget);
+            const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, false>, kTileLdsBudget);
             if (attr != hipSuccess)
                 return hipErrorNotSupported;
             hipLaunchKernelGGL((prefilter_tile_contig_kernel<T, false>), dim3((unsigned)nblk), dim3(kBlock),
@@ -895,7 +910,7 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
     const size_t lds = tile_rows * C * sizeof(T);
 #define EDHIP_TILE_STRIDED(CC, VV)                                                                   \
     do {                                                                                             \
-        static const hipError_t attr =                                                               \
+        const hipError_t attr =                                                                      \
             allow_large_lds(prefilter_tile_strided_kernel<T, CC, VV>, kTileLdsBudget);              \
         if (attr != hipSuccess)                                                                      \
             return hipErrorNotSupported;                                                             \

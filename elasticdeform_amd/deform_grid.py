@@ -300,6 +300,15 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
             raise ValueError("X_shape is required if the crop parameter is given.")
         X_shape = [tuple(dy.shape) for dy in dYs]
 
+    # every argument check runs before anything touches the device, in the reference's order
+    # (deform_grid.py:246-266): a bad displacement / order / crop raises what the reference raises
+    plan = _host.Plan([_host.ShapeOnly(s) for s in X_shape], displacement, order, mode, cval, crop,
+                      axis, affine, rotate, zoom)
+    if [tuple(s) for s in plan.output_shapes] != [tuple(dy.shape) for dy in dYs]:
+        raise ValueError("X_shape does not match output shape and cropping. "
+                         "Expected output shape is %s, but %s given."
+                         % (str(plan.output_shapes), str([tuple(dy.shape) for dy in dYs])))
+
     torch = _torch()
     device = _device_for(list(dYs) + [displacement])
     with torch.cuda.device(device):
@@ -307,12 +316,6 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         # gradient accumulators start at zero (deform_grid.py:243)
         dXs = [torch.zeros(tuple(int(v) for v in s), dtype=dy.dtype, device=device)
                for s, dy in zip(X_shape, dYd)]
-
-        plan = _host.Plan(dXs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
-        if [tuple(s) for s in plan.output_shapes] != [tuple(dy.shape) for dy in dYs]:
-            raise ValueError("X_shape does not match output shape and cropping. "
-                             "Expected output shape is %s, but %s given."
-                             % (str(plan.output_shapes), str([tuple(dy.shape) for dy in dYs])))
 
         dd = _to_device(displacement, device)
         df, dflag = _prefilter_displacement(dd, device)
@@ -405,6 +408,17 @@ def deform_grid_gradient_batch(dY, displacements, order=3, mode='constant', cval
         if crop is not None:
             raise ValueError("X_shape is required if the crop parameter is given.")
         X_shape = tuple(dY.shape[1:])
+    if not _host.is_array(displacements) or displacements.ndim < 3:
+        raise Exception('displacements should be an array of shape (batch, naxis, n_0, ...).')
+    assert displacements.shape[0] == dY.shape[0], 'One displacement grid per sample is required.'
+    assert not isinstance(order, (list, tuple)) and not isinstance(mode, (list, tuple)) and \
+        not isinstance(cval, (list, tuple)), 'order, mode and cval are shared by the batch.'
+    plan = _host.Plan([_host.ShapeOnly(X_shape)], displacements[0], order, mode, cval, crop, axis,
+                      affine, rotate, zoom)
+    if tuple(plan.output_shapes[0]) != tuple(dY.shape[1:]):
+        raise ValueError("X_shape does not match output shape and cropping. "
+                         "Expected output shape is %s, but %s given."
+                         % (str(plan.output_shapes[0]), str(tuple(dY.shape[1:]))))
     torch = _torch()
     device = _device_for([dY, displacements])
     with torch.cuda.device(device):
@@ -412,11 +426,6 @@ def deform_grid_gradient_batch(dY, displacements, order=3, mode='constant', cval
         dd = _to_device(displacements, device)
         B = int(dYd.shape[0])
         dX = torch.zeros((B,) + tuple(int(v) for v in X_shape), dtype=dYd.dtype, device=device)
-        plan = _batch_plan(dX, displacements, order, mode, cval, crop, axis, affine, rotate, zoom)
-        if tuple(plan.output_shapes[0]) != tuple(dYd.shape[1:]):
-            raise ValueError("X_shape does not match output shape and cropping. "
-                             "Expected output shape is %s, but %s given."
-                             % (str(plan.output_shapes[0]), str(tuple(dYd.shape[1:]))))
         ax = plan.axis[0]
         o = int(plan.order[0])
         raw = False

@@ -51,14 +51,15 @@ def load_reference():
     if ext is None or not os.path.isdir(src):
         return None
     root = tempfile.mkdtemp(prefix="ed_ref_pkg_")
-    pkg = os.path.join(root, "elasticdeform")
+    # (imported under a private name: `elasticdeform` itself is this repo's drop-in alias package)
+    pkg = os.path.join(root, "ed_reference_pkg")
     os.mkdir(pkg)
     for f in ("__init__.py", "deform_grid.py", "torch.py"):
         os.symlink(os.path.join(src, f), os.path.join(pkg, f))
     os.symlink(ext, os.path.join(pkg, os.path.basename(ext)))
     sys.path.insert(0, root)
     try:
-        _ref_pkg = importlib.import_module("elasticdeform")
+        _ref_pkg = importlib.import_module("ed_reference_pkg")
     finally:
         sys.path.remove(root)
     return _ref_pkg

@@ -224,6 +224,20 @@ def cfg4_inputs(n=256):
     return [img, lab], disp, kw
 
 
+CFG5_BATCH = 64            # volumes per GPU of BASELINE cfg5 (512 volumes of 128^3 over 8 GPUs)
+CFG5_GOLDEN = (0, 31, 63)  # samples of the shard whose reference outputs are stored
+
+
+def cfg5_sample(b, n=128):
+    """Sample b of a cfg5 shard: a 128^3 float32 volume, its own 5^3 control grid (sigma 2.5, the
+    relative strength of cfg2 at 256^3) and a gradient seed -- one RNG stream per sample so that a
+    rank can materialise just its shard (generated per shard)."""
+    X = np.random.default_rng(5000 + b).random((n, n, n), dtype=np.float32)
+    disp = np.random.default_rng(55000 + b).standard_normal((3, 5, 5, 5)) * 2.5
+    dY = np.random.default_rng(555000 + b).random((n, n, n), dtype=np.float32)
+    return X, disp, dict(order=3, mode="mirror"), dY
+
+
 def big_cases():
     cases = []
     cases.append(dict(name="cfg1_readme", make=cfg1_inputs, grad=False, big=False,
@@ -244,6 +258,13 @@ def big_cases():
     cases.append(dict(name="cfg3_128", make=make3, grad=True, big=True,
                       dY=lambda: cfg3_inputs()[3],
                       pick=lambda: ((slice(40, 72, 2), slice(0, 128, 8), slice(96, 128)),)))
+    for b in CFG5_GOLDEN:
+        def make5(b=b):
+            X, disp, kw, _ = cfg5_sample(b)
+            return X, disp, kw
+        cases.append(dict(name="cfg5_b%d" % b, make=make5, grad=True, big=True,
+                          dY=lambda b=b: cfg5_sample(b)[3],
+                          pick=lambda: ((slice(3, 128, 8), slice(5, 128, 8), slice(64, 128)),)))
     cases.append(dict(name="cfg4_multi", make=cfg4_inputs, grad=False, big=True,
                       pick=lambda: ((slice(None), slice(None, None, 4), slice(None, None, 4),
                                      slice(None, None, 2)),

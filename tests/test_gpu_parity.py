@@ -8,7 +8,9 @@ Tolerances (BASELINE.json north_star): float32 within 1e-5.  Default arithmetic 
 float64 volumes through the fast kernels (float64: 1e-11) and integer / bool volumes through the
 exact kernels (bit equality, incl. order-0 label resampling); with arithmetic 'exact' float64 and
 float32 outputs are compared for bit equality too.  Float gradients (atomics reorder the
-additions): 1e-5 (f32) / 1e-11 (f64), scaled by the transposed prefilter's gain where it applies.
+additions): float64 1e-10 / 1e-12; float32 1e-5 of the gradient's scale AND a measured bound
+against the exact (fp64) gradient -- no worse than 4x the reference's own float32 error
+(_f32_grad_check).
 """
 import os
 
@@ -53,15 +55,29 @@ SMALL = [c for c in C.all_cases() if not c["big"]]
 BIG = [c for c in C.all_cases() if c["big"]]
 
 
-def _f32_grad_check(g, w, kw, naxis):
-    """float32 gradients: the scatter's atomic additions round in a run-dependent order, and the
-    transposed prefilter amplifies those last-bit differences by its gain (up to ~3x per axis for
-    order 3, ~7.5x for order 5) -- in the reference's sequential float32 `+=` just as here.  Bound
-    relative to the gradient's scale, like the ragged-shape tests."""
-    order = kw.get("order", 3)
-    order = max(order) if isinstance(order, (list, tuple)) else order
-    amp = 8.0 ** naxis if (order > 1 and kw.get("prefilter", True)) else 1.0
-    np.testing.assert_allclose(g, w, rtol=1e-5, atol=1e-5 * max(1.0, amp * np.abs(w).max()))
+def _f32_grad_check(g, w, truth):
+    """float32 gradient `g` against the reference's float32 result `w` (golden vector / oracle) and
+    against `truth`, the same gradient in exact arithmetic (the fp64 oracle on the upcast dY: no
+    float32 rounding anywhere).  The reference accumulates `dX += (float)(dY * w)` sequentially in
+    float32 (deform.c:953-995) and rounds its transposed prefilter to float32 after every axis;
+    the GPU adds the same terms in another order.  Both are float32 evaluations of `truth`, so the
+    MEASURED bound is: the GPU result is no further from the exact gradient than 4x the
+    reference's own float32 error (+ 4 ulp of the gradient's scale), and it agrees with the
+    reference to 1e-5 of the gradient's scale (BASELINE.json north_star: 1e-5 fp32)."""
+    assert g.dtype == np.float32 and w.dtype == np.float32 and g.shape == w.shape == truth.shape
+    scale = max(1.0, float(np.abs(truth).max()))
+    err_ref = float(np.abs(w.astype(np.float64) - truth).max())
+    err_gpu = float(np.abs(g.astype(np.float64) - truth).max())
+    assert err_gpu <= 4.0 * err_ref + 4.0 * np.finfo(np.float32).eps * scale, (err_gpu, err_ref, scale)
+    np.testing.assert_allclose(g, w, rtol=1e-5, atol=1e-5 * scale)
+
+
+def _grad_truth(dY, disp, X, kw, case=None):
+    """Exact-arithmetic gradient for _f32_grad_check: the oracle on float64 copies of dY."""
+    up = [d.astype(np.float64) for d in dY] if isinstance(dY, list) else dY.astype(np.float64)
+    t = orc.deform_grid_gradient(up, disp, X_shape=C.x_shapes(X), **kw)
+    t = _aslist(t)
+    return _pick(case, t) if case is not None else t
 
 
 @pytest.fixture(autouse=True)
@@ -83,10 +99,12 @@ def test_forward_and_gradient_vs_golden(case, golden):
     if case["grad"]:
         dY = C.seeded_dY(case, out)
         grad = ed.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
-        for g, w in zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad")):
+        truth = None
+        for i, (g, w) in enumerate(zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad"))):
             assert g.dtype == w.dtype and g.shape == w.shape
             if w.dtype == np.float32:
-                _f32_grad_check(g, w, kw, disp.shape[0])
+                truth = truth or _grad_truth(dY, disp, X, kw, case)
+                _f32_grad_check(g, w, truth[i])
             else:
                 np.testing.assert_allclose(g, w, rtol=1e-10, atol=1e-10)
 
@@ -103,9 +121,11 @@ def test_exact_arithmetic_is_bit_equal(case, golden):
     if case["grad"]:
         dY = C.seeded_dY(case, out)
         grad = ed.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
-        for g, w in zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad")):
+        truth = None
+        for i, (g, w) in enumerate(zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad"))):
             if w.dtype == np.float32:
-                _f32_grad_check(g, w, kw, disp.shape[0])
+                truth = truth or _grad_truth(dY, disp, X, kw, case)
+                _f32_grad_check(g, w, truth[i])
             elif w.dtype == np.float64:
                 np.testing.assert_allclose(g, w, rtol=1e-12, atol=1e-12)
             else:
@@ -141,8 +161,9 @@ def test_baseline_configs_vs_golden(case, golden):
     if case["grad"]:
         dY = C.seeded_dY(case, out)
         grad = ed.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
-        for g, w in zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad")):
-            _f32_grad_check(g, w, kw, disp.shape[0])
+        truth = _grad_truth(dY, disp, X, kw, case)      # a few seconds of CPU at 128^3
+        for g, w, t in zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad"), truth):
+            _f32_grad_check(g, w, t)
 
 
 def test_cfg1_readme_example(golden):
@@ -190,15 +211,14 @@ def test_ragged_shapes_vs_oracle(shape, points, dtype):
                 gw = orc.deform_grid_gradient(dY, disp, prefilter=False, **kw)
                 gg = ed.deform_grid_gradient(dY, disp, prefilter=False, **kw)
                 np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * max(1.0, np.abs(gw).max()))
-                # with the transposed prefilter (K4, bit-exact on equal input) the order in which
-                # the scatter rounded its float sums is amplified by the filter's gain (up to
-                # ~3x per axis for order 3, ~7.5x for order 5) -- in the reference just as here,
-                # whose own float32 accumulation order is equally arbitrary.  Bound the error
-                # relative to the gradient's scale.
+                # with the transposed prefilter: float32 against the exact gradient, no worse than
+                # the reference's own float32 evaluation (see _f32_grad_check)
                 gw = orc.deform_grid_gradient(dY, disp, **kw)
                 gg = ed.deform_grid_gradient(dY, disp, **kw)
-                amp = 8.0 ** len(shape) if order > 1 else 1.0
-                np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * amp * np.abs(gw).max())
+                if dtype == np.float32:
+                    _f32_grad_check(gg, gw, orc.deform_grid_gradient(dY.astype(np.float64), disp, **kw))
+                else:
+                    np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * max(1.0, np.abs(gw).max()))
 
 
 def test_integer_gradient_is_bit_exact():
@@ -446,8 +466,11 @@ def test_crop_aware_prefilter_matches_whole_volume(mode, dtype):
             dY = rng.random(want.shape).astype(dtype)
             gw = orc.deform_grid_gradient(dY, disp, X_shape=X.shape, **kw)
             gg = ed.deform_grid_gradient(dY, disp, X_shape=X.shape, **kw)
-            eps = 1e-5 if dtype == np.float32 else 1e-10
-            np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * 8.0 ** naxis * np.abs(gw).max())
+            if dtype == np.float32:
+                _f32_grad_check(gg, gw, orc.deform_grid_gradient(dY.astype(np.float64), disp,
+                                                                 X_shape=X.shape, **kw))
+            else:
+                np.testing.assert_allclose(gg, gw, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(gw).max()))
         if mode in ("constant", "nearest"):
             assert all(engaged), engaged
         else:
@@ -611,14 +634,14 @@ def test_batch_api_equals_per_sample_calls():
         dY = rng.random(got.shape).astype(np.float32)
         gg = ed.deform_grid_gradient_batch(dY, D, X_shape=X.shape[1:], **kw)
         gl = np.stack([ed.deform_grid_gradient(dY[b], D[b], X_shape=X.shape[1:], **kw) for b in range(B)])
-        np.testing.assert_allclose(gg, gl, rtol=1e-5, atol=1e-5 * max(1.0, 64 * np.abs(gl).max()))
+        np.testing.assert_allclose(gg, gl, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(gl).max()))
         # CUDA tensors + autograd
         Xt = torch.from_numpy(X).to(dev).requires_grad_()
         Yt = et.deform_grid_batch(Xt, torch.from_numpy(D).to(dev), **kw)
         assert Yt.is_cuda
         np.testing.assert_array_equal(Yt.detach().cpu().numpy(), got)
         Yt.backward(torch.from_numpy(dY).to(dev))
-        np.testing.assert_allclose(Xt.grad.cpu().numpy(), gl, rtol=1e-5, atol=1e-5 * max(1.0, 64 * np.abs(gl).max()))
+        np.testing.assert_allclose(Xt.grad.cpu().numpy(), gl, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(gl).max()))
     # per-sample random grids drawn on the device
     Xb = torch.rand((6, 24, 26, 28), device=dev)
     g = torch.Generator(device=dev)
@@ -641,3 +664,73 @@ def test_release_scratch_then_reuse():
     np.testing.assert_array_equal(a, b)
     ed.release_scratch()
     ed.release_scratch()        # idempotent
+
+
+# ---- BASELINE.json cfg3 / cfg5 at their named sizes, through the paths the configs name ----------
+
+def test_cfg3_autograd_round_trip_at_size(golden):
+    """cfg3: 128^3 float32 forward + deform_grid_gradient as an autograd round trip through
+    elasticdeform.torch (the reference's import name, served by the alias package), CUDA tensors,
+    against the reference's golden outputs for the same seeds."""
+    import elasticdeform.torch as etorch
+    case = [c for c in C.all_cases() if c["name"] == "cfg3_128"][0]
+    X, disp, kw, dY = C.cfg3_inputs()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Xt = torch.from_numpy(X).to(dev).requires_grad_()
+    y = etorch.deform_grid(Xt, torch.from_numpy(disp).to(dev), **kw)
+    assert y.is_cuda and y.shape == Xt.shape
+    y.backward(torch.from_numpy(dY).to(dev))
+    pick = case["pick"]()[0]
+    np.testing.assert_allclose(y.detach().cpu().numpy()[pick], golden.outputs(case, "out")[0], **F32_TOL)
+    truth = _grad_truth(dY, disp, X, kw, case)[0]
+    _f32_grad_check(Xt.grad.cpu().numpy()[pick], golden.outputs(case, "grad")[0], truth)
+    # positional arguments, like the reference's tests call it (tests/test_deform_grid.py:75-78)
+    y2 = etorch.deform_grid(Xt.detach(), torch.from_numpy(disp).to(dev), 3, "mirror")
+    assert torch.equal(y2, y.detach())
+
+
+def test_cfg5_shard_batch_at_size(golden):
+    """cfg5: one GPU's shard of the 512-volume batch -- 64 volumes of 128^3 float32, one 5^3
+    control grid each -- forward + gradient through deform_grid_batch / deform_grid_gradient_batch.
+    Three samples against the reference's golden vectors, every sample against the per-sample
+    calls (bit-equal forward; the gradient's atomics reorder float32 additions)."""
+    B = C.CFG5_BATCH
+    dev = torch.device("cuda", torch.cuda.current_device())
+    X = np.empty((B, 128, 128, 128), dtype=np.float32)
+    D = np.empty((B, 3, 5, 5, 5))
+    dY = np.empty_like(X)
+    for b in range(B):
+        X[b], D[b], kw, dY[b] = C.cfg5_sample(b)
+    Xd, Dd, dYd = (torch.from_numpy(a).to(dev) for a in (X, D, dY))
+    out = ed.deform_grid_batch(Xd, Dd, **kw)
+    grad = ed.deform_grid_gradient_batch(dYd, Dd, **kw)
+    assert out.is_cuda and out.shape == Xd.shape and grad.shape == Xd.shape
+    for b in C.CFG5_GOLDEN:
+        case = [c for c in C.all_cases() if c["name"] == "cfg5_b%d" % b][0]
+        pick = case["pick"]()[0]
+        np.testing.assert_allclose(out[b].cpu().numpy()[pick], golden.outputs(case, "out")[0], **F32_TOL)
+        truth = _grad_truth(dY[b], D[b], X[b], kw, case)[0]
+        _f32_grad_check(grad[b].cpu().numpy()[pick], golden.outputs(case, "grad")[0], truth)
+    for b in range(B):
+        one = ed.deform_grid(Xd[b], Dd[b], **kw)
+        assert torch.equal(out[b], one), b
+        g1 = ed.deform_grid_gradient(dYd[b], Dd[b], **kw)
+        scale = max(1.0, float(g1.abs().max()))
+        assert float((grad[b] - g1).abs().max()) <= 1e-5 * scale, b
+
+
+def test_label_values_beyond_2_53_round_trip_like_the_reference():
+    """int64 / uint64 label maps, order 0: the reference takes every value through a double and its
+    clamping store (deform.c:863-887,906-919), which alters values beyond 2^53 and near the type's
+    limits.  The label kernel reproduces that round trip (bit-equal with the oracle)."""
+    rng = np.random.default_rng(64)
+    disp = rng.standard_normal((3, 3, 3, 3)) * 2
+    big = np.array([2**53 + 1, 2**60 + 3, 2**63 - 1, 2**62 + 12345, 7], dtype=np.int64)
+    Xi = big[rng.integers(0, len(big), (12, 14, 16))]
+    Xi[::2] *= -1
+    Xu = np.array([2**53 + 1, 2**64 - 1, 2**63 + 5, 2**60 + 9, 3], dtype=np.uint64)[rng.integers(0, 5, (12, 14, 16))]
+    for X in (Xi, Xu):
+        for mode in ("nearest", "mirror", "constant"):
+            want = orc.deform_grid(X, disp, order=0, mode=mode, cval=2.0)
+            got = ed.deform_grid(X, disp, order=0, mode=mode, cval=2.0)
+            np.testing.assert_array_equal(got, want)

@@ -163,3 +163,41 @@ def test_crop_window_logic():
     # even orders: floor(c + 0.5) - order // 2 .. + order
     plan2 = _host.Plan([X], disp, 2, 'constant', 0.0, (slice(80, 120),) * 3, [(1, 2, 3)], None, None, None)
     assert _host.source_box(plan2, 0, X.shape, [(70, 130)] * 3)[0] == (70 - 2, 130 + 2)
+
+
+def test_gradient_entry_points_validate_before_touching_the_device():
+    """deform_grid_gradient checks its arguments in the reference's order (deform_grid.py:246-266)
+    BEFORE any allocation: the reference's exception classes come out even where no GPU exists."""
+    import elasticdeform_amd as ed
+    dY = np.zeros((9, 11), dtype=np.float32)
+    with pytest.raises(AssertionError, match="Displacement matrix should be a numpy.ndarray"):
+        ed.deform_grid_gradient(dY, [[0.0]])
+    with pytest.raises(AssertionError, match="Displacement matrix should be a numpy.ndarray"):
+        ed.deform_grid_gradient(dY, None)
+    with pytest.raises(AssertionError, match="Number of dimensions of displacement"):
+        ed.deform_grid_gradient(dY, np.zeros((2, 3)))
+    with pytest.raises(AssertionError, match="order should be"):
+        ed.deform_grid_gradient(dY, np.zeros((2, 3, 3)), order=7)
+    with pytest.raises(ValueError, match="X_shape is required"):
+        ed.deform_grid_gradient(dY, np.zeros((2, 3, 3)), crop=(slice(0, 4), slice(0, 4)))
+    with pytest.raises(ValueError, match="X_shape does not match"):
+        ed.deform_grid_gradient(dY, np.zeros((2, 3, 3)), crop=(slice(0, 4), slice(0, 4)),
+                                X_shape=(9, 11))
+    with pytest.raises(RuntimeError, match="boundary mode not supported"):
+        ed.deform_grid_gradient(dY, np.zeros((2, 3, 3)), mode="bogus")
+    with pytest.raises(AssertionError):
+        ed.deform_grid_gradient_batch(np.zeros((2, 9, 11), np.float32), np.zeros((3, 2, 3, 3)))
+
+
+def test_reference_import_name_is_served_by_the_alias_package():
+    """`import elasticdeform` / `import elasticdeform.torch` (the reference's names,
+    /root/reference/elasticdeform/__init__.py:1, torch.py:33) resolve to this build."""
+    import elasticdeform
+    import elasticdeform_amd
+    assert elasticdeform.deform_grid is elasticdeform_amd.deform_grid
+    assert elasticdeform.deform_random_grid is elasticdeform_amd.deform_random_grid
+    assert elasticdeform.deform_grid_gradient is elasticdeform_amd.deform_grid_gradient
+    torch = pytest.importorskip("torch")  # noqa: F841
+    import elasticdeform.torch as etorch
+    import elasticdeform_amd.torch as etorch_amd
+    assert etorch.deform_grid is etorch_amd.deform_grid

@@ -1,0 +1,315 @@
+// dev tool: VALU issue cost and LDS access cost on MI355X (gfx950), per wave-instruction.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_issue.bin tools/ubench_issue.hip
+//   tools/ubench_issue.bin            -> every test; `tools/ubench_issue.bin lds` / `valu` selects a family
+// Each VALU test is an unrolled run of 64 independent instructions inside a loop; a block is 256
+// threads (one wave per SIMD), `occ` blocks per CU give occ waves per SIMD.  Reported: shader cycles
+// (s_memtime delta of one wave) per wave-instruction and per SIMD, i.e. the issue cost when occ waves
+// compete for one SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+enum {
+    V_FMA_F32, V_PK_FMA_F32, V_FMA_F64, V_ADD_F64, V_MUL_F64, V_FLOOR_F64, V_CVT_I32_F64, V_CVT_F32_F64,
+    V_CVT_F64_I32, V_CVT_I32_F32, V_ADD_U32, V_MUL_LO_U32, V_MOV_DPP, V_READLANE, V_CNDMASK, V_MIN_BCAST,
+    V_PK_MIN_I16, V_ADD_DPP, V_PK_MUL_F32, V_MAD_U32_U24, V_LSHL_ADD, V_FLOOR_F32, V_FRACT_F64, V_NTESTS
+};
+static const char* kNames[] = {
+    "v_fma_f32", "v_pk_fma_f32", "v_fma_f64", "v_add_f64", "v_mul_f64", "v_floor_f64", "v_cvt_i32_f64",
+    "v_cvt_f32_f64", "v_cvt_f64_i32", "v_cvt_i32_f32", "v_add_u32", "v_mul_lo_u32", "v_mov_b32 dpp",
+    "v_readlane_b32", "v_cndmask_b32", "v_min_i32 row_bcast15", "v_pk_min_i16", "v_add_u32 dpp row_shr1",
+    "v_pk_mul_f32", "v_mad_u32_u24", "v_lshl_add_u32", "v_floor_f32", "v_fract_f64"};
+
+template <int OP>
+__global__ __launch_bounds__(256) void valu_kernel(float* out, int iters, long long* cyc)
+{
+    float a = threadIdx.x * 1e-3f, b = 1.0001f, c = 0.5f;
+    double da = threadIdx.x * 1e-3, db = 1.0000001, dc = 0.25;
+    int ia = threadIdx.x, ib = 3;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 pa = {a, a}, pb = {b, b}, pc = {c, c};
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        if (OP == V_FMA_F32) { REP64(asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));) }
+        if (OP == V_PK_FMA_F32) { REP64(asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pa) : "v"(pb), "v"(pc));) }
+        if (OP == V_PK_MUL_F32) { REP64(asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(pa) : "v"(pb));) }
+        if (OP == V_FMA_F64) { REP64(asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(da) : "v"(db), "v"(dc));) }
+        if (OP == V_ADD_F64) { REP64(asm volatile("v_add_f64 %0, %1, %0" : "+v"(da) : "v"(db));) }
+        if (OP == V_MUL_F64) { REP64(asm volatile("v_mul_f64 %0, %1, %0" : "+v"(da) : "v"(db));) }
+        if (OP == V_FLOOR_F64) { REP64(asm volatile("v_floor_f64 %0, %0" : "+v"(da));) }
+        if (OP == V_FRACT_F64) { REP64(asm volatile("v_fract_f64 %0, %0" : "+v"(da));) }
+        if (OP == V_CVT_I32_F64) { REP64(asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(ia) : "v"(da));) }
+        if (OP == V_CVT_F32_F64) { REP64(asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a) : "v"(da));) }
+        if (OP == V_CVT_F64_I32) { REP64(asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(da) : "v"(ia));) }
+        if (OP == V_CVT_I32_F32) { REP64(asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(ia) : "v"(a));) }
+        if (OP == V_FLOOR_F32) { REP64(asm volatile("v_floor_f32 %0, %0" : "+v"(a));) }
+        if (OP == V_ADD_U32) { REP64(asm volatile("v_add_u32 %0, %1, %0" : "+v"(ia) : "v"(ib));) }
+        if (OP == V_MUL_LO_U32) { REP64(asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(ia) : "v"(ib));) }
+        if (OP == V_MAD_U32_U24) { REP64(asm volatile("v_mad_u32_u24 %0, %1, %1, %0" : "+v"(ia) : "v"(ib));) }
+        if (OP == V_LSHL_ADD) { REP64(asm volatile("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(ia) : "v"(ib));) }
+        if (OP == V_MOV_DPP) { REP64(asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(ia));) }
+        if (OP == V_ADD_DPP) { REP64(asm volatile("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(ia) : "v"(ib));) }
+        if (OP == V_READLANE) { int s; REP64(asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s) : "v"(ia));) ia += s; }
+        if (OP == V_CNDMASK) { REP64(asm volatile("v_cndmask_b32 %0, %1, %0, vcc" : "+v"(ia) : "v"(ib) : "vcc");) }
+        if (OP == V_MIN_BCAST) { REP64(asm volatile("v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(ia));) }
+        if (OP == V_PK_MIN_I16) { REP64(asm volatile("v_pk_min_i16 %0, %1, %0" : "+v"(ia) : "v"(ib));) }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        cyc[0] = t1 - t0;
+    float r = a + (float)da + (float)ia + pa.x + pa.y;
+    if (r == -1.2345f)
+        out[0] = r;
+}
+
+// ---- LDS ----------------------------------------------------------------------------------------
+enum {
+    L_READ_B64, L_READ_B64_MIS, L_READ2_B32_MIS, L_READ_B32, L_READ_B128, L_ADD_U32, L_ADD_U32_16OF64, L_ADD_U32_Q1,
+    L_ADD_RTN, L_ADD_K16, L_ADD_K32, L_ADD_SAME2, L_ADD_SAME4, L_ADD_STRIDE2, L_ADD_U32_FIRST16, L_READ_B64_RAND,
+    L_READ2_B64, L_READ_B64_X2, L_ADD_K16_64, L_ADD_K32_64, L_ADD_ROWS24, L_ADD_ROWS16, L_ADD_ROWS48, L_ADD_ROWS40,
+    L_READ_B64_2WAY, L_READ_B64_ROWS, L_WRITE_B128, L_NTESTS
+};
+static const char* kLNames[] = {
+    "ds_read_b64 aligned", "ds_read_b64 4B-misaligned", "ds_read2_b32 4B-aligned pair", "ds_read_b32", "ds_read_b128",
+    "ds_add_u32 64 lanes", "ds_add_u32 every 4th lane", "ds_add_u32 lanes 0-15 of each 64... (exec=1 quarter rows)",
+    "ds_add_rtn_u32", "ds_add_u32 groups of 16 lanes share banks", "ds_add_u32 groups of 32 lanes share banks",
+    "ds_add_u32 2 lanes per address", "ds_add_u32 4 lanes per address", "ds_add_u32 stride 2 dwords",
+    "ds_add_u32 lanes 0-15 only", "ds_read_b64 pseudo-random 8B slots",
+    "ds_read2_b64 (16 B per lane, one instr)", "2 x ds_read_b64 (16 B per lane, two instrs; per instr)",
+    "ds_add_u32 16-lane groups 64 dwords apart", "ds_add_u32 32-lane groups 64 dwords apart",
+    "ds_add_u32 4 rows of 16, pitch 24", "ds_add_u32 4 rows of 16, pitch 16", "ds_add_u32 4 rows of 16, pitch 48",
+    "ds_add_u32 4 rows of 16, pitch 40", "ds_read_b64 2-way bank conflict (lane, lane+16 same banks)",
+    "ds_read_b64 8 rows x 8 lanes pitch 16 dwords (K1 regular)", "ds_write_b128"};
+
+template <int OP>
+__global__ __launch_bounds__(256) void lds_kernel(float* out, int iters, long long* cyc)
+{
+    __shared__ __attribute__((aligned(16))) unsigned int s[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256)
+        s[i] = i;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned base = wave * 2048 * 4;        // byte address of the wave's 8 KiB
+    unsigned addr;
+    switch (OP) {
+    case L_READ_B64: addr = base + lane * 8; break;
+    case L_READ_B64_MIS: addr = base + lane * 8 + 4; break;
+    case L_READ2_B32_MIS: addr = base + lane * 8 + 4; break;
+    case L_READ_B32: addr = base + lane * 4; break;
+    case L_READ_B128: addr = base + lane * 16; break;
+    case L_ADD_K16: addr = base + ((lane & 15) + (lane >> 4) * 32) * 4; break;
+    case L_ADD_K32: addr = base + ((lane & 31) + (lane >> 5) * 32) * 4; break;
+    case L_ADD_SAME2: addr = base + (lane >> 1) * 4; break;
+    case L_ADD_SAME4: addr = base + (lane >> 2) * 4; break;
+    case L_ADD_STRIDE2: addr = base + lane * 8; break;
+    case L_READ_B64_RAND: addr = base + ((lane * 37 + 11) & 255) * 8; break;
+    case L_READ2_B64: addr = base + lane * 16; break;
+    case L_READ_B64_X2: addr = base + lane * 16; break;
+    case L_ADD_K16_64: addr = base + ((lane & 15) + (lane >> 4) * 64) * 4; break;
+    case L_ADD_K32_64: addr = base + ((lane & 31) + (lane >> 5) * 64) * 4; break;
+    case L_ADD_ROWS24: addr = base + ((lane & 15) + (lane >> 4) * 24) * 4; break;
+    case L_ADD_ROWS16: addr = base + ((lane & 15) + (lane >> 4) * 16) * 4; break;
+    case L_ADD_ROWS48: addr = base + ((lane & 15) + (lane >> 4) * 48) * 4; break;
+    case L_ADD_ROWS40: addr = base + ((lane & 15) + (lane >> 4) * 40) * 4; break;
+    case L_READ_B64_2WAY: addr = base + ((lane & 15) * 2 + (lane >> 4) * 64) * 4; break;
+    case L_READ_B64_ROWS: addr = base + ((lane & 7) * 2 + (lane >> 3) * 16) * 4; break;
+    case L_WRITE_B128: addr = base + lane * 16; break;
+    default: addr = base + lane * 4; break;
+    }
+    bool on = true;
+    if (OP == L_ADD_U32_16OF64) on = (lane & 3) == 0;
+    if (OP == L_ADD_U32_Q1 || OP == L_ADD_U32_FIRST16) on = lane < 16;
+    unsigned acc = 0;
+    unsigned long long acc64 = 0;
+    long long t0 = __builtin_readcyclecounter();
+    if (on) {
+        for (int it = 0; it < iters; ++it) {
+            if (OP == L_READ2_B64) {
+                typedef unsigned long long ul2 __attribute__((ext_vector_type(2)));
+                ul2 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v[k]) : "v"(addr), "n"(k * 32), "n"(k * 32 + 1));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    acc64 += v[k].x + v[k].y;
+            } else if (OP == L_WRITE_B128) {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                u4 val = {(unsigned)it, 1u, 2u, 3u};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(k * 1024) : "memory");
+            } else if (OP == L_READ_B64_X2) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[2 * k]) : "v"(addr), "n"(k * 1024));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[2 * k + 1]) : "v"(addr), "n"(k * 1024 + 8));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc64 += v[k];
+            } else if (OP == L_READ_B64 || OP == L_READ_B64_MIS || OP == L_READ_B64_RAND || OP == L_READ_B64_2WAY ||
+                       OP == L_READ_B64_ROWS) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[k]) : "v"(addr), "n"(k * 512));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc64 += v[k];
+            } else if (OP == L_READ2_B32_MIS) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v[k]) : "v"(addr), "n"(k * 2), "n"(k * 2 + 1));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc64 += v[k];
+            } else if (OP == L_READ_B32) {
+                unsigned v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[k]) : "v"(addr), "n"(k * 256));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc += v[k];
+            } else if (OP == L_READ_B128) {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                u4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[k]) : "v"(addr), "n"(k * 1024));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    acc += v[k].x + v[k].w;
+            } else if (OP == L_ADD_RTN) {
+                unsigned v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2 offset:%3" : "=v"(v[k]) : "v"(addr), "v"(acc), "n"(k * 256));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc += v[k];
+            } else {
+                const unsigned val = it;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(k * 512) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        cyc[0] = t1 - t0;
+    if (acc + (unsigned)acc64 == 0x12345u)
+        out[0] = (float)acc;
+}
+
+template <int OP>
+static int run_valu(float* out, long long* cyc, hipEvent_t a, hipEvent_t b)
+{
+    for (int occ : {1, 2, 4, 8}) {
+        const int iters = 4096;
+        float best = 1e9f;
+        long long c = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL(valu_kernel<OP>, dim3(256 * occ), dim3(256), 0, 0, out, iters, cyc);
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            if (ms < best) {
+                best = ms;
+                CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+            }
+        }
+        const double instr = (double)iters * 64;
+        printf("%-26s occ=%d  %8.3f ms  s_memtime/instr(one wave) %6.2f   ns per wave-instr per SIMD %6.3f\n",
+               kNames[OP], occ, best, (double)c / instr, best * 1e6 / (instr * occ));
+    }
+    return 0;
+}
+
+template <int OP>
+static int run_lds(float* out, long long* cyc, hipEvent_t a, hipEvent_t b)
+{
+    for (int occ : {1, 4}) {
+        const int iters = 2048;
+        float best = 1e9f;
+        long long c = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL(lds_kernel<OP>, dim3(256 * occ), dim3(256), 0, 0, out, iters, cyc);
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            if (ms < best) {
+                best = ms;
+                CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+            }
+        }
+        const int per_it = (OP == L_READ_B128 || OP == L_READ2_B64 || OP == L_WRITE_B128) ? 4 : 8;
+        const double instr_cu = (double)iters * per_it * 4 * occ;      // wave-instructions per CU
+        printf("%-58s waves/CU=%2d  %8.3f ms  ns per wave-instr per CU %6.3f  (x2.4 = %5.2f cycles)\n",
+               kLNames[OP], 4 * occ, best, best * 1e6 / instr_cu, best * 1e6 / instr_cu * 2.4);
+    }
+    return 0;
+}
+
+template <int OP>
+struct ValuAll {
+    static int go(float* o, long long* c, hipEvent_t a, hipEvent_t b)
+    {
+        if (run_valu<OP>(o, c, a, b)) return 1;
+        return ValuAll<OP + 1>::go(o, c, a, b);
+    }
+};
+template <>
+struct ValuAll<V_NTESTS> {
+    static int go(float*, long long*, hipEvent_t, hipEvent_t) { return 0; }
+};
+template <int OP>
+struct LdsAll {
+    static int go(float* o, long long* c, hipEvent_t a, hipEvent_t b)
+    {
+        if (run_lds<OP>(o, c, a, b)) return 1;
+        return LdsAll<OP + 1>::go(o, c, a, b);
+    }
+};
+template <>
+struct LdsAll<L_NTESTS> {
+    static int go(float*, long long*, hipEvent_t, hipEvent_t) { return 0; }
+};
+
+int main(int argc, char** argv)
+{
+    float* out;
+    long long* cyc;
+    CK(hipMalloc(&out, 4));
+    CK(hipMalloc(&cyc, 8));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    const bool all = argc < 2;
+    if (all || !strcmp(argv[1], "valu"))
+        if (ValuAll<0>::go(out, cyc, a, b)) return 1;
+    if (all || !strcmp(argv[1], "lds"))
+        if (LdsAll<0>::go(out, cyc, a, b)) return 1;
+    return 0;
+}
