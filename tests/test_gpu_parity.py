@@ -55,21 +55,27 @@ SMALL = [c for c in C.all_cases() if not c["big"]]
 BIG = [c for c in C.all_cases() if c["big"]]
 
 
-def _f32_grad_check(g, w, truth):
+def _f32_grad_check(g, w, truth, flat=True):
     """float32 gradient `g` against the reference's float32 result `w` (golden vector / oracle) and
     against `truth`, the same gradient in exact arithmetic (the fp64 oracle on the upcast dY: no
     float32 rounding anywhere).  The reference accumulates `dX += (float)(dY * w)` sequentially in
     float32 (deform.c:953-995) and rounds its transposed prefilter to float32 after every axis;
     the GPU adds the same terms in another order.  Both are float32 evaluations of `truth`, so the
     MEASURED bound is: the GPU result is no further from the exact gradient than 4x the
-    reference's own float32 error (+ 4 ulp of the gradient's scale), and it agrees with the
-    reference to 1e-5 of the gradient's scale (BASELINE.json north_star: 1e-5 fp32)."""
+    reference's own float32 error (+ 4 ulp of the gradient's scale).  With `flat` (every golden
+    case, the BASELINE configs, the crop cases) it must also agree with the reference to 1e-5 of
+    the gradient's scale (BASELINE.json north_star: 1e-5 fp32).  The ragged-shape sweep drops the
+    flat bound: there the REFERENCE's own float32 result is further than that from the exact
+    gradient (measured on the MI355X run of this suite: 2.8e-5 on a 2x2x2 volume, 2e-4 at scale 5.9
+    for order 5 in 4-D -- its per-axis float32 rounding of the transposed prefilter), so no
+    float32 implementation can be within 1e-5 of it except by copying its rounding order."""
     assert g.dtype == np.float32 and w.dtype == np.float32 and g.shape == w.shape == truth.shape
     scale = max(1.0, float(np.abs(truth).max()))
     err_ref = float(np.abs(w.astype(np.float64) - truth).max())
     err_gpu = float(np.abs(g.astype(np.float64) - truth).max())
     assert err_gpu <= 4.0 * err_ref + 4.0 * np.finfo(np.float32).eps * scale, (err_gpu, err_ref, scale)
-    np.testing.assert_allclose(g, w, rtol=1e-5, atol=1e-5 * scale)
+    if flat:
+        np.testing.assert_allclose(g, w, rtol=1e-5, atol=1e-5 * scale)
 
 
 def _grad_truth(dY, disp, X, kw, case=None):
@@ -216,7 +222,8 @@ def test_ragged_shapes_vs_oracle(shape, points, dtype):
                 gw = orc.deform_grid_gradient(dY, disp, **kw)
                 gg = ed.deform_grid_gradient(dY, disp, **kw)
                 if dtype == np.float32:
-                    _f32_grad_check(gg, gw, orc.deform_grid_gradient(dY.astype(np.float64), disp, **kw))
+                    _f32_grad_check(gg, gw, orc.deform_grid_gradient(dY.astype(np.float64), disp, **kw),
+                                    flat=False)
                 else:
                     np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * max(1.0, np.abs(gw).max()))
 
