@@ -1,0 +1,840 @@
+// deform_hot.hip -- K1 (forward gather) and K2 (gradient scatter-add) for the benchmark case: float32
+// volumes, 3 deformed axes, unit stride along x on both sides, spline orders 1-5.  Same algorithm and
+// LDS tiling as the general kernels of deform_tile.hip (which keep serving float64, strided layouts and
+// the tiles these kernels hand to the spill list), rebuilt around the instruction costs measured on
+// MI355X (profiles/r02_ubench_valu.txt): fp32 FMA / integer add issue in 2 cycles per wave, everything
+// else -- fp64, conversions, DPP, v_readlane, 3-operand integer ops -- in 4, so the per-voxel work is
+// cut where the 4-cycle instructions were:
+//
+//   * the kernel argument block is small (HotGeom) and the rarely used uniform values live in LDS:
+//     the general kernel kept ~100 SGPRs of arguments live and spilled them through v_writelane /
+//     v_readlane (a fifth of its VALU instructions);
+//   * coordinates: without an affine map floor / fraction are taken of the DISPLACEMENT alone and the
+//     output index is added as an integer (exact; three int->fp64 conversions and fp64 adds less per
+//     voxel); the boundary map stays one divergent region for the few lanes that leave the array;
+//   * Q rows are [control column][component padded to 4]: a voxel's 12 fp64 taps are 4 ds_read_b128 +
+//     4 ds_read_b64 off 4 addresses, which depend on the lane only (computed once per tile);
+//   * staging of interior tiles walks rows with incremental (z, y) counters instead of two divisions
+//     and two mirror maps per 16-byte chunk;
+//   * the gather is instantiated per row pitch, so the 16 row offsets of a voxel are immediates;
+//   * bounding-box reductions finish inside the wave with DPP row_bcast steps (no v_readlane).
+//
+// Reference: the per-voxel pipeline of DeformGrid, deform.c:649-1001 (see deform_tile.hip's header
+// for the phase-by-phase mapping).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "ed_device.h"
+#include "ed_params.h"
+#include "ed_tile.h"
+
+namespace ed {
+namespace tile {
+
+namespace {
+
+constexpr int kGradBoxBytes = 24 * 1024;       // K2: fixed-point cells per tile (4 workgroups per CU)
+
+// Bounding box of a wave's tap windows: min of lo[3], max of hi[3] over the 64 lanes with DPP only --
+// four row steps (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then
+// row_bcast:15 / row_bcast:31 carry the row results upwards so that lane 63 holds the wave's result;
+// that lane folds it into the tile's six LDS slots (ds_min_i32 x3, ds_max_i32 x3).  Hand-written:
+// the compiler turns every __builtin_amdgcn_update_dpp step into copy + s_nop + v_mov_dpp + v_min
+// (4 instructions instead of 1) and wraps the single-lane atomics in a wave-reduction loop -- together
+// ~200 instructions per wave and tile, a quarter of the kernel's VALU work.  The six chains are
+// interleaved, which also covers the DPP read-after-write hazard (2 wait states) without s_nop.
+// All 64 lanes must be active.
+#define ED_RED6(OP, CTRL)                                  \
+    "v_min_i32_dpp %0, %0, %0 " CTRL "\n\t"                \
+    "v_min_i32_dpp %1, %1, %1 " CTRL "\n\t"                \
+    "v_min_i32_dpp %2, %2, %2 " CTRL "\n\t"                \
+    "v_max_i32_dpp %3, %3, %3 " CTRL "\n\t"                \
+    "v_max_i32_dpp %4, %4, %4 " CTRL "\n\t"                \
+    "v_max_i32_dpp %5, %5, %5 " CTRL "\n\t"
+__device__ __forceinline__ void box_reduce_to_lds(int* red, int lane, int (&lo)[3], int (&hi)[3])
+{
+    asm volatile("s_nop 1\n\t"
+                 ED_RED6(, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 ED_RED6(, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 ED_RED6(, "row_half_mirror row_mask:0xf bank_mask:0xf")
+                 ED_RED6(, "row_mirror row_mask:0xf bank_mask:0xf")
+                 ED_RED6(, "row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 ED_RED6(, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
+    if (lane == 63) {
+        const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)red;
+        asm volatile("ds_min_i32 %0, %1\n\t"
+                     "ds_min_i32 %0, %2 offset:4\n\t"
+                     "ds_min_i32 %0, %3 offset:8\n\t"
+                     "ds_max_i32 %0, %4 offset:12\n\t"
+                     "ds_max_i32 %0, %5 offset:16\n\t"
+                     "ds_max_i32 %0, %6 offset:20"
+                     :
+                     : "v"(addr), "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2])
+                     : "memory");
+    }
+}
+#undef ED_RED6
+
+// ---- strip prologue: x table, Q rows, uniform parameters -> LDS ----------------------------------------
+struct HotStrip {
+    int tz, ty, tx0, ntile, sample;
+};
+
+__device__ __forceinline__ bool hot_strip(const HotGeom& hg, HotStrip& sp)
+{
+    // strips are dealt to the 8 XCDs in contiguous chunks (block b runs on XCD b % 8)
+    const int b = blockIdx.x;
+    const int per = (hg.total_strips + 7) >> 3;
+    int s = (b & 7) * per + (b >> 3);
+    if (s >= hg.total_strips)
+        return false;
+    sp.sample = s / hg.nstrips;
+    s -= sp.sample * hg.nstrips;
+    const int sx = s % hg.strips_x;
+    s /= hg.strips_x;
+    sp.ty = s % hg.tiles[1];
+    sp.tz = s / hg.tiles[1];
+    sp.tx0 = sx * hg.strip_tiles;
+    sp.ntile = min(hg.strip_tiles, hg.tiles[2] - sp.tx0);
+    return true;
+}
+
+__device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& sp, char* smem)
+{
+    const int tid = threadIdx.x;
+    int* sred = reinterpret_cast<int*>(smem + kOffRed);
+    {   // x table: 64 entries x 48 bytes = 768 dwords
+        const int* src = reinterpret_cast<const int*>(hg.xt + sp.tx0 * kT);
+        int* dst = reinterpret_cast<int*>(smem + kOffTabX);
+        const int avail = (hg.out_len[2] - sp.tx0 * kT) * 12;
+        for (int e = tid; e < kStrip * kT * 12; e += kBlock)
+            dst[e] = e < avail ? src[e] : 0;
+    }
+    {   // Q rows: (zi, yy) -> (oz, oy); 4 threads per row, 16 bytes at a time
+        const int row16 = 2 * hg.ncpx;                   // 16-byte pieces per row (32 bytes per column)
+        const int r = tid >> 2;
+        const int oz = min(sp.tz * kT + (r >> 3), hg.out_len[0] - 1);
+        const int oy = min(sp.ty * kT + (r & 7), hg.out_len[1] - 1);
+        const double2* src = reinterpret_cast<const double2*>(
+            hg.q + sp.sample * hg.q_bstride + ((long long)oz * hg.out_len[1] + oy) * (4 * hg.ncpx));
+        double2* dst = reinterpret_cast<double2*>(smem + kOffQ) + r * row16;
+        for (int k = tid & 3; k < row16; k += 4)
+            dst[k] = src[k];
+    }
+    if (tid < 24) {
+        const int k = tid & 7;
+        sred[tid] = k < 3 ? 0x7fffffff : (int)0x80000000;
+    }
+    if (tid >= 128 && tid < 128 + 12) {
+        HotParams* hp = reinterpret_cast<HotParams*>(smem + kOffHot);
+        const int k = tid - 128;
+        hp->affine[k] = hg.affine[k];
+        if (k < 3) {
+            hp->offd[k] = (double)hg.off[k];
+            hp->last[k] = (double)(hg.in_len[k] - 1);
+            hp->period[k] = hg.period[k];
+            hp->inv_period[k] = hg.inv_period[k];
+        }
+        if (k < 8) {
+            hp->step_len[k] = hg.step_len[k];
+            hp->in_step_stride[k] = hg.vol_step[k];
+            hp->out_step_stride[k] = hg.img_step[k];
+        }
+        if (k == 0)
+            hp->nstep = hg.nstep;
+    }
+    __syncthreads();
+}
+
+// Phase A for one voxel (deform.c:649-824): displacement from the lane's Q row, (affine), + offset,
+// window start and fractional offsets.  `b[h]` = output index + crop offset along axis h (no affine)
+// or 0 (affine: the real base is in `P`).  Returns true when the voxel maps to the constant.
+template <int ORDER, bool AFFINE>
+__device__ __forceinline__ bool hot_coords(const HotGeom& hg, const HotParams* hp, const char* qrow,
+                                           const double (&tw)[4], const int (&tib)[4], const int (&b)[3],
+                                           const double (&P)[3], int* start, float* frac)
+{
+    double d[3];
+    {
+        // 4 control columns x 3 components: ds_read_b128 (components 0, 1) + ds_read_b64 (2) per column
+        double2 q01[4];
+        double q2[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            q01[l] = *reinterpret_cast<const double2*>(qrow + tib[l]);
+            q2[l] = *reinterpret_cast<const double*>(qrow + tib[l] + 16);
+        }
+        d[0] = tw[0] * q01[0].x;
+        d[1] = tw[0] * q01[0].y;
+        d[2] = tw[0] * q2[0];
+#pragma unroll
+        for (int l = 1; l < 4; ++l) {
+            d[0] = fma(tw[l], q01[l].x, d[0]);
+            d[1] = fma(tw[l], q01[l].y, d[1]);
+            d[2] = fma(tw[l], q2[l], d[2]);
+        }
+    }
+    int ci[3];
+    bool inr[3];
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+        inr[h] = coord_axis_fast<ORDER, float>(AFFINE ? P[h] + d[h] : d[h], AFFINE ? 0 : b[h], hg.in_len[h],
+                                               ci[h], frac[h]);
+    bool cst = false;
+    if (!(inr[0] && inr[1] && inr[2])) {
+        // one divergent region: the axes along which the source point left the array
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            if (!inr[h])
+                cst = coord_axis_mapped<ORDER, float>(AFFINE ? P[h] + d[h] : (double)b[h] + d[h], hg.in_len[h],
+                                                      hg.mode, hp->period[h], hp->inv_period[h], ci[h],
+                                                      frac[h]) || cst;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+        start[h] = cst ? 0 : ci[h] - ORDER / 2;
+    return cst;
+}
+
+__device__ __forceinline__ void hot_step_offsets(const HotParams* hp, long long ss, long long& vol_off,
+                                                 long long& img_off)
+{
+    vol_off = 0;
+    img_off = 0;
+    long long r = ss;
+    const int nstep = hp->nstep;
+    for (int l = 0; l < nstep; ++l) {
+        const long long len = hp->step_len[l];
+        const long long q = r / len;
+        const long long c = r - q * len;
+        vol_off += hp->in_step_stride[l] * c;
+        img_off += hp->out_step_stride[l] * c;
+        r = q;
+    }
+}
+
+// 64-tap (order 3) separable gather of one voxel from the staged box; PITCH is a template argument so
+// that the row offsets are immediates.  `bp` points at tap (0, 0, 0) in the copy whose shift matches
+// the parity of the window's x start: every x-run is a sequence of aligned ds_read_b64.
+template <int ORDER, int PITCH, bool FENCE = false>
+__device__ __forceinline__ float hot_gather(const float* bp, int plane, const float* w0, const float* w1,
+                                            const float* w2)
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int NTX = NT + (NT & 1);
+    float a0 = 0.f;
+#pragma unroll
+    for (int l0 = 0; l0 < NT; ++l0) {
+        const float* pp = bp + l0 * plane;
+        float a1 = 0.f;
+#pragma unroll
+        for (int l1 = 0; l1 < NT; ++l1) {
+            const float* rp = pp + l1 * PITCH;
+            float a2 = 0.f;
+#pragma unroll
+            for (int l2 = 0; l2 < NTX; l2 += 2) {
+                const float2 pr = *reinterpret_cast<const float2*>(rp + l2);
+                if (FENCE)
+                    ED_NO_DS_MERGE();
+                a2 = fmaf(w2[l2], pr.x, a2);
+                a2 = fmaf(w2[l2 + 1], pr.y, a2);
+            }
+            a1 = fmaf(w1[l1], a2, a1);
+        }
+        a0 = fmaf(w0[l0], a1, a0);
+    }
+    return a0;
+}
+
+// ================================================================================================
+// K1: forward
+// ================================================================================================
+// async global -> LDS copy of 16 bytes per lane (LDS-DMA): the wave's 64 lanes fill 1 KiB of LDS
+// starting at the wave-uniform `lds`, in lane order; the global address is per lane.  No VGPR, no
+// ds_write, and the wave keeps running: the data is ordered for readers by s_waitcnt vmcnt + barrier.
+__device__ __forceinline__ void glds16(const float* g, float* lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// phases A + B of one tile for this lane's two voxels: coordinates, then the bounding box of the
+// tile's tap windows reduced into the LDS slots `red` (min x3, max x3)
+template <int ORDER, bool AFFINE, int ABL>
+__device__ __forceinline__ void hot_tile_coords(const HotGeom& hg, const HotParams* hp, const AxTab* tabx,
+                                                int* red, const char* const (&qrow)[2], const int (&oz)[2],
+                                                int oy, int ox0, int xx, int lane, const bool (&vzy)[2],
+                                                const double (&Pzy)[3][2], int (&start)[2][3],
+                                                float (&frac)[2][3], bool (&valid)[2], bool (&constant)[2])
+{
+    constexpr int kPadX = (ORDER + 1) & 1;
+    const int ox = ox0 + xx;
+    const bool vx = ox < hg.out_len[2];
+    double tw[4];
+    int tib[4];
+    {
+        const AxTab& t = tabx[xx];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            tw[l] = t.w[l];
+            tib[l] = t.idx[l] * 8;          // idx counts doubles of a Q row: byte offset
+        }
+    }
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b[3] = {oz[i] + hg.off[0], oy + hg.off[1], ox + hg.off[2]};
+        double P[3] = {0.0, 0.0, 0.0};
+        if (AFFINE) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h)
+                P[h] = fma(hp->affine[h * 4 + 2], (double)ox, Pzy[h][i]);
+        }
+        if (ABL & 4) {
+            constant[i] = false;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                start[i][h] = min(max(b[h] - 1, 0), hg.in_len[h] - 4);
+                frac[i][h] = 0.5f + (float)tw[0] * 1e-30f + (float)tib[0] * 1e-30f;
+            }
+        } else
+        constant[i] = hot_coords<ORDER, AFFINE>(hg, hp, qrow[i], tw, tib, b, P, start[i], frac[i]);
+        valid[i] = vzy[i] && vx;
+        if (valid[i] && !constant[i]) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                lo[h] = min(lo[h], start[i][h]);
+                hi[h] = max(hi[h], start[i][h] + ORDER + (h == 2 ? kPadX : 0));
+            }
+        }
+    }
+    if (!(ABL & 8))
+        box_reduce_to_lds(red, lane, lo, hi);
+}
+
+// ABL: compile-time ablation switches for profiling (0 in production; EDHIP_HOT_ABL selects one of
+// the instantiated values for order 3): 2 skip the gather, 4 skip the coordinates, 8 skip the
+// bounding-box reduction (analytic box), 32 skip staging, 64 skip the output store
+//
+// Tile loop, software-pipelined: once the box of tile t is known its staging copies are issued as
+// asynchronous LDS-DMA, and the coordinates + bounding box of tile t + 1 are computed while they are
+// in flight; the gather of tile t follows the barrier that retires the copies.
+template <int ORDER, bool AFFINE, int ABL = 0>
+__global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int kPadX = NT & 1;          // even orders read one zero-weight padding tap
+    constexpr int NTX = NT + kPadX;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    HotStrip sp;
+    if (!hot_strip(hg, sp))
+        return;
+    hot_prologue(hg, sp, smem);
+
+    const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
+    int* sred = reinterpret_cast<int*>(smem + kOffRed);
+    const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
+    float* box0 = reinterpret_cast<float*>(smem + hg.off_box);
+    float* box1 = box0 + hg.box_cap;      // cap = 56 (mod 64): the two copies sit on disjoint banks
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int yy = lane >> 3, xx = lane & 7;
+    const float* __restrict__ vol = hg.vol_r + sp.sample * hg.vol_bstride;
+    float* img = hg.img_w + sp.sample * hg.img_bstride;
+
+    // per-lane values that stay fixed along the strip
+    const int oy = sp.ty * kT + yy;
+    const char* qrow[2];
+    int oz[2], obase[2];
+    bool vzy[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int zi = wave + 4 * i;
+        oz[i] = sp.tz * kT + zi;
+        qrow[i] = smem + kOffQ + (zi * kT + yy) * (32 * hg.ncpx);
+        vzy[i] = oz[i] < hg.out_len[0] && oy < hg.out_len[1];
+        obase[i] = oz[i] * hg.img_sz + oy * hg.img_sy + sp.tx0 * kT + xx;
+    }
+    double Pzy[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};     // affine: A[h][0] oz + A[h][1] oy + A[h][3] + off_h
+    if (AFFINE) {
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                Pzy[h][i] = fma(hp->affine[h * 4 + 0], (double)oz[i],
+                                fma(hp->affine[h * 4 + 1], (double)oy, hp->affine[h * 4 + 3] + hp->offd[h]));
+    }
+
+    int start[2][3];
+    float frac[2][3];
+    bool valid[2], constant[2];
+    hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx, sred, qrow, oz, oy, sp.tx0 * kT, xx, lane, vzy, Pzy,
+                                        start, frac, valid, constant);
+
+    for (int ti = 0; ti < sp.ntile; ++ti) {
+        int* red = sred + (ti % 3) * 8;
+        __syncthreads();   // B1: box known; every gather of the previous tile is done
+        int b0[3] = {red[0], red[1], red[2]};
+        int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
+        bool any = red[3] >= red[0];
+        if (ABL & 8) {        // (only meaningful together with ABL & 4: identity coordinates)
+            any = true;
+            b0[0] = min(max(sp.tz * kT + hg.off[0] - 1, 0), hg.in_len[0] - 4);
+            b0[1] = min(max(sp.ty * kT + hg.off[1] - 1, 0), hg.in_len[1] - 4);
+            b0[2] = min(max((sp.tx0 + ti) * kT + hg.off[2] - 1, 0), hg.in_len[2] - 4);
+            ext[0] = ext[1] = ext[2] = kT + 3;
+        }
+        // re-arm the buffer of tile ti + 2 (three buffers in rotation: tile ti + 1 reduces into its
+        // buffer during this iteration, tile ti's is being read)
+        if (tid < 6)
+            sred[((ti + 2) % 3) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
+        // row pitch 16 * odd: four consecutive rows sit on four disjoint groups of 16 banks
+        const int pitch = ext[2] <= 16 ? 16 : (ext[2] <= 48 ? 48 : 0);
+        // (ABL & 256: rows per plane padded to a multiple of 4, so that the bank of a tap depends on
+        // its (row mod 4, x) only -- 14 % fewer bank-conflict cycles, 8 us faster, but more tiles
+        // overflow the box and the call as a whole loses: not used)
+        const int by = (ABL & 256) ? (ext[1] + 3) & ~3 : ext[1];
+        const int nrows = ext[0] * by;
+        const bool fits = pitch > 0 && nrows * pitch <= hg.box_cap;
+        const bool staged = any && fits;
+        if (any && !fits && tid == 0) {    // hand the whole tile to the general kernels
+            const int slot = atomicAdd(&hg.spill[0], 1);
+            hg.spill[1 + slot] = sp.sample * hg.ntiles +
+                                 (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti;
+        }
+        // the box and the padded row behind it lie inside the volume: no mirror map while staging
+        const bool interior = b0[0] >= 0 && b0[0] + ext[0] <= hg.in_len[0] && b0[1] >= 0 &&
+                              b0[1] + ext[1] <= hg.in_len[1] && b0[2] >= 0 &&
+                              b0[2] + pitch + 1 <= hg.in_len[2];
+        const bool x_inside = b0[2] >= 0 && b0[2] + ext[2] <= hg.in_len[2];
+
+        // ---- phase C: stage the source box into LDS (two copies, the second shifted by one) ----------
+        auto stage = [&](const float* src) {
+            if (interior) {
+                // LDS-DMA: one wave-instruction fills 1 KiB = RW consecutive box rows (16 rows of 64
+                // bytes, or 5 rows of 192 bytes with lanes 60-63 idle); lane -> (row, 16-byte chunk)
+                const int cpr = pitch >> 2;
+                const int RW = pitch == 16 ? 16 : 5;
+                const int lrow = pitch == 16 ? lane >> 2 : (lane * 21846) >> 18;      // lane / 12
+                const int q = lane - lrow * cpr;
+                const float inv_by = 1.0f / (float)by;
+                for (int r0 = wave * RW; r0 < nrows; r0 += 4 * RW) {
+                    const int r = r0 + lrow;
+                    const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                    if (lrow < RW && r < nrows && yr < ext[1]) {
+                        const float* g = src + ((b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2] + 4 * q);
+                        glds16(g, box0 + r0 * pitch);
+                        glds16(g + 1, box1 + r0 * pitch);
+                    }
+                }
+            } else {
+                // edge tile: every box index goes through the mirror map, as the reference does
+                // with the taps of a window that sticks out (deform.c:791-813)
+                const float inv_by = 1.0f / (float)by;
+                const int sub = tid & 7;
+                for (int r = tid >> 3; r < nrows; r += kBlock / 8) {
+                    const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                    if (yr >= ext[1])
+                        continue;            // padding row of the plane
+                    const int zs = mirror_i32(b0[0] + zr, hg.in_len[0]);
+                    const int ys = mirror_i32(b0[1] + yr, hg.in_len[1]);
+                    const float* rowp = src + (zs * hg.vol_sz + ys * hg.vol_sy);
+                    float* d0 = box0 + r * pitch;
+                    float* d1 = box1 + r * pitch;
+                    for (int xi = sub; xi < ext[2]; xi += 8) {
+                        const int xs = x_inside ? b0[2] + xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
+                        const float val = rowp[xs];
+                        d0[xi] = val;
+                        if (xi > 0)
+                            d1[xi - 1] = val;
+                    }
+                }
+            }
+        };
+        long long vol_off = 0, img_off = 0;
+        if (hg.nstep)
+            hot_step_offsets(hp, 0, vol_off, img_off);
+        if (staged && !(ABL & 32))
+            stage(vol + vol_off);
+
+        // ---- phases A + B of the NEXT tile, while the copies are in flight ------------------------
+        int nstart[2][3];
+        float nfrac[2][3];
+        bool nvalid[2] = {false, false}, nconstant[2] = {false, false};
+        if (ti + 1 < sp.ntile)
+            hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx + (ti + 1) * kT, sred + ((ti + 1) % 3) * 8, qrow, oz,
+                                                oy, (sp.tx0 + ti + 1) * kT, xx, lane, vzy, Pzy, nstart, nfrac,
+                                                nvalid, nconstant);
+
+        if (!(any && !fits)) {
+            for (long long ss = 0; ss < hg.nsteps; ++ss) {
+                if (ss > 0) {
+                    hot_step_offsets(hp, ss, vol_off, img_off);
+                    if (staged && !(ABL & 32)) {
+                        __syncthreads();     // previous step's gathers are done with the box
+                        stage(vol + vol_off);
+                    }
+                }
+                if (staged && !(ABL & 32))
+                    __syncthreads();         // B2: retires this wave's copies (vmcnt) and everyone's
+
+                // ---- phase D: gather -------------------------------------------------------------
+                const int plane = by * pitch;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (!valid[i])
+                        continue;
+                    float val;
+                    if (constant[i]) {
+                        val = hg.cval;
+                    } else if (ABL & 2) {
+                        val = frac[i][0] + frac[i][1] + frac[i][2] + (float)start[i][0] + (float)start[i][1] + (float)start[i][2];
+                    } else {
+                        float w0[NT], w1[NT], w2[NTX];
+                        weights_from_frac<float, ORDER>(frac[i][0], w0);
+                        weights_from_frac<float, ORDER>(frac[i][1], w1);
+                        weights_from_frac<float, ORDER>(frac[i][2], w2);
+                        if (kPadX)
+                            w2[NT] = 0.f;
+                        const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1], rx = start[i][2] - b0[2];
+                        // aligned pairs from the copy whose shift matches the parity of rx
+                        const float* bp = ((rx & 1) ? box1 - 1 : box0) + ((rz * by + ry) * pitch + rx);
+                        val = pitch == 16 ? hot_gather<ORDER, 16, (ABL & 128) != 0>(bp, plane, w0, w1, w2)
+                                          : hot_gather<ORDER, 48, (ABL & 128) != 0>(bp, plane, w0, w1, w2);
+                    }
+                    // streaming store (a tile writes 32-byte row segments; see deform_tile.hip)
+                    if (!(ABL & 64) || val == -12345.678f)
+                        __builtin_nontemporal_store(val, img + (img_off + obase[i] + ti * kT));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            valid[i] = nvalid[i];
+            constant[i] = nconstant[i];
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                start[i][h] = nstart[i][h];
+                frac[i][h] = nfrac[i][h];
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// K2: gradient.  Tiles of 8 (z) x 8 (y) x 16 (x) voxels, four voxels per lane; taps are scattered
+// into fixed-point LDS cells with integer atomics and flushed with one float atomic per touched
+// source element (see deform_tile.hip for the scale's no-overflow bound).
+// ================================================================================================
+template <int ORDER, bool AFFINE, int GRAD_WAVES>
+__global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotGeom hg)
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int TX = 16, NV = 4, ZSTEP = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    HotStrip sp;
+    if (!hot_strip(hg, sp))
+        return;
+    hot_prologue(hg, sp, smem);
+
+    const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
+    int* sred = reinterpret_cast<int*>(smem + kOffRed);
+    const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
+    int* box = reinterpret_cast<int*>(smem + hg.off_box);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xx = tid & 15, yy = (tid >> 4) & 7, zq = tid >> 7;
+    const int ntile = (sp.ntile * kT + TX - 1) / TX;
+    float* dx = hg.vol_w + sp.sample * hg.vol_bstride;
+    const float* __restrict__ dy = hg.img_r + sp.sample * hg.img_bstride;
+
+    const int oy = sp.ty * kT + yy;
+    const char* qrow0 = smem + kOffQ + (zq * kT + yy) * (32 * hg.ncpx);      // voxel i: + i * ZSTEP rows of 8
+    const int qstep = ZSTEP * kT * 32 * hg.ncpx;
+    const int oz0 = sp.tz * kT + zq;
+    const bool vy = oy < hg.out_len[1];
+    int phase = 0;
+
+    for (int ti = 0; ti < ntile; ++ti) {
+        int* red = sred + (ti % 3) * 8;
+        const int ox = sp.tx0 * kT + ti * TX + xx;
+        const bool vx = ox < hg.out_len[2];
+
+        double tw[4];
+        int tib[4];
+        {
+            const AxTab& t = tabx[ti * TX + xx];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                tw[l] = t.w[l];
+                tib[l] = t.idx[l] * 8;
+            }
+        }
+        double Pxy[3] = {0.0, 0.0, 0.0};      // affine: A[h][1] oy + A[h][2] ox + A[h][3] + off_h
+        if (AFFINE) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h)
+                Pxy[h] = fma(hp->affine[h * 4 + 2], (double)ox,
+                             fma(hp->affine[h * 4 + 1], (double)oy, hp->affine[h * 4 + 3] + hp->offd[h]));
+        }
+        int start[NV][3];
+        float frac[NV][3];
+        bool active[NV];
+        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int oz = oz0 + ZSTEP * i;
+            const int b[3] = {oz + hg.off[0], oy + hg.off[1], ox + hg.off[2]};
+            double P[3] = {0.0, 0.0, 0.0};
+            if (AFFINE) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h)
+                    P[h] = fma(hp->affine[h * 4 + 0], (double)oz, Pxy[h]);
+            }
+            const bool cst = hot_coords<ORDER, AFFINE>(hg, hp, qrow0 + i * qstep, tw, tib, b, P, start[i], frac[i]);
+            active[i] = vy && vx && oz < hg.out_len[0] && !cst;     // constant voxels contribute nothing (:928)
+            if (active[i]) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    lo[h] = min(lo[h], start[i][h]);
+                    hi[h] = max(hi[h], start[i][h] + ORDER);
+                }
+            }
+        }
+        box_reduce_to_lds(red, lane, lo, hi);
+        __syncthreads();   // B1: box known; the previous tile's flush is done
+        const int b0[3] = {red[0], red[1], red[2]};
+        const int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
+        const bool any = red[3] >= red[0];
+        if (tid < 6)
+            sred[((ti + 2) % 3) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
+        if (!any)
+            continue;      // nothing to scatter (uniform)
+        // 16 lanes of a row hit 16 consecutive cells; pitch 8 * odd keeps neighbouring rows apart
+        const int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
+        const int by = ext[1];
+        const int nrows = ext[0] * by;
+        const int nbox = nrows * pitch;
+        if (pitch == 0 || nbox > hg.box_cap) {
+            if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < hg.tiles[2]) {
+                const int slot = atomicAdd(&hg.spill[0], 1);
+                hg.spill[1 + slot] = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] +
+                                     sp.tx0 + ti * (TX / kT) + tid;
+            }
+            continue;
+        }
+        const bool interior = b0[0] >= 0 && b0[0] + ext[0] <= hg.in_len[0] && b0[1] >= 0 &&
+                              b0[1] + ext[1] <= hg.in_len[1] && b0[2] >= 0 && b0[2] + ext[2] <= hg.in_len[2];
+        int ooff[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            ooff[i] = (oz0 + ZSTEP * i) * hg.img_sz + oy * hg.img_sy + ox;
+
+        for (long long ss = 0; ss < hg.nsteps; ++ss, ++phase) {
+            long long vol_off = 0, img_off = 0;
+            if (hg.nstep)
+                hot_step_offsets(hp, ss, vol_off, img_off);
+            if (ss > 0)
+                __syncthreads();         // previous step's flush is done with the box
+            // zero the accumulators
+            for (int e = tid * 4; e < nbox; e += kBlock * 4)
+                *reinterpret_cast<int4*>(box + e) = make_int4(0, 0, 0, 0);
+            float gval[NV];
+            float gm = 0.f;
+            float* dst = dx + vol_off;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                gval[i] = active[i] ? dy[img_off + ooff[i]] : 0.f;
+                if ((__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000) {
+                    // inf / NaN gradient: no fixed-point scale exists -- this voxel scatters its
+                    // taps with float atomics straight to global memory (rare, rolled loops)
+                    float w0[NT], w1[NT], w2[NT];
+                    weights_from_frac<float, ORDER>(frac[i][0], w0);
+                    weights_from_frac<float, ORDER>(frac[i][1], w1);
+                    weights_from_frac<float, ORDER>(frac[i][2], w2);
+#pragma unroll 1
+                    for (int t = 0; t < NT * NT * NT; ++t) {
+                        const int l0 = t / (NT * NT), l1 = (t / NT) % NT, l2 = t % NT;
+                        const int zs = mirror_i32(start[i][0] + l0, hg.in_len[0]);
+                        const int ys = mirror_i32(start[i][1] + l1, hg.in_len[1]);
+                        const int xs = mirror_i32(start[i][2] + l2, hg.in_len[2]);
+                        float wp = w0[0], wq = w1[0], wr = w2[0];
+#pragma unroll
+                        for (int l = 1; l < NT; ++l) {
+                            wp = l0 == l ? w0[l] : wp;
+                            wq = l1 == l ? w1[l] : wq;
+                            wr = l2 == l ? w2[l] : wr;
+                        }
+                        unsafeAtomicAdd(dst + (zs * hg.vol_sz + ys * hg.vol_sy + xs), gval[i] * wp * wq * wr);
+                    }
+                    gval[i] = 0.f;
+                }
+                gm += fabsf(gval[i]);
+            }
+            gm = wave_sum(gm);
+            float* gsum = reinterpret_cast<float*>(smem + kOffSum) + (phase & 1) * 4;
+            if (lane == 0)
+                gsum[wave] = gm;
+            __syncthreads();             // B2: box zeroed, sum known
+            const float gtot = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
+            if (gtot == 0.f)
+                continue;                // all-zero gradient tile (uniform)
+            // |sum in a cell| <= max tap weight * sum over the tile of |dY|: this scale cannot overflow
+            constexpr double kWmax = ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : (ORDER == 3 ? 0.2963
+                                    : (ORDER == 4 ? 0.2150 : 0.1664));
+            const float scale = (float)((2147483648.0 - 1024.0) / (kWmax * 1.001 * (double)gtot));
+            const float inv_scale = 1.f / scale;
+
+#pragma unroll 2
+            for (int i = 0; i < NV; ++i) {
+                int st0 = start[0][0], st1 = start[0][1], st2 = start[0][2];
+                float f0 = frac[0][0], f1 = frac[0][1], f2 = frac[0][2], gv = gval[0];
+                bool act = active[0];
+#pragma unroll
+                for (int k = 1; k < NV; ++k) {
+                    const bool sel = i == k;
+                    st0 = sel ? start[k][0] : st0;
+                    st1 = sel ? start[k][1] : st1;
+                    st2 = sel ? start[k][2] : st2;
+                    f0 = sel ? frac[k][0] : f0;
+                    f1 = sel ? frac[k][1] : f1;
+                    f2 = sel ? frac[k][2] : f2;
+                    gv = sel ? gval[k] : gv;
+                    act = sel ? active[k] : act;
+                }
+                if (!act || gv == 0.f)
+                    continue;
+                float w0[NT], w1[NT], w2[NT];
+                weights_from_frac<float, ORDER>(f0, w0);
+                weights_from_frac<float, ORDER>(f1, w1);
+                weights_from_frac<float, ORDER>(f2, w2);
+                const int rz = st0 - b0[0], ry = st1 - b0[1], rx = st2 - b0[2];
+                int* bp = box + (rz * by + ry) * pitch + rx;
+                const float gs = gv * scale;
+#pragma unroll
+                for (int l0 = 0; l0 < NT; ++l0) {
+                    const float g0 = gs * w0[l0];
+#pragma unroll
+                    for (int l1 = 0; l1 < NT; ++l1) {
+                        const float g1 = g0 * w1[l1];
+                        int* rp = bp + (l0 * by + l1) * pitch;
+#pragma unroll
+                        for (int l2 = 0; l2 < NT; ++l2)
+                            atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)__float2int_rn(g1 * w2[l2]));
+                    }
+                }
+            }
+            __syncthreads();             // B3: all contributions are in
+            // flush: half a wave per box row, lanes along x -- one float atomic per touched source
+            // element, runs of consecutive addresses (deform.c:791-813: mirror-mapped at the edges)
+            {
+                const int sub = tid & 31;
+                const int rslot = tid >> 5;                    // 8 rows per pass
+                const int dz = 8 / by, dyy = 8 - dz * by;      // uniform
+                int zr = (int)(((float)rslot + 0.5f) / (float)by), yr = rslot - zr * by;
+                while (zr < ext[0]) {
+                    const int* row = box + (zr * by + yr) * pitch;
+                    int rowoff;
+                    if (interior)
+                        rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
+                    else
+                        rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
+                                 mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+                    for (int xi = sub; xi < ext[2]; xi += 32) {
+                        const int acc = row[xi];
+                        if (acc != 0) {
+                            const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
+                            unsafeAtomicAdd(dst + (rowoff + xs), (float)acc * inv_scale);
+                        }
+                    }
+                    zr += dz;
+                    yr += dyy;
+                    if (yr >= by) {
+                        yr -= by;
+                        zr += 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int ORDER>
+hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t lds, hipStream_t stream)
+{
+    if (gradient) {
+        if (hg.has_affine)
+            hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 3>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+        else if (getenv("EDHIP_GRAD_W4"))
+            hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+        else
+            hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 3>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+    } else {
+        if (hg.has_affine)
+            hipLaunchKernelGGL((hot_fwd_kernel<ORDER, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+        else if (ORDER == 3 && getenv("EDHIP_HOT_ABL")) {
+            if constexpr (ORDER == 3) {
+                switch (atoi(getenv("EDHIP_HOT_ABL"))) {
+#define ED_ABL_CASE(A) case A: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, A>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
+                ED_ABL_CASE(256) ED_ABL_CASE(258) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
+#undef ED_ABL_CASE
+                default: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
+                }
+            }
+        } else
+            hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// LDS: x table | reduction slots | wave sums | parameters | 64 Q rows | box.  Returns 0 when the
+// control grid is too wide for a useful box (the general kernels take the call).
+size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box)
+{
+    const size_t q = (size_t)kT * kT * 32 * (size_t)ncpx;
+    const size_t off = (kOffQ + q + 15) & ~(size_t)15;
+    *off_box = (int)off;
+    if (gradient) {
+        *box_cap = kGradBoxBytes / 4;
+        const size_t total = off + kGradBoxBytes;
+        return total <= 64 * 1024 ? total : 0;
+    }
+    // forward: two shifted float copies; 4 workgroups per CU -> 40960 bytes each (wide control
+    // grids: a 64 KiB block, fewer workgroups per CU)
+    size_t budget = 40 * 1024;
+    if (off + 2 * 4 * 2488 > budget)
+        budget = 64 * 1024;
+    if (off + 2 * 4 * 2488 > budget)
+        return 0;
+    size_t cap = (budget - off) / 8;
+    cap = ((cap - 56) / 64) * 64 + 56;        // cap = 56 (mod 64): the copies sit on disjoint banks
+    *box_cap = (int)cap;
+    return off + 2 * 4 * cap;
+}
+
+hipError_t launch_hot_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds,
+                             hipStream_t stream)
+{
+    switch (order) {
+    case 1: return launch_order<1>(hg, gradient, nblk, lds, stream);
+    case 2: return launch_order<2>(hg, gradient, nblk, lds, stream);
+    case 3: return launch_order<3>(hg, gradient, nblk, lds, stream);
+    case 4: return launch_order<4>(hg, gradient, nblk, lds, stream);
+    case 5: return launch_order<5>(hg, gradient, nblk, lds, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
+}  // namespace tile
+}  // namespace ed

@@ -6,7 +6,7 @@
 //
 //   tables   (tile_tables_kernel, once per call) the displacement spline is a tensor product
 //            (deform.c:639-758), so it is contracted over z and y once per call, in fp64:
-//            Q[o_z][o_y][c][k_x] = sum w_z w_y D_f, plus the x-table XT[o_x] (cubic weights and
+//            Q[o_z][o_y][k_x][c] = sum w_z w_y D_f, plus the x-table XT[o_x] (cubic weights and
 //            mirror-mapped control indices -- the reference's `dsplvals`).  A voxel is left with 4
 //            x-taps per component: 12 fp64 FMAs instead of the reference's 192 multiply-adds.
 //   strip    a 256-thread workgroup (4 waves) owns a strip of up to 8 tiles along x (4 / 2 for small
@@ -44,309 +44,26 @@
 #include <atomic>
 #include <type_traits>
 #include <cstdlib>
+#include <cstring>
 
 #include "ed_device.h"
 #include "ed_exact_coord.h"
 #include "ed_params.h"
 #include "ed_workspace.h"
+#include "ed_tile.h"
 
 namespace ed {
 
 namespace {
 
-constexpr int kT = 8;                 // tile edge
-constexpr int kStrip = 8;             // tiles per strip (along x)
-constexpr int kBlock = 256;
-
-struct AxTab {
-    double w[4];
-    int idx[4];
-};
-
-// 16 bytes at 4-byte alignment: compiles to one global_load_dwordx4 (unaligned access is on)
-struct __attribute__((packed, aligned(4))) F4u {
-    float x, y, z, w;
-};
-static_assert(sizeof(AxTab) == 48, "AxTab layout");
-
-// LDS carve (bytes)
-constexpr int kOffTabX = 0;                               // [kStrip][8] AxTab
-constexpr int kOffRed = kOffTabX + kStrip * kT * 48;      // int[3][8]: lo[3], hi[3], -, - (triple-buffered)
-constexpr int kOffSum = kOffRed + 96;                     // float[2][4]: per-wave sum |dY| (K2)
-constexpr int kOffHot = kOffSum + 32;                     // HotParams (uniform values kept out of SGPRs)
-constexpr int kOffQ = kOffHot + 416;
-static_assert(kOffQ % 16 == 0, "LDS carve alignment");
-
-// Uniform per-call values the per-voxel code needs.  Kept in LDS and fetched with broadcast reads:
-// as kernel arguments they would be hoisted into ~100 scalar registers, live across the whole tile
-// loop, and the spill reloads (v_readlane) were a third of the kernel's VALU work.
-struct HotParams {
-    double offd[3];        // crop offset per axis
-    double last[3];        // I_k - 1
-    double period[3];      // boundary-map period for the input's mode, and its reciprocal
-    double inv_period[3];
-    double affine[12];     // inverse map, 3 x 4
-    long long step_len[8];
-    long long in_step_stride[8];
-    long long out_step_stride[8];
-    int nstep;
-    int pad_;
-};
-static_assert(sizeof(HotParams) <= 416, "HotParams must fit its LDS slot");
-
-__device__ __forceinline__ int mirror_i32(int idx, int len)
-{
-    if ((unsigned)idx < (unsigned)len)
-        return idx;                       // in range: the common case
-    if (len <= 1)
-        return 0;
-    if (idx < 0 && idx > -len)
-        return -idx;                      // one reflection at the low end
-    if (idx >= len && idx <= 2 * len - 2)
-        return 2 * len - 2 - idx;         // one reflection at the high end
-    const int period = 2 * len - 2;
-    if (idx < 0) {
-        idx = period * (-idx / period) + idx;
-        idx = idx <= 1 - len ? idx + period : -idx;
-    } else {
-        idx -= period * (idx / period);
-        if (idx >= len)
-            idx = period - idx;
-    }
-    return idx;
-}
-
-// Wave-wide min / max / sum without touching LDS: four DPP steps fold each row of 16 lanes
-// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row
-// results meet in scalar registers.  All 64 lanes must be active.
-#define ED_DPP_STEP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
-__device__ __forceinline__ int wave_min(int v)
-{
-    v = min(v, ED_DPP_STEP(v, 0xB1));
-    v = min(v, ED_DPP_STEP(v, 0x4E));
-    v = min(v, ED_DPP_STEP(v, 0x141));
-    v = min(v, ED_DPP_STEP(v, 0x140));
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ int wave_max(int v)
-{
-    v = max(v, ED_DPP_STEP(v, 0xB1));
-    v = max(v, ED_DPP_STEP(v, 0x4E));
-    v = max(v, ED_DPP_STEP(v, 0x141));
-    v = max(v, ED_DPP_STEP(v, 0x140));
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ float wave_sum(float f)
-{
-    f += __int_as_float(ED_DPP_STEP(__float_as_int(f), 0xB1));
-    f += __int_as_float(ED_DPP_STEP(__float_as_int(f), 0x4E));
-    f += __int_as_float(ED_DPP_STEP(__float_as_int(f), 0x141));
-    f += __int_as_float(ED_DPP_STEP(__float_as_int(f), 0x140));
-    const int v = __float_as_int(f);
-    return (__int_as_float(__builtin_amdgcn_readlane(v, 0)) +
-            __int_as_float(__builtin_amdgcn_readlane(v, 16))) +
-           (__int_as_float(__builtin_amdgcn_readlane(v, 32)) +
-            __int_as_float(__builtin_amdgcn_readlane(v, 48)));
-}
-
-// Boundary map of a real coordinate for the fast kernels: the same piecewise map as deform.c:47-128
-// (legacy SciPy semantics, same branch structure) with the trunc-divisions `(npy_intp)(c / period)`
-// replaced by floor(c * (1 / period)) -- equal as real functions (every argument is positive
-// there), different only in the last ulp of the product, which the fast path does not promise.
-__device__ __forceinline__ double map_coordinate_fast(double c, int len, int mode, double period,
-                                                      double inv_period)
-{
-    const double last = (double)(len - 1);
-    if (c < 0) {
-        switch (mode) {
-        case EDHIP_MODE_MIRROR:
-            if (len <= 1) {
-                c = 0;
-            } else {
-                c = period * floor(-c * inv_period) + c;
-                c = c <= -last ? c + period : -c;
-            }
-            break;
-        case EDHIP_MODE_REFLECT:
-            if (len <= 1) {
-                c = 0;
-            } else {
-                if (c < -period)
-                    c = period * floor(-c * inv_period) + c;
-                c = c < (double)(-len) ? c + period : -c - 1;
-            }
-            break;
-        case EDHIP_MODE_WRAP:
-            if (len <= 1)
-                c = 0;
-            else
-                c += period * (floor(-c * inv_period) + 1);
-            break;
-        case EDHIP_MODE_NEAREST: c = 0; break;
-        default: c = -1; break;   // constant
-        }
-    } else if (c > last) {
-        switch (mode) {
-        case EDHIP_MODE_MIRROR:
-            if (len <= 1) {
-                c = 0;
-            } else {
-                c -= period * floor(c * inv_period);
-                if (c >= (double)len)
-                    c = period - c;
-            }
-            break;
-        case EDHIP_MODE_REFLECT:
-            if (len <= 1) {
-                c = 0;
-            } else {
-                c -= period * floor(c * inv_period);
-                if (c >= (double)len)
-                    c = period - c - 1;
-            }
-            break;
-        case EDHIP_MODE_WRAP:
-            if (len <= 1)
-                c = 0;
-            else
-                c -= period * floor(c * inv_period);
-            break;
-        case EDHIP_MODE_NEAREST: c = last; break;
-        default: c = -1; break;   // constant
-        }
-    }
-    return c;
-}
-
-// B-spline basis weights from the fractional offset, in the data's own width.  Same closed forms
-// as deform.c:160-268 (last weight = 1 - sum of the others) with the divisions folded into
-// constants.  x is c - floor(c) (odd orders) or c - floor(c + 0.5) (even orders).
-template <typename T, int ORDER>
-__device__ __forceinline__ void weights_from_frac(T x, T* w)
-{
-    const T z = (T)1 - x;
-    if (ORDER == 0) {
-        w[0] = (T)1;
-        return;
-    }
-    if (ORDER == 1) {
-        w[0] = z;
-    } else if (ORDER == 2) {
-        w[1] = (T)0.75 - x * x;
-        const T y = (T)0.5 - x;
-        w[0] = (T)0.5 * y * y;
-    } else if (ORDER == 3) {
-        // all four cubic pieces in closed form (cheaper than "last = 1 - sum"; same polynomials)
-        const T x2 = x * x, z2 = z * z;
-        w[0] = z2 * z * (T)(1.0 / 6.0);
-        w[3] = x2 * x * (T)(1.0 / 6.0);
-        w[1] = x2 * (x * (T)0.5 - (T)1) + (T)(2.0 / 3.0);
-        w[2] = z2 * (z * (T)0.5 - (T)1) + (T)(2.0 / 3.0);
-        return;
-    } else if (ORDER == 4) {
-        T t = x * x;
-        w[2] = t * (t * (T)0.25 - (T)0.625) + (T)(115.0 / 192.0);
-        T y = (T)1 + x;
-        w[1] = y * (y * (y * ((T)5 - y) * (T)(1.0 / 6.0) - (T)1.25) + (T)(5.0 / 24.0)) +
-               (T)(55.0 / 96.0);
-        w[3] = z * (z * (z * ((T)5 - z) * (T)(1.0 / 6.0) - (T)1.25) + (T)(5.0 / 24.0)) +
-               (T)(55.0 / 96.0);
-        y = (T)0.5 - x;
-        t = y * y;
-        w[0] = t * t * (T)(1.0 / 24.0);
-    } else {
-        T t = x * x;
-        w[2] = t * (t * ((T)0.25 - x * (T)(1.0 / 12.0)) - (T)0.5) + (T)0.55;
-        t = z * z;
-        w[3] = t * (t * ((T)0.25 - z * (T)(1.0 / 12.0)) - (T)0.5) + (T)0.55;
-        T y = x + (T)1;
-        w[1] = y * (y * (y * (y * (y * (T)(1.0 / 24.0) - (T)0.375) + (T)1.25) - (T)1.75) +
-                    (T)0.625) + (T)0.425;
-        const T zz = z + (T)1;
-        w[4] = zz * (zz * (zz * (zz * (zz * (T)(1.0 / 24.0) - (T)0.375) + (T)1.25) - (T)1.75) +
-                     (T)0.625) + (T)0.425;
-        y = (T)1 - x;
-        t = y * y;
-        w[0] = y * t * t * (T)(1.0 / 120.0);
-    }
-    T last = (T)1;
-#pragma unroll
-    for (int i = 0; i < ORDER; ++i)
-        last -= w[i];
-    w[ORDER] = last;
-}
-
-struct TileGeom {
-    int in_len[3];        // I_k (the tile kernels require extents < 2^30)
-    int out_len[3];
-    int tiles[3];         // number of tiles per axis
-    int strips_x;         // strips per tile row
-    int strip_tiles;      // tiles per strip (8, or 4 / 2 for small outputs)
-    int nstrips;
-    int ncpx;             // control points along x = stride of one component row of Q
-    int box_cap;          // elements per LDS copy
-    int off_ov;           // LDS byte offset of the overlay region (box | D, P)
-    int in_stride[3];     // element strides (the tile kernels require < 2^31 elements per volume)
-    int out_stride[3];
-    int mode;             // boundary mode of this input
-    int has_affine;
-    int off[3];           // crop offsets
-    double period[3];     // boundary-map period of each axis for `mode`, and its reciprocal
-    double inv_period[3];
-    double affine[12];    // inverse map, 3 x 4
-    int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
-    int* spill_next;      // the second level's spill list (its count is reset by the tables kernel)
-    int* label_list;      // label kernel: [0] = count, [1..cap] = linear ids of near-tie voxels (or nullptr)
-    int label_cap;
-    const int* worklist;  // second-level pass: [0] = count, [1..] = tile ids to process (else nullptr)
-    const double* q_global;   // [O_z][O_y][3][ncpx]: displacement contracted over z and y
-    const AxTab* xt_global;   // [O_x]: cubic weights / control indices along x
-    int dbg;              // ablation switches for profiling (EDHIP_TILE_DBG), 0 in production
-};
-
-struct StripPos {
-    int tz, ty, tx0, ntile;   // tile coordinates of the strip and number of tiles in it
-};
-
-__device__ __forceinline__ bool strip_position(const TileGeom& tg, int work, StripPos& sp)
-{
-    if (tg.worklist) {
-        // second-level pass: one 8^3 tile per work item, taken from the first level's spill list
-        if (work >= tg.worklist[0])
-            return false;
-        int t = tg.worklist[1 + work];
-        sp.tx0 = t % tg.tiles[2];
-        t /= tg.tiles[2];
-        sp.ty = t % tg.tiles[1];
-        sp.tz = t / tg.tiles[1];
-        sp.ntile = 1;
-        return true;
-    }
-    if (work != (int)blockIdx.x)
-        return false;        // first level: one strip per block
-    // strips are dealt to the XCDs in contiguous chunks (block b runs on XCD b % 8): neighbouring
-    // strips, whose source boxes overlap, share an L2
-    const int b = blockIdx.x;
-    const int per = (tg.nstrips + 7) >> 3;
-    int s = (b & 7) * per + (b >> 3);
-    if (s >= tg.nstrips)
-        return false;
-    const int sx = s % tg.strips_x;
-    s /= tg.strips_x;
-    sp.ty = s % tg.tiles[1];
-    sp.tz = s / tg.tiles[1];
-    sp.tx0 = sx * tg.strip_tiles;
-    sp.ntile = min(tg.strip_tiles, tg.tiles[2] - sp.tx0);
-    return true;
-}
+using namespace tile;
 
 // Per-call tables (one small launch before the tile kernel).  The displacement spline is
 // separable and its weights depend only on the output index along each axis (deform.c:639-647):
 //   XT[ox]            = cubic weights + mirror-mapped control indices along x   (the reference's
 //                       `dsplvals` rows, for one axis)
-//   Q[oz][oy][h][j2]  = sum_{l0,l1} wz[oz][l0] wy[oy][l1] D[h, iz[l0], iy[l1], j2]
+//   Q[oz][oy][j2][h]  = sum_{l0,l1} wz[oz][l0] wy[oy][l1] D[h, iz[l0], iy[l1], j2]   (h padded to 4:
+//                       one control column is 32 bytes, XT's indices are pre-multiplied by 4)
 // so that a voxel is left with 4 x-taps per component (12 fp64 FMAs instead of the reference's 192
 // multiply-adds, deform.c:693-758).  One block per output z: P = D contracted over z in LDS, then
 // every output y of that slice.
@@ -357,9 +74,11 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     __shared__ AxTab tz_;
     const int tid = threadIdx.x;
     const int oz = blockIdx.x;
+    const int sample = blockIdx.y;        // one control grid (and one Q table) per volume of a batch
+    const char* disp = g.disp + (int64_t)sample * tg.disp_bstride;
     const int ncpy = (int)g.ncp[1], ncpx = (int)g.ncp[2];
     const int nyx = ncpy * ncpx;
-    if (oz == 0 && tid == 0) {      // reset both spill counters (saves two memset launches per call)
+    if (oz == 0 && sample == 0 && tid == 0) {      // reset both spill counters (saves two memset launches per call)
         tg.spill[0] = 0;
         tg.spill_next[0] = 0;
         if (tg.label_list)
@@ -381,11 +100,14 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     };
     if (tid == 0)
         entry(0, oz, tz_);
-    if (oz == 0) {
+    if (oz == 0 && sample == 0) {
         AxTab* xt = const_cast<AxTab*>(tg.xt_global);
         for (int ox = tid; ox < tg.out_len[2]; ox += kBlock) {
             AxTab t;
             entry(2, ox, t);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                t.idx[l] *= 4;          // element offset of control column idx in a Q row [ncpx][4]
             xt[ox] = t;
         }
     }
@@ -393,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     for (int e = tid; e < 3 * nyx; e += kBlock) {
         const int h = e / nyx, j = e - h * nyx;
         const int j1 = j / ncpx, j2 = j - j1 * ncpx;
-        const char* base = g.disp + g.disp_stride[0] * h + g.disp_stride[2] * j1 + g.disp_stride[3] * j2;
+        const char* base = disp + g.disp_stride[0] * h + g.disp_stride[2] * j1 + g.disp_stride[3] * j2;
         double acc = 0.0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
@@ -401,19 +123,21 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
         sP[e] = acc;
     }
     __syncthreads();
-    double* q = const_cast<double*>(tg.q_global);
+    double* q = const_cast<double*>(tg.q_global) + (int64_t)sample * tg.q_bstride;
     for (int oy = tid; oy < tg.out_len[1]; oy += kBlock) {
         AxTab ty;
         entry(1, oy, ty);
-        double* row = q + ((int64_t)oz * tg.out_len[1] + oy) * 3 * ncpx;
-        for (int h = 0; h < 3; ++h)
-            for (int j2 = 0; j2 < ncpx; ++j2) {
+        double* row = q + ((int64_t)oz * tg.out_len[1] + oy) * 4 * ncpx;
+        for (int j2 = 0; j2 < ncpx; ++j2) {
+            for (int h = 0; h < 3; ++h) {
                 double acc = 0.0;
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
                     acc += ty.w[l] * sP[h * nyx + ty.idx[l] * ncpx + j2];
-                row[h * ncpx + j2] = acc;
+                row[j2 * 4 + h] = acc;
             }
+            row[j2 * 4 + 3] = 0.0;
+        }
     }
 }
 
@@ -435,11 +159,12 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& 
             dst[e] = e < avail ? src[e] : 0;
     }
     {   // Q rows: (zi, yy) -> global row (oz, oy); 4 threads per row
-        const int rowlen = 3 * tg.ncpx;
+        const int rowlen = 4 * tg.ncpx;
         const int r = tid >> 2;
         const int oz = min(sp.tz * kT + (r >> 3), tg.out_len[0] - 1);
         const int oy = min(sp.ty * kT + (r & 7), tg.out_len[1] - 1);
-        const double* src = tg.q_global + ((int64_t)oz * tg.out_len[1] + oy) * rowlen;
+        const double* src = tg.q_global + (int64_t)sp.sample * tg.q_bstride +
+                            ((int64_t)oz * tg.out_len[1] + oy) * rowlen;
         double* dst = sQ + r * rowlen;
         for (int k = tid & 3; k < rowlen; k += 4)
             dst[k] = src[k];
@@ -475,12 +200,12 @@ __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const HotParams
                                              const AxTab& tx_, int zi, int yy, const int* o,
                                              int* start, T* frac)
 {
-    double c[3], fl[3];
-    int ci[3];
-    bool oob = false;
+    double c[3];          // affine: the full coordinate; otherwise the displacement alone
+    int bi[3], ci[3];
+    bool inr[3];
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
-        const double* qrow = sQ + ((zi * kT + yy) * 3 + h) * tg.ncpx;
+        const double* qrow = sQ + (zi * kT + yy) * 4 * tg.ncpx + h;
         double d = 0.0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
@@ -491,32 +216,26 @@ __device__ __forceinline__ bool voxel_coords(const TileGeom& tg, const HotParams
             for (int l = 0; l < 3; ++l)
                 b = fma(hp->affine[h * 4 + l], (double)o[l], b);
             c[h] = b + hp->offd[h] + d;
+            bi[h] = 0;
         } else {
-            c[h] = (double)(o[h] + tg.off[h]) + d;      // the crop offset folds into the integer
+            c[h] = d;
+            bi[h] = o[h] + tg.off[h];               // the crop offset folds into the integer
         }
-        fl[h] = floor((ORDER & 1) ? c[h] : c[h] + 0.5);
-        ci[h] = (int)fl[h];
-        // in range <=> 0 <= c < I-1 (c == I-1 exactly takes the slow path, which leaves it alone)
-        const int lim = (ORDER & 1) ? tg.in_len[h] - 1 : tg.in_len[h];
-        oob = oob || (unsigned)ci[h] >= (unsigned)lim || ((ORDER & 1) == 0 && (c[h] < 0.0 || c[h] > hp->last[h]));
+        inr[h] = coord_axis_fast<ORDER, T>(c[h], bi[h], tg.in_len[h], ci[h], frac[h]);
     }
     bool cst = false;
-    if (oob) {
-        // one divergent region for all three axes: only lanes whose source point left the array
+    if (!(inr[0] && inr[1] && inr[2])) {
+        // one divergent region: the axes along which the source point left the array
 #pragma unroll
         for (int h = 0; h < 3; ++h) {
-            c[h] = map_coordinate_fast(c[h], (int)hp->last[h] + 1, tg.mode, hp->period[h],
-                                       hp->inv_period[h]);
-            cst = cst || !(c[h] > -1.0);
-            fl[h] = floor((ORDER & 1) ? c[h] : c[h] + 0.5);
-            ci[h] = (int)fl[h];
+            if (!inr[h])
+                cst = coord_axis_mapped<ORDER, T>((double)bi[h] + c[h], (int)hp->last[h] + 1, tg.mode,
+                                                  hp->period[h], hp->inv_period[h], ci[h], frac[h]) || cst;
         }
     }
 #pragma unroll
-    for (int h = 0; h < 3; ++h) {
+    for (int h = 0; h < 3; ++h)
         start[h] = cst ? 0 : ci[h] - ORDER / 2;
-        frac[h] = (T)(c[h] - fl[h]);
-    }
     return cst;
 }
 
@@ -587,8 +306,8 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int yy = lane >> 3, xx = lane & 7;
-    const T* __restrict__ in = reinterpret_cast<const T*>(v.in);
-    T* out = reinterpret_cast<T*>(v.out);
+    const T* __restrict__ in = reinterpret_cast<const T*>(v.in) + (int64_t)sp.sample * tg.in_bstride;
+    T* out = reinterpret_cast<T*>(v.out) + (int64_t)sp.sample * tg.out_bstride;
     if (ABL & 16)
         return;
 
@@ -660,7 +379,8 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
         if (any && !fits) {
             if (tid == 0) {    // hand the whole tile to the spill kernel
                 const int slot = atomicAdd(&tg.spill[0], 1);
-                tg.spill[1 + slot] = (sp.tz * tg.tiles[1] + sp.ty) * tg.tiles[2] + sp.tx0 + ti;
+                tg.spill[1 + slot] = sp.sample * tg.ntiles +
+                                     (sp.tz * tg.tiles[1] + sp.ty) * tg.tiles[2] + sp.tx0 + ti;
             }
             continue;
         }
@@ -864,8 +584,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 2 : 3) void deform_tile3_g
     constexpr int ZSTEP = 8 / NV;
     const int xx = tid % TX, yy = (tid / TX) & 7, zq = tid / (TX * 8);
     const int ntile = (sp.ntile * kT + TX - 1) / TX;
-    T* dx = reinterpret_cast<T*>(const_cast<char*>(v.in));      // accumulated into
-    const T* __restrict__ dy = reinterpret_cast<const T*>(v.out);
+    T* dx = reinterpret_cast<T*>(const_cast<char*>(v.in)) + (int64_t)sp.sample * tg.in_bstride;   // accumulated into
+    const T* __restrict__ dy = reinterpret_cast<const T*>(v.out) + (int64_t)sp.sample * tg.out_bstride;
 
     for (int ti = 0; ti < ntile; ++ti) {
         const int o0[3] = {sp.tz * kT, sp.ty * kT, sp.tx0 * kT + ti * TX};
@@ -919,7 +639,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 2 : 3) void deform_tile3_g
         if (!fits) {
             if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < tg.tiles[2]) {
                 const int slot = atomicAdd(&tg.spill[0], 1);
-                tg.spill[1 + slot] = (sp.tz * tg.tiles[1] + sp.ty) * tg.tiles[2] + sp.tx0 +
+                tg.spill[1 + slot] = sp.sample * tg.ntiles +
+                                     (sp.tz * tg.tiles[1] + sp.ty) * tg.tiles[2] + sp.tx0 +
                                      ti * (TX / kT) + tid;
             }
             continue;
@@ -1078,14 +799,17 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_direct_kernel(const GridG
 {
     constexpr int NT = ORDER + 1;
     (void)g;
-    T* inp = reinterpret_cast<T*>(const_cast<char*>(v.in));
-    T* outp = reinterpret_cast<T*>(v.out);
-    const int ntile_total = tg.tiles[0] * tg.tiles[1] * tg.tiles[2];
+    const int ntile_total = tg.ntiles * tg.nbatch;
     const int nwork = WORKLIST ? tg.spill[0] : ntile_total;
     const int tid = threadIdx.x;
     const int xx = tid & 7, yy = (tid >> 3) & 7, zq = tid >> 6;
     for (int s = blockIdx.x; s < nwork; s += gridDim.x) {
         int t = WORKLIST ? tg.spill[1 + s] : s;
+        const int sample = t / tg.ntiles;
+        t -= sample * tg.ntiles;
+        T* inp = reinterpret_cast<T*>(const_cast<char*>(v.in)) + (int64_t)sample * tg.in_bstride;
+        T* outp = reinterpret_cast<T*>(v.out) + (int64_t)sample * tg.out_bstride;
+        const double* qs = tg.q_global + (int64_t)sample * tg.q_bstride;
         const int tx = t % tg.tiles[2];
         t /= tg.tiles[2];
         const int ty = t % tg.tiles[1];
@@ -1100,37 +824,38 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_direct_kernel(const GridG
             if (oz >= tg.out_len[0])
                 continue;
             const int o[3] = {oz, oy, ox};
-            const double* qrow0 = tg.q_global + ((int64_t)oz * tg.out_len[1] + oy) * 3 * tg.ncpx;
+            const double* qrow0 = qs + ((int64_t)oz * tg.out_len[1] + oy) * 4 * tg.ncpx;
             // coordinates (same arithmetic as voxel_coords, tables read from global memory)
-            double c[3];
+            int ci[3];
+            T fr[3];
             bool cst = false;
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                const double* qrow = qrow0 + h * tg.ncpx;
+                const double* qrow = qrow0 + h;
                 double d = 0.0;
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
                     d = fma(tx_.w[l], qrow[tx_.idx[l]], d);
-                double b;
+                double c = d;
+                int bi = o[h] + tg.off[h];
                 if (tg.has_affine) {
-                    b = tg.affine[h * 4 + 3];
+                    double b = tg.affine[h * 4 + 3];
 #pragma unroll
                     for (int l = 0; l < 3; ++l)
                         b = fma(tg.affine[h * 4 + l], (double)o[l], b);
-                    b += (double)tg.off[h];
-                } else {
-                    b = (double)(o[h] + tg.off[h]);
+                    c = b + (double)tg.off[h] + d;
+                    bi = 0;
                 }
-                c[h] = map_coordinate_fast(b + d, tg.in_len[h], tg.mode, tg.period[h], tg.inv_period[h]);
-                cst = cst || !(c[h] > -1.0);
+                if (!coord_axis_fast<ORDER, T>(c, bi, tg.in_len[h], ci[h], fr[h]))
+                    cst = coord_axis_mapped<ORDER, T>((double)bi + c, tg.in_len[h], tg.mode, tg.period[h],
+                                                      tg.inv_period[h], ci[h], fr[h]) || cst;
             }
             int tap[3][NT];
             T w[3][NT];
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                const double fl = floor((ORDER & 1) ? c[h] : c[h] + 0.5);
-                const int st = cst ? 0 : (int)fl - ORDER / 2;
-                weights_from_frac<T, ORDER>((T)(c[h] - fl), w[h]);
+                const int st = cst ? 0 : ci[h] - ORDER / 2;
+                weights_from_frac<T, ORDER>(fr[h], w[h]);
 #pragma unroll
                 for (int l = 0; l < NT; ++l)
                     tap[h][l] = mirror_i32(st + l, tg.in_len[h]) * tg.in_stride[h];
@@ -1193,7 +918,7 @@ inline int ceil_log2(int64_t n)
     return l;
 }
 
-inline size_t q_bytes(const GridGeom& g) { return 8 * (size_t)(kT * kT * 3) * (size_t)g.ncp[2]; }
+inline size_t q_bytes(const GridGeom& g) { return 8 * (size_t)(kT * kT * 4) * (size_t)g.ncp[2]; }
 // near-tie list of the label kernel: up to 1M voxel ids (4 MiB), never more than the output has
 inline size_t label_list_bytes(const GridGeom& g)
 {
@@ -1206,7 +931,7 @@ inline size_t label_list_bytes(const GridGeom& g)
 
 inline size_t q_global_bytes(const GridGeom& g)
 {
-    return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 3 * (size_t)g.ncp[2];
+    return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 4 * (size_t)g.ncp[2];
 }
 
 // ================================================================================================
@@ -1246,12 +971,12 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_label_kernel(const GridGe
             if (oz >= tg.out_len[0])
                 continue;
             const int o[3] = {oz, oy, ox};
-            const double* qrow0 = tg.q_global + ((int64_t)oz * tg.out_len[1] + oy) * 3 * tg.ncpx;
+            const double* qrow0 = tg.q_global + ((int64_t)oz * tg.out_len[1] + oy) * 4 * tg.ncpx;
             double raw[3];
             bool tie = false;
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                const double* qrow = qrow0 + h * tg.ncpx;
+                const double* qrow = qrow0 + h;
                 double d = 0.0;
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
@@ -1382,10 +1107,15 @@ void profile_mark(bool after, hipStream_t stream)
 }
 
 template <typename T, int ORDER, bool PAIR, bool GRAD>
-hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
+hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, const DeformBatch* batch)
 {
     TileGeom tg;
     IOView ve = v;
+    const int nb = batch ? batch->nbatch : 1;
+    tg.nbatch = nb;
+    tg.in_bstride = batch ? batch->in_bstride / (int64_t)sizeof(T) : 0;
+    tg.out_bstride = batch ? batch->out_bstride / (int64_t)sizeof(T) : 0;
+    tg.disp_bstride = batch ? batch->disp_bstride : 0;
     for (int k = 0; k < 3; ++k) {
         tg.in_len[k] = (int)g.in_len[k];
         tg.out_len[k] = (int)g.out_len[k];
@@ -1411,16 +1141,18 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     // launch still has a few workgroups per CU (even lengths: the gradient kernel walks 16-wide tiles)
     tg.strip_tiles = kStrip;
     while (tg.strip_tiles > 2 &&
-           (int64_t)tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles) < 1024)
+           (int64_t)nb * tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles) < 1024)
         tg.strip_tiles >>= 1;
     tg.strips_x = (tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles;
     const int64_t nstrips = (int64_t)tg.tiles[0] * tg.tiles[1] * tg.strips_x;
     const int64_t ntiles = (int64_t)tg.tiles[0] * tg.tiles[1] * tg.tiles[2];
     if (nstrips <= 0)
         return hipSuccess;
-    if (ntiles > 0x3fffffffLL)
+    if (ntiles * nb > 0x3fffffffLL || nstrips * nb > 0x3fffffffLL)
         return hipErrorInvalidValue;
     tg.nstrips = (int)nstrips;
+    tg.ntiles = (int)ntiles;
+    tg.q_bstride = (long long)(q_global_bytes(g) / 8);
     tg.ncpx = (int)g.ncp[2];
     // LDS: head | Q | overlay (box | D, P).  K1 float32 odd orders: two shifted copies of 4096
     // elements; otherwise one copy (6144 x 4 bytes or 4096 x 8 bytes)
@@ -1447,12 +1179,13 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         tg.dbg = dbg ? atoi(dbg) : 0;
     }
     // scratch: first-level spill list | second-level spill list | x table | Q
-    const size_t list_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
+    const size_t list_bytes = (sizeof(int) * ((size_t)ntiles * nb + 1) + 63) & ~(size_t)63;
     const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
+    const size_t q_all = ((q_global_bytes(g) * (size_t)nb) + 63) & ~(size_t)63;
     hipError_t e = hipSuccess;
     // (edhip_deform reserved deform_tile_workspace_bytes() up front, so this does not move the
     // prefiltered control grid that may sit in the head of the workspace)
-    void* ws = workspace_reserve(stream, kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q_global_bytes(g) +
+    void* ws = workspace_reserve(stream, kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q_all +
                                              label_list_bytes(g), &e);
     if (!ws)
         return e;
@@ -1467,15 +1200,17 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     tg.label_list = nullptr;
     tg.label_cap = 0;
     if (std::is_integral<T>::value) {
-        tg.label_list = (int*)((char*)ws + 2 * list_bytes + xt_bytes + ((q_global_bytes(g) + 63) & ~(size_t)63));
+        tg.label_list = (int*)((char*)ws + 2 * list_bytes + xt_bytes + q_all);
         tg.label_cap = (int)(label_list_bytes(g) / sizeof(int)) - 32;
     }
     {
-        hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0]), dim3(kBlock),
+        hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0], (unsigned)nb), dim3(kBlock),
                            sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
         e = hipGetLastError();
     }
     if constexpr (std::is_integral<T>::value) {
+        if (nb != 1)
+            return hipErrorNotSupported;      // the label kernels take one volume per call
         if (e == hipSuccess) {
             const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
             hipLaunchKernelGGL(deform_tile3_label_kernel<T>, dim3(nblk), dim3(kBlock), 0, stream, g, ve, tg);
@@ -1487,7 +1222,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     if (ORDER < 1) {
         // order 0: one tap per voxel, no source box, straight from / to global memory
         if (e == hipSuccess) {
-            const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
+            const unsigned nblk = (unsigned)(ntiles * nb < (1 << 20) ? ntiles * nb : (1 << 20));
             hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, false>), dim3(nblk),
                                dim3(kBlock), 0, stream, g, ve, tg);
             e = hipGetLastError();
@@ -1497,9 +1232,67 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     // ---- level 1: strips, small boxes, highest occupancy ------------------------------------------
     profile_mark(false, stream);
     if (e == hipSuccess) {
-        const unsigned nblk = (unsigned)(((nstrips + 7) / 8) * 8);
+        const unsigned nblk = (unsigned)(((nstrips * nb + 7) / 8) * 8);
         constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
-        if (GRAD)
+        bool hot_done = false;
+        if constexpr (std::is_same<T, float>::value && ORDER >= 1) {
+            // float32, unit stride along x on both sides: the benchmark kernels of deform_hot.hip
+            if (tg.in_stride[2] == 1 && tg.out_stride[2] == 1 && !(tg.dbg & 512) && !getenv("EDHIP_NO_HOT")) {
+                HotGeom hg;
+                memset(&hg, 0, sizeof(hg));
+                hg.vol_r = reinterpret_cast<const float*>(ve.in);
+                hg.vol_w = reinterpret_cast<float*>(const_cast<char*>(ve.in));
+                hg.img_r = reinterpret_cast<const float*>(ve.out);
+                hg.img_w = reinterpret_cast<float*>(ve.out);
+                hg.q = tg.q_global;
+                hg.xt = tg.xt_global;
+                hg.spill = tg.spill;
+                hg.vol_bstride = tg.in_bstride;
+                hg.img_bstride = tg.out_bstride;
+                hg.q_bstride = tg.q_bstride;
+                for (int k = 0; k < 3; ++k) {
+                    hg.in_len[k] = tg.in_len[k];
+                    hg.out_len[k] = tg.out_len[k];
+                    hg.off[k] = tg.off[k];
+                    hg.tiles[k] = tg.tiles[k];
+                    hg.period[k] = tg.period[k];
+                    hg.inv_period[k] = tg.inv_period[k];
+                }
+                hg.vol_sz = tg.in_stride[0];
+                hg.vol_sy = tg.in_stride[1];
+                hg.img_sz = tg.out_stride[0];
+                hg.img_sy = tg.out_stride[1];
+                hg.strips_x = tg.strips_x;
+                hg.strip_tiles = tg.strip_tiles;
+                hg.nstrips = tg.nstrips;
+                hg.total_strips = tg.nstrips * nb;
+                hg.ntiles = tg.ntiles;
+                hg.ncpx = tg.ncpx;
+                hg.mode = tg.mode;
+                hg.has_affine = tg.has_affine;
+                hg.cval = (float)ve.cval;
+                hg.nstep = ve.nstep;
+                hg.nsteps = ve.nsteps;
+                for (int l = 0; l < ve.nstep; ++l) {
+                    hg.step_len[l] = ve.step_len[l];
+                    hg.vol_step[l] = ve.in_step_stride[l];
+                    hg.img_step[l] = ve.out_step_stride[l];
+                }
+                for (int k = 0; k < 12; ++k)
+                    hg.affine[k] = tg.affine[k];
+                const size_t hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box);
+                if (hlds) {
+                    const hipError_t he = launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
+                    if (he == hipSuccess)
+                        hot_done = true;
+                    else if (he != hipErrorNotSupported)
+                        e = he;
+                }
+            }
+        }
+        if (hot_done || e != hipSuccess)
+            ;
+        else if (GRAD)
             hipLaunchKernelGGL((deform_tile3_grad_kernel<T, (ORDER < 1 ? 2 : ORDER), 16>), dim3(nblk),
                                dim3(kBlock), lds, stream, g, ve, tg);
         else if (kBenchKernel && tg.dbg) {
@@ -1531,7 +1324,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
         box2 = (64 * 1024 - t2.off_ov) & ~(size_t)63;
     t2.box_cap = (int)((box2 - (GRAD ? 64 : 0)) / sizeof(T));      // gradient: cells of sizeof(T) + wave sums
     const size_t lds2 = t2.off_ov + box2;
-    const unsigned n2 = (unsigned)(ntiles < 512 ? ntiles : 512);
+    const unsigned n2 = (unsigned)(ntiles * nb < 512 ? ntiles * nb : 512);
     const bool skip_l2 = getenv("EDHIP_SKIP_L2") != nullptr;      // debugging aid
     if (e == hipSuccess && !skip_l2) {
         if (GRAD)
@@ -1546,7 +1339,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream)
     if (e == hipSuccess) {
         TileGeom t3 = tg;
         t3.spill = skip_l2 ? list_a : list_b;
-        const unsigned nsp = (unsigned)(ntiles < 512 ? ntiles : 512);
+        const unsigned nsp = (unsigned)(ntiles * nb < 512 ? ntiles * nb : 512);
         hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, true>), dim3(nsp), dim3(kBlock),
                            0, stream, g, ve, t3);
         e = hipGetLastError();
@@ -1570,19 +1363,20 @@ double tile_profile_last_us()
     return (double)ms * 1e3;
 }
 
-size_t deform_tile_workspace_bytes(const GridGeom& g)
+size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch)
 {
     if (g.naxis != 3)
         return kWorkspaceGridBytes;
     int64_t ntiles = 1;
     for (int k = 0; k < 3; ++k)
         ntiles *= (g.out_len[k] + kT - 1) / kT;
-    const size_t list_bytes = (sizeof(int) * ((size_t)ntiles + 1) + 63) & ~(size_t)63;
+    const size_t list_bytes = (sizeof(int) * ((size_t)ntiles * nbatch + 1) + 63) & ~(size_t)63;
     const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
     const size_t q = q_global_bytes(g);
     if (q > ((size_t)512 << 20))
         return kWorkspaceGridBytes;
-    return kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q + label_list_bytes(g);
+    return kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + ((q * (size_t)nbatch + 63) & ~(size_t)63) +
+           label_list_bytes(g);
 }
 
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
@@ -1650,68 +1444,72 @@ bool deform_label_supported(const GridGeom& g, const IOView& v, int gradient)
 
 hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream)
 {
+    const DeformBatch* batch = nullptr;
     if (!deform_label_supported(g, v, 0))
         return hipErrorNotSupported;
     switch (label_elem_size(v.in_dtype)) {
-    case 1: return launch_tile<uint8_t, 0, false, false>(g, v, stream);
-    case 2: return launch_tile<uint16_t, 0, false, false>(g, v, stream);
-    case 4: return launch_tile<uint32_t, 0, false, false>(g, v, stream);
-    default: return launch_tile<uint64_t, 0, false, false>(g, v, stream);
+    case 1: return launch_tile<uint8_t, 0, false, false>(g, v, stream, batch);
+    case 2: return launch_tile<uint16_t, 0, false, false>(g, v, stream, batch);
+    case 4: return launch_tile<uint32_t, 0, false, false>(g, v, stream, batch);
+    default: return launch_tile<uint64_t, 0, false, false>(g, v, stream, batch);
     }
 }
 
-hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
+hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream,
+                              const DeformBatch* batch)
 {
     if (!deform_tile_supported(g, v, gradient))
         return hipErrorNotSupported;
+    if (batch && (double)q_global_bytes(g) * batch->nbatch > (double)((size_t)4 << 30))
+        return hipErrorNotSupported;          // per-sample Q tables: keep the scratch bounded
     const bool f32 = v.in_dtype == EDHIP_F32;
     if (v.order < 2) {
         // direct kernel (forward gathers / float atomics)
         if (gradient) {
             if (f32)
-                return v.order == 0 ? launch_tile<float, 0, false, true>(g, v, stream)
-                                    : launch_tile<float, 1, false, true>(g, v, stream);
-            return v.order == 0 ? launch_tile<double, 0, false, true>(g, v, stream)
-                                : launch_tile<double, 1, false, true>(g, v, stream);
+                return v.order == 0 ? launch_tile<float, 0, false, true>(g, v, stream, batch)
+                                    : launch_tile<float, 1, false, true>(g, v, stream, batch);
+            return v.order == 0 ? launch_tile<double, 0, false, true>(g, v, stream, batch)
+                                : launch_tile<double, 1, false, true>(g, v, stream, batch);
         }
         if (f32)
-            return v.order == 0 ? launch_tile<float, 0, false, false>(g, v, stream)
-                                : launch_tile<float, 1, true, false>(g, v, stream);
-        return v.order == 0 ? launch_tile<double, 0, false, false>(g, v, stream)
-                            : launch_tile<double, 1, false, false>(g, v, stream);
+            return v.order == 0 ? launch_tile<float, 0, false, false>(g, v, stream, batch)
+                                : launch_tile<float, 1, true, false>(g, v, stream, batch);
+        return v.order == 0 ? launch_tile<double, 0, false, false>(g, v, stream, batch)
+                            : launch_tile<double, 1, false, false>(g, v, stream, batch);
     }
     if (gradient) {
         if (f32) {
             switch (v.order) {
-            case 2: return launch_tile<float, 2, false, true>(g, v, stream);
-            case 3: return launch_tile<float, 3, false, true>(g, v, stream);
-            case 4: return launch_tile<float, 4, false, true>(g, v, stream);
-            case 5: return launch_tile<float, 5, false, true>(g, v, stream);
+            case 2: return launch_tile<float, 2, false, true>(g, v, stream, batch);
+            case 3: return launch_tile<float, 3, false, true>(g, v, stream, batch);
+            case 4: return launch_tile<float, 4, false, true>(g, v, stream, batch);
+            case 5: return launch_tile<float, 5, false, true>(g, v, stream, batch);
             default: return hipErrorNotSupported;
             }
         }
         switch (v.order) {
-        case 2: return launch_tile<double, 2, false, true>(g, v, stream);
-        case 3: return launch_tile<double, 3, false, true>(g, v, stream);
-        case 4: return launch_tile<double, 4, false, true>(g, v, stream);
-        case 5: return launch_tile<double, 5, false, true>(g, v, stream);
+        case 2: return launch_tile<double, 2, false, true>(g, v, stream, batch);
+        case 3: return launch_tile<double, 3, false, true>(g, v, stream, batch);
+        case 4: return launch_tile<double, 4, false, true>(g, v, stream, batch);
+        case 5: return launch_tile<double, 5, false, true>(g, v, stream, batch);
         default: return hipErrorNotSupported;
         }
     }
     if (f32) {
         switch (v.order) {
-        case 2: return launch_tile<float, 2, true, false>(g, v, stream);
-        case 3: return launch_tile<float, 3, true, false>(g, v, stream);
-        case 4: return launch_tile<float, 4, true, false>(g, v, stream);
-        case 5: return launch_tile<float, 5, true, false>(g, v, stream);
+        case 2: return launch_tile<float, 2, true, false>(g, v, stream, batch);
+        case 3: return launch_tile<float, 3, true, false>(g, v, stream, batch);
+        case 4: return launch_tile<float, 4, true, false>(g, v, stream, batch);
+        case 5: return launch_tile<float, 5, true, false>(g, v, stream, batch);
         default: return hipErrorNotSupported;
         }
     }
     switch (v.order) {
-    case 2: return launch_tile<double, 2, false, false>(g, v, stream);
-    case 3: return launch_tile<double, 3, false, false>(g, v, stream);
-    case 4: return launch_tile<double, 4, false, false>(g, v, stream);
-    case 5: return launch_tile<double, 5, false, false>(g, v, stream);
+    case 2: return launch_tile<double, 2, false, false>(g, v, stream, batch);
+    case 3: return launch_tile<double, 3, false, false>(g, v, stream, batch);
+    case 4: return launch_tile<double, 4, false, false>(g, v, stream, batch);
+    case 5: return launch_tile<double, 5, false, false>(g, v, stream, batch);
     default: return hipErrorNotSupported;
     }
 }

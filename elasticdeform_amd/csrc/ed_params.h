@@ -58,9 +58,17 @@ hipError_t launch_deform_fast(const GridGeom& g, const IOView& v, int gradient, 
 bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient);
 
 // LDS-tiled forward kernel (3 deformed axes, order >= 2): the benchmark's hot kernel.
-hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
+// A batch of independent volumes handled by ONE set of launches (edhip_deform_batch): sample b's
+// arrays sit b * stride bytes after sample 0's; everything else (shapes, strides, order, mode, cval,
+// crop, affine) is shared.  The strip / tile index of the kernels carries the sample.
+struct DeformBatch {
+    int nbatch;
+    int64_t in_bstride, out_bstride, disp_bstride;   // bytes
+};
+hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream,
+                              const DeformBatch* batch = nullptr);
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient);
-size_t deform_tile_workspace_bytes(const GridGeom& g);   // scratch the tile path will ask for
+size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch = 1);   // scratch the tile path will ask for
 
 // order-0 resampling of label maps (any dtype, 3 deformed axes, forward): bit-equal to the exact
 // kernel (fast coordinates, exact re-evaluation of near-tie voxels), see deform_tile.hip
