@@ -38,7 +38,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libedhip.so
 
 # every symbol include/edhip.h declares
 EXPORTS = ('edhip_version', 'edhip_status_string', 'edhip_device_count', 'edhip_deform',
-           'edhip_deform_batch', 'edhip_source_box', 'edhip_spline_filter1d', 'edhip_release_scratch', 'edhip_profile_dominant',
+           'edhip_deform_batch', 'edhip_deform_batch_strided', 'edhip_source_box', 'edhip_spline_filter1d', 'edhip_release_scratch', 'edhip_profile_dominant',
            'edhip_profile_last_us')
 
 
@@ -89,6 +89,13 @@ def load():
             ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
             ctypes.POINTER(ctypes.c_double), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p,
             ctypes.c_size_t]
+        L.edhip_deform_batch_strided.restype = ctypes.c_int
+        L.edhip_deform_batch_strided.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.POINTER(EdhipArray), ctypes.c_int64,
+            ctypes.POINTER(EdhipArray), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
+            ctypes.POINTER(EdhipArray), ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
+            ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+            ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         L.edhip_profile_dominant.restype = ctypes.c_int
         L.edhip_profile_dominant.argtypes = [ctypes.c_int]
         L.edhip_profile_last_us.restype = ctypes.c_double
@@ -181,6 +188,28 @@ def deform_batch(gradient, in_descs, disp_descs, output_offset, out_descs, axis,
     buf = ctypes.create_string_buffer(256)
     status = L.edhip_deform_batch(
         int(bool(gradient)), n, ins, disps, off, outs, len(axis),
+        axis.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(order), int(mode), float(cval), aff,
+        int(flags), ctypes.c_void_p(stream), buf, 256)
+    raise_for_status(status, buf)
+
+
+def deform_batch_strided(gradient, nbatch, in_desc, in_bstride, disp_desc, disp_bstride, output_offset,
+                         out_desc, out_bstride, axis, order, mode, cval, inverse_affine, flags, stream):
+    """edhip_deform_batch_strided: the batch described once -- sample 0's descriptors plus the byte
+    distance between consecutive samples of each stacked array."""
+    L = load()
+    axis = numpy.ascontiguousarray(axis, dtype=numpy.int32).reshape(-1)
+    off = aff = None
+    if output_offset is not None:
+        off_arr = numpy.ascontiguousarray(output_offset, dtype=numpy.int64)
+        off = off_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    if inverse_affine is not None:
+        aff_arr = numpy.ascontiguousarray(inverse_affine, dtype=numpy.float64)
+        aff = aff_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    buf = ctypes.create_string_buffer(256)
+    status = L.edhip_deform_batch_strided(
+        int(bool(gradient)), int(nbatch), ctypes.byref(in_desc), int(in_bstride), ctypes.byref(disp_desc),
+        int(disp_bstride), off, ctypes.byref(out_desc), int(out_bstride), len(axis),
         axis.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(order), int(mode), float(cval), aff,
         int(flags), ctypes.c_void_p(stream), buf, 256)
     raise_for_status(status, buf)

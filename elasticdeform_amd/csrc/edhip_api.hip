@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "ed_params.h"
 #include "ed_workspace.h"
@@ -115,6 +117,65 @@ int make_geometry(const edhip_array* displacement, const int64_t* in_len, const 
     return EDHIP_OK;
 }
 
+// One input/output pair as the kernels see it: strides of the deformed axes, the non-deformed
+// ("step") axes flattened (deform.c:399-436).
+int make_view(const edhip_array& in, const edhip_array& out, int naxis, const int32_t* axis, int order,
+              int mode, double cval, ed::IOView& v, char* err, size_t errlen)
+{
+    using namespace ed;
+    memset(&v, 0, sizeof(v));
+    v.in = (const char*)in.data;
+    v.out = (char*)out.data;
+    v.in_dtype = in.dtype;
+    v.out_dtype = out.dtype;
+    v.order = order;
+    v.mode = mode;
+    v.cval = cval;
+    v.nsteps = 1;
+    int64_t min_deform = INT64_MAX, min_step = INT64_MAX;
+    for (int d = 0; d < in.ndim; ++d) {
+        int k = -1;
+        for (int j = 0; j < naxis; ++j)
+            if (axis[j] == d)
+                k = j;
+        if (k >= 0) {
+            v.in_stride[k] = in.stride_bytes[d];
+            v.out_stride[k] = out.stride_bytes[d];
+            if (out.shape[d] > 1 && iabs64(out.stride_bytes[d]) < min_deform)
+                min_deform = iabs64(out.stride_bytes[d]);
+        } else {
+            if (in.shape[d] != out.shape[d])
+                return fail(err, errlen, EDHIP_ERR_INVALID,
+                            "non-deformed axes of input and output must have the same size");
+            v.step_len[v.nstep] = in.shape[d];
+            v.in_step_stride[v.nstep] = in.stride_bytes[d];
+            v.out_step_stride[v.nstep] = out.stride_bytes[d];
+            v.nsteps *= in.shape[d];
+            if (out.shape[d] > 1 && iabs64(out.stride_bytes[d]) < min_step)
+                min_step = iabs64(out.stride_bytes[d]);
+            v.nstep++;
+        }
+    }
+    v.steps_fastest = v.nstep > 0 && min_step < min_deform;
+    return EDHIP_OK;
+}
+
+// descriptors of a batch that differ only in their base pointers, at a constant distance
+bool uniform_batch(const edhip_array* a, int n, int64_t* stride)
+{
+    *stride = n > 1 ? (const char*)a[1].data - (const char*)a[0].data : 0;
+    for (int b = 0; b < n; ++b) {
+        if (a[b].dtype != a[0].dtype || a[b].ndim != a[0].ndim)
+            return false;
+        for (int d = 0; d < a[0].ndim; ++d)
+            if (a[b].shape[d] != a[0].shape[d] || a[b].stride_bytes[d] != a[0].stride_bytes[d])
+                return false;
+        if ((const char*)a[b].data != (const char*)a[0].data + (int64_t)b * *stride)
+            return false;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -215,40 +276,12 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         const edhip_array& in = inputs[i];
         const edhip_array& out = outputs[i];
         IOView v;
-        memset(&v, 0, sizeof(v));
-        v.in = (const char*)in.data;
-        v.out = (char*)out.data;
-        v.in_dtype = in.dtype;
-        v.out_dtype = out.dtype;
-        v.order = orders[i];
-        v.mode = modes[i];
-        v.cval = cvals[i];
-        v.nsteps = 1;
-        int64_t min_deform = INT64_MAX, min_step = INT64_MAX;
-        for (int d = 0; d < in.ndim; ++d) {
-            int k = -1;
-            for (int j = 0; j < naxis; ++j)
-                if (axis[i * naxis + j] == d)
-                    k = j;
-            if (k >= 0) {
-                v.in_stride[k] = in.stride_bytes[d];
-                v.out_stride[k] = out.stride_bytes[d];
-                if (out.shape[d] > 1 && iabs64(out.stride_bytes[d]) < min_deform)
-                    min_deform = iabs64(out.stride_bytes[d]);
-            } else {
-                if (in.shape[d] != out.shape[d])
-                    return fail(err, errlen, EDHIP_ERR_INVALID,
-                                "non-deformed axes of input and output must have the same size");
-                v.step_len[v.nstep] = in.shape[d];
-                v.in_step_stride[v.nstep] = in.stride_bytes[d];
-                v.out_step_stride[v.nstep] = out.stride_bytes[d];
-                v.nsteps *= in.shape[d];
-                if (out.shape[d] > 1 && iabs64(out.stride_bytes[d]) < min_step)
-                    min_step = iabs64(out.stride_bytes[d]);
-                v.nstep++;
-            }
+        {
+            const int st = make_view(in, out, naxis, axis + i * naxis, orders[i], modes[i], cvals[i], v, err,
+                                     errlen);
+            if (st != EDHIP_OK)
+                return st;
         }
-        v.steps_fastest = v.nstep > 0 && min_step < min_deform;
         if (v.nsteps <= 0)
             continue;
 
@@ -289,6 +322,50 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
     if (nbatch < 0 || (nbatch > 0 && (!inputs || !displacements || !outputs)))
         return fail(err, errlen, EDHIP_ERR_INVALID, "invalid batch");
     ed::StreamGuard guard((hipStream_t)hip_stream);
+    // ---- one set of launches for the whole batch (the strip index of the tile kernels carries the
+    //      sample): same-shaped float volumes at a constant distance, one prefiltered grid each ------
+    {
+        using namespace ed;
+        DeformBatch db;
+        db.nbatch = nbatch;
+        const bool candidate = nbatch >= 2 && naxis == 3 && axis && !(flags & (EDHIP_FLAG_EXACT | EDHIP_FLAG_RAW_DISPLACEMENT)) &&
+                               !getenv("EDHIP_BATCH_LOOP") &&
+                               (inputs[0].dtype == EDHIP_F32 || inputs[0].dtype == EDHIP_F64) &&
+                               outputs[0].dtype == inputs[0].dtype && inputs[0].ndim == outputs[0].ndim &&
+                               inputs[0].ndim >= 3 && inputs[0].ndim <= EDHIP_MAX_DIMS &&
+                               displacements[0].ndim == 4 && displacements[0].shape[0] == 3 &&
+                               uniform_batch(inputs, nbatch, &db.in_bstride) &&
+                               uniform_batch(outputs, nbatch, &db.out_bstride) &&
+                               uniform_batch(displacements, nbatch, &db.disp_bstride);
+        bool axes_ok = candidate && order >= 0 && order <= 5 && mode >= 0 && mode <= 4;
+        for (int j = 0; axes_ok && j < naxis; ++j)
+            axes_ok = axis[j] >= 0 && axis[j] < inputs[0].ndim && (j == 0 || axis[j] > axis[j - 1]);
+        if (axes_ok) {
+            hipStream_t stream = (hipStream_t)hip_stream;
+            GridGeom g;
+            int64_t in_len[kMaxAxes], out_len[kMaxAxes];
+            bool shapes_ok = dtype_ok(displacements[0].dtype);
+            for (int k = 0; k < naxis; ++k) {
+                in_len[k] = inputs[0].shape[axis[k]];
+                out_len[k] = outputs[0].shape[axis[k]];
+                shapes_ok = shapes_ok && displacements[0].shape[k + 1] > 0 && in_len[k] >= 2;
+            }
+            IOView v;
+            if (shapes_ok &&
+                make_geometry(&displacements[0], in_len, out_len, output_offset, naxis, affine, flags, stream, g,
+                              nullptr, 0) == EDHIP_OK &&
+                make_view(inputs[0], outputs[0], naxis, axis, order, mode, cval, v, nullptr, 0) == EDHIP_OK &&
+                g.nvox > 0 && v.nsteps > 0 && deform_tile_supported(g, v, gradient != 0)) {
+                const hipError_t e = launch_deform_tile(g, v, gradient != 0, stream, &db);
+                if (e == hipSuccess)
+                    return EDHIP_OK;
+                if (e != hipErrorNotSupported)
+                    return hip_fail(err, errlen, e, "deform kernel launch");
+                (void)hipGetLastError();
+            }
+        }
+    }
+    // ---- otherwise: item by item (every shape, dtype and flag edhip_deform takes) ---------------------
     for (int b = 0; b < nbatch; ++b) {
         // stream order keeps item b + 1's control grid / tables (which reuse the workspace) behind
         // item b's kernels
@@ -299,6 +376,41 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
             return st;
     }
     return EDHIP_OK;
+}
+
+int edhip_deform_batch_strided(int gradient, int nbatch, const edhip_array* input0,
+                               int64_t input_batch_stride, const edhip_array* displacement0,
+                               int64_t displacement_batch_stride, const int64_t* output_offset,
+                               const edhip_array* output0, int64_t output_batch_stride, int naxis,
+                               const int32_t* axis, int32_t order, int32_t mode, double cval,
+                               const double* affine, uint32_t flags, void* hip_stream, char* err,
+                               size_t errlen)
+{
+    if (err && errlen)
+        err[0] = 0;
+    if (nbatch < 0 || (nbatch > 0 && (!input0 || !displacement0 || !output0)))
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid batch");
+    if (nbatch == 0)
+        return EDHIP_OK;
+    std::vector<edhip_array> all;
+    try {
+        all.resize(3 * (size_t)nbatch);
+    } catch (...) {
+        return fail(err, errlen, EDHIP_ERR_MEMORY, "out of host memory");
+    }
+    edhip_array* in = all.data();
+    edhip_array* disp = in + nbatch;
+    edhip_array* out = disp + nbatch;
+    for (int b = 0; b < nbatch; ++b) {
+        in[b] = *input0;
+        in[b].data = (char*)input0->data + (int64_t)b * input_batch_stride;
+        disp[b] = *displacement0;
+        disp[b].data = (char*)displacement0->data + (int64_t)b * displacement_batch_stride;
+        out[b] = *output0;
+        out[b].data = (char*)output0->data + (int64_t)b * output_batch_stride;
+    }
+    return edhip_deform_batch(gradient, nbatch, in, disp, output_offset, out, naxis, axis, order, mode, cval,
+                              affine, flags, hip_stream, err, errlen);
 }
 
 int edhip_release_scratch(void)

@@ -102,6 +102,13 @@ def _desc(t):
     return _lib.describe(t.data_ptr(), _dtype_name(t), t.shape, [s * es for s in t.stride()])
 
 
+def _desc_sample0(t):
+    """Descriptor of sample 0 of a stacked tensor (B, ...) and the byte distance between samples."""
+    es = t.element_size()
+    return (_lib.describe(t.data_ptr(), _dtype_name(t), t.shape[1:], [s * es for s in t.stride()[1:]]),
+            t.stride(0) * es)
+
+
 def _stream(device):
     return _torch().cuda.current_stream(device).cuda_stream
 
@@ -368,10 +375,10 @@ def deform_grid_batch(X, displacements, order=3, mode='constant', cval=0.0, crop
     has the meaning it has for a single sample and is shared.  Returns ``(B, ...)``.
 
     Equivalent to ``stack([deform_grid(X[b], displacements[b], ...) for b in range(B)])`` --
-    same kernels, same results -- but the B samples are prefiltered together (the batch axis is
-    just another outer axis of the filter passes) and deformed from a single library call
-    (``edhip_deform_batch``), which removes the per-sample host overhead that dominates for small
-    volumes.  The reference has no batched entry point (one grid per call, deform_grid.py:52).
+    same results, bit for bit -- but the B samples are prefiltered together (the batch axis is just
+    another outer axis of the filter passes) and deformed by ONE set of kernel launches
+    (``edhip_deform_batch_strided``: the strip index of the tile kernels carries the sample), which
+    removes the per-sample launches and host overhead that dominate for small volumes.  The reference has no batched entry point (one grid per call, deform_grid.py:52).
     """
     plan = _batch_plan(X, displacements, order, mode, cval, crop, axis, affine, rotate, zoom)
     torch = _torch()
@@ -385,15 +392,15 @@ def deform_grid_batch(X, displacements, order=3, mode='constant', cval=0.0, crop
         Xf = Xd
         if prefilter and o > 1:
             Xf = _filter_axes(Xd, [a + 1 for a in ax], o, False, device)
-        # all B control grids are prefiltered together (three launches for the batch instead of one
-        # per sample inside edhip_deform; same values: tests pin RAW_DISPLACEMENT == per-axis filter)
-        raw = False
+        # all B control grids are prefiltered together (three launches for the batch; same values as
+        # the per-call RAW_DISPLACEMENT path: a test pins that), then ONE library call and -- for
+        # float volumes with 3 deformed axes -- one tables launch + one tile launch for all B samples
         df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
         out = torch.empty((B,) + tuple(int(v) for v in plan.output_shapes[0]), dtype=Xd.dtype, device=device)
-        _lib.deform_batch(False, [_desc(Xf[b]) for b in range(B)], [_desc(df[b]) for b in range(B)],
-                          plan.output_offset, [_desc(out[b]) for b in range(B)], ax, o,
-                          int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine,
-                          _flags | (_lib.FLAG_RAW_DISPLACEMENT if raw else 0), _stream(device))
+        (xd, xs), (dd0, ds), (od, os_) = _desc_sample0(Xf), _desc_sample0(df), _desc_sample0(out)
+        _lib.deform_batch_strided(False, B, xd, xs, dd0, ds, plan.output_offset, od, os_, ax, o,
+                                  int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine, _flags,
+                                  _stream(device))
         return _from_device(out, X)
 
 
@@ -428,12 +435,11 @@ def deform_grid_gradient_batch(dY, displacements, order=3, mode='constant', cval
         dX = torch.zeros((B,) + tuple(int(v) for v in X_shape), dtype=dYd.dtype, device=device)
         ax = plan.axis[0]
         o = int(plan.order[0])
-        raw = False
         df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
-        _lib.deform_batch(True, [_desc(dX[b]) for b in range(B)], [_desc(df[b]) for b in range(B)],
-                          plan.output_offset, [_desc(dYd[b]) for b in range(B)], ax, o,
-                          int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine,
-                          _flags | (_lib.FLAG_RAW_DISPLACEMENT if raw else 0), _stream(device))
+        (xd, xs), (dd0, ds), (yd, ys) = _desc_sample0(dX), _desc_sample0(df), _desc_sample0(dYd)
+        _lib.deform_batch_strided(True, B, xd, xs, dd0, ds, plan.output_offset, yd, ys, ax, o,
+                                  int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine, _flags,
+                                  _stream(device))
         if prefilter and o > 1:
             dX = _filter_axes(dX, [a + 1 for a in ax], o, True, device, overwrite=True)
         return _from_device(dX, dY)

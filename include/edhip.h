@@ -161,8 +161,10 @@ int edhip_deform(int gradient, int ninputs,
  * SURVEY.md section 8(f) rank 2): item b is exactly
  *   edhip_deform(gradient, 1, &inputs[b], &displacements[b], output_offset, &outputs[b], naxis,
  *                axis, &order, &mode, &cval, affine, flags, hip_stream, ...)
- * -- same kernels, same results -- enqueued back to back from one host call.  `axis` (naxis
- * entries), order, mode, cval, the crop offsets and the affine map are shared by the batch.
+ * -- same results, bit for bit.  `axis` (naxis entries), order, mode, cval, the crop offsets and
+ * the affine map are shared by the batch.  Descriptors that differ only by a constant pointer
+ * stride (see edhip_deform_batch_strided) take the single-launch path described there; anything
+ * else is enqueued item by item.
  * The reference has no batched entry point; a host loop over its deform_grid is the equivalent.
  */
 int edhip_deform_batch(int gradient, int nbatch,
@@ -175,6 +177,25 @@ int edhip_deform_batch(int gradient, int nbatch,
                        const double* affine,
                        uint32_t flags, void* hip_stream,
                        char* err, size_t errlen);
+
+/*
+ * The same batch described once: sample b's arrays are sample 0's moved by b * stride bytes (a
+ * stacked tensor with a leading batch axis).  Spares the caller nbatch descriptors per array.
+ * When the volumes are float32 / float64 with 3 deformed axes and the control grids are already
+ * prefiltered (no EDHIP_FLAG_RAW_DISPLACEMENT), the whole batch is ONE set of launches: one tables
+ * kernel producing the per-sample displacement tables, one tile launch whose strip index carries
+ * the sample, one pair of spill passes -- bit-identical to nbatch edhip_deform calls.
+ */
+int edhip_deform_batch_strided(int gradient, int nbatch,
+                               const edhip_array* input0, int64_t input_batch_stride,
+                               const edhip_array* displacement0, int64_t displacement_batch_stride,
+                               const int64_t* output_offset,
+                               const edhip_array* output0, int64_t output_batch_stride,
+                               int naxis, const int32_t* axis,
+                               int32_t order, int32_t mode, double cval,
+                               const double* affine,
+                               uint32_t flags, void* hip_stream,
+                               char* err, size_t errlen);
 
 /*
  * Frees the scratch workspaces the library caches per (device, stream): per-call tables, spill

@@ -741,3 +741,50 @@ def test_label_values_beyond_2_53_round_trip_like_the_reference():
             want = orc.deform_grid(X, disp, order=0, mode=mode, cval=2.0)
             got = ed.deform_grid(X, disp, order=0, mode=mode, cval=2.0)
             np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_single_launch_batch_equals_item_by_item(dtype):
+    """edhip_deform_batch_strided: the whole batch as ONE set of launches (strip index carries the
+    sample) against the item-by-item path of the same entry point (EDHIP_BATCH_LOOP), bit for bit in
+    the forward direction -- strong deformation (tiles overflow into the spill levels across
+    samples), a crop, a channel axis, an affine map, orders 1-5 -- and within the float rounding of
+    the atomics for the gradient."""
+    rng = np.random.default_rng(23)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cases = [
+        dict(shape=(6, 40, 44, 70), pts=(3, 3, 3), sigma=2.0, kw=dict(order=3, mode="mirror")),
+        dict(shape=(5, 48, 40, 72), pts=(2, 3, 3), sigma=9.0, kw=dict(order=3, mode="wrap")),
+        dict(shape=(4, 2, 36, 40, 50), pts=(3, 3, 3), sigma=3.0,
+             kw=dict(order=2, mode="constant", cval=0.25, axis=(1, 2, 3),
+                     crop=(slice(3, 30), slice(0, 33), slice(7, 47)))),
+        dict(shape=(3, 33, 35, 37), pts=(3, 4, 3), sigma=3.0,
+             kw=dict(order=5, mode="nearest", affine=np.eye(3, 4) + 0.03 * rng.standard_normal((3, 4)))),
+        dict(shape=(7, 30, 30, 30), pts=(3, 3, 3), sigma=2.0, kw=dict(order=1, mode="reflect")),
+        dict(shape=(3, 34, 30, 41), pts=(3, 3, 3), sigma=2.0, kw=dict(order=4, mode="mirror")),
+    ]
+    for c in cases:
+        X = torch.from_numpy(rng.random(c["shape"]).astype(dtype)).to(dev)
+        B = X.shape[0]
+        D = torch.from_numpy(rng.standard_normal((B, 3) + c["pts"]) * c["sigma"]).to(dev)
+        kw = c["kw"]
+        one = ed.deform_grid_batch(X, D, **kw)
+        os.environ["EDHIP_BATCH_LOOP"] = "1"
+        try:
+            loop = ed.deform_grid_batch(X, D, **kw)
+        finally:
+            del os.environ["EDHIP_BATCH_LOOP"]
+        assert torch.equal(one, loop), (c["shape"], kw)
+        # one sample against the oracle
+        want = orc.deform_grid(X[B - 1].cpu().numpy(), D[B - 1].cpu().numpy(), **kw)
+        tol = F32_TOL if dtype == np.float32 else F64_TOL
+        np.testing.assert_allclose(one[B - 1].cpu().numpy(), want, **tol)
+        dY = torch.from_numpy(rng.random(tuple(one.shape)).astype(dtype)).to(dev)
+        g1 = ed.deform_grid_gradient_batch(dY, D, X_shape=tuple(X.shape[1:]), **kw)
+        os.environ["EDHIP_BATCH_LOOP"] = "1"
+        try:
+            g2 = ed.deform_grid_gradient_batch(dY, D, X_shape=tuple(X.shape[1:]), **kw)
+        finally:
+            del os.environ["EDHIP_BATCH_LOOP"]
+        eps = 1e-5 if dtype == np.float32 else 1e-11
+        assert float((g1 - g2).abs().max()) <= eps * max(1.0, float(g2.abs().max())), (c["shape"], kw)
