@@ -17,12 +17,22 @@ value = Mvoxels/s = N * 256^3 * K / (max-over-ranks wall time of the K steps) / 
 owns an independent volume (different seed), no data-path collective (the path shards by volume,
 SURVEY.md section 8e) => weak scaling.
 
+`--workload cfg5` switches to BASELINE cfg5's per-GPU shard: 64 volumes of 128^3 float32 with one
+5^3 grid each (512 volumes over 8 GPUs), forward + gradient through the single-launch batch kernels
+(deform_grid_batch / deform_grid_gradient_batch); same metric, same JSON line.
+
 Extra objects on the JSON line:
-  roofline      dominant kernel = K1 forward (deform_tile3_fwd_kernel<float,3,true> plus its tiny
-                tables / spill companions, i.e. one edhip_deform(gradient=0) call), HBM-bound.
+  roofline      the DOMINANT kernel of the timed step = the kernel with the largest per-step GPU
+                time.  The level-1 launches of K1 (forward gather) and K2 (gradient scatter) are
+                both timed live with HIP events recorded by the library on the launch stream
+                (edhip_profile_dominant); the larger one is reported (today K2), HBM-bound.
                 achieved = algorithmic bytes per launch (8 B/voxel: 4 read + 4 written,
-                SURVEY.md 8d) / average launch duration, measured live with HIP events on the
-                stream the kernel is launched on; peak 8 TB/s.
+                SURVEY.md 8d) / average launch duration; peak 8 TB/s.  `traffic` = HBM bytes per
+                launch from the PMC passes recorded in profiles/hbm_traffic.json, reported only
+                when that file was measured for the kernel named here (stamped with its commit).
+  north_star_kernel   the same numbers for K1, the kernel BASELINE.json's 50 % target is quoted on.
+  step_roofline       the whole step against HBM: 64 B/voxel algorithmic (K3 24 + K1 8 + K2 8 +
+                K4 24) / ms_per_step.
   cpu_baseline  the REAL reference C path (oracle/_ref, compiled from /root/reference) when that
                 binary is present, else our C port (oracle/ed_oracle.c); one host core; bounded
                 sample (128^3 forward + gradient with the same arguments); rank 0, N=1 only.
@@ -45,7 +55,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--side", type=int, default=N_SIDE, help=argparse.SUPPRESS)
+    ap.add_argument("--side", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2")
+    ap.add_argument("--batch", type=int, default=64, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -135,17 +147,25 @@ def main():
     dgm = importlib.import_module("elasticdeform_amd.deform_grid")
     from elasticdeform_amd import _lib
 
-    n = args.side
-    # every rank owns its own synthetic volume (shard = one volume; no cross-rank traffic)
-    X = torch.from_numpy(np.random.default_rng(2 + 1000 * rank).random((n, n, n), dtype=np.float32)).to(dev)
-    dY = torch.from_numpy(np.random.default_rng(7 + 1000 * rank).random((n, n, n), dtype=np.float32)).to(dev)
-    disp_h = np.random.default_rng(22 + 1000 * rank).standard_normal((3, 5, 5, 5)) * (5.0 * n / 256)
-    disp = torch.from_numpy(disp_h).to(dev)
+    cfg5 = args.workload == "cfg5"
+    n = args.side or (128 if cfg5 else N_SIDE)
+    B = args.batch if cfg5 else 1
+    # every rank owns its own synthetic data (shard = whole volumes; no cross-rank traffic)
+    shape = (B, n, n, n) if cfg5 else (n, n, n)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2 + 1000 * rank)
+    X = torch.rand(shape, device=dev, dtype=torch.float32, generator=gen)
+    dY = torch.rand(shape, device=dev, dtype=torch.float32, generator=gen)
+    sigma = 5.0 * n / 256          # same relative strength at every size (cfg5: 2.5 at 128^3)
+    dshape = (B, 3, 5, 5, 5) if cfg5 else (3, 5, 5, 5)
+    disp = torch.from_numpy(np.random.default_rng(22 + 1000 * rank).standard_normal(dshape) * sigma).to(dev)
     kw = dict(order=3, mode="mirror")
+    fwd = ed.deform_grid_batch if cfg5 else ed.deform_grid
+    bwd = ed.deform_grid_gradient_batch if cfg5 else ed.deform_grid_gradient
 
     def step():
-        y = ed.deform_grid(X, disp, **kw)
-        g = ed.deform_grid_gradient(dY, disp, **kw)
+        y = fwd(X, disp, **kw)
+        g = bwd(dY, disp, **kw)
         return y, g
 
     def fence():
@@ -167,7 +187,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-phase and dominant-kernel timing with HIP events on the launch stream ---------------
+    # ---- per-phase and per-kernel timing with HIP events on the launch stream ---------------------
     def timed(fn, iters):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(iters)]
@@ -184,82 +204,148 @@ def main():
 
     iters = max(10, args.steps)
     # (phases: medians -- a single allocator / first-use hiccup would dominate a 20-sample mean)
-    _, fwd_ms = timed(lambda: ed.deform_grid(X, disp, **kw), iters)
-    _, grad_ms = timed(lambda: ed.deform_grid_gradient(dY, disp, **kw), iters)
+    _, fwd_ms = timed(lambda: fwd(X, disp, **kw), iters)
+    _, grad_ms = timed(lambda: bwd(dY, disp, **kw), iters)
 
-    # K1 alone: prefiltered inputs prepared once, then only edhip_deform(gradient=0) between events
-    Xf = dgm._filter_axes(X, [0, 1, 2], 3, False, dev)
-    df = dgm._filter_axes(disp, [1, 2, 3], 3, False, dev)
+    # K1 / K2 alone: prefiltered inputs prepared once, then only the deform call between events
+    vol_axes = [1, 2, 3] if cfg5 else [0, 1, 2]
+    Xf = dgm._filter_axes(X, vol_axes, 3, False, dev)
+    df = dgm._filter_axes(disp, [a + 1 for a in vol_axes], 3, False, dev)
     out = torch.empty_like(X)
     dxs = torch.zeros_like(X)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    args_f = ([dgm._desc(Xf)], dgm._desc(df), None, [dgm._desc(out)], [(0, 1, 2)], [3], [3], [0.0],
-              None, _lib.FLAG_AUTO, stream)
-    args_g = ([dgm._desc(dxs)], dgm._desc(df), None, [dgm._desc(dY)], [(0, 1, 2)], [3], [3], [0.0],
-              None, _lib.FLAG_AUTO, stream)
+    if cfg5:
+        (xd, xs), (dd0, ds), (od, os_) = dgm._desc_sample0(Xf), dgm._desc_sample0(df), dgm._desc_sample0(out)
+        (gxd, gxs), (gyd, gys) = dgm._desc_sample0(dxs), dgm._desc_sample0(dY)
+
+        def k1():
+            _lib.deform_batch_strided(False, B, xd, xs, dd0, ds, None, od, os_, (0, 1, 2), 3, 3, 0.0, None,
+                                      _lib.FLAG_AUTO, stream)
+
+        def k2():
+            _lib.deform_batch_strided(True, B, gxd, gxs, dd0, ds, None, gyd, gys, (0, 1, 2), 3, 3, 0.0, None,
+                                      _lib.FLAG_AUTO, stream)
+    else:
+        args_f = ([dgm._desc(Xf)], dgm._desc(df), None, [dgm._desc(out)], [(0, 1, 2)], [3], [3], [0.0],
+                  None, _lib.FLAG_AUTO, stream)
+        args_g = ([dgm._desc(dxs)], dgm._desc(df), None, [dgm._desc(dY)], [(0, 1, 2)], [3], [3], [0.0],
+                  None, _lib.FLAG_AUTO, stream)
+
+        def k1():
+            _lib.deform(False, *args_f)
+
+        def k2():
+            _lib.deform(True, *args_g)
     for _ in range(3):
-        _lib.deform(False, *args_f)
-    k1_ms, k1_med = timed(lambda: _lib.deform(False, *args_f), max(50, iters))
-    # the dominant kernel alone (without the per-call tables kernel and the two spill passes):
+        k1()
+        k2()
+    k1_ms, _ = timed(k1, max(30, iters))
+    k2_ms, _ = timed(k2, max(30, iters))
+    # the level-1 launch of each (without the per-call tables kernel and the two spill passes):
     # HIP events recorded by the library around that launch, on the launch stream
     L = _lib.load()
-    L.edhip_profile_dominant(1)
-    dom = []
-    for _ in range(max(50, iters)):
-        _lib.deform(False, *args_f)
-        us = L.edhip_profile_last_us()
-        if us > 0:
-            dom.append(us)
-    L.edhip_profile_dominant(0)
-    if dom:
-        dom_us = sum(dom) / len(dom)
-        dom_med = sorted(dom)[len(dom) // 2]
-    else:
-        dom_us, dom_med = k1_ms * 1e3, k1_med * 1e3
-    _, k2_ms = timed(lambda: _lib.deform(True, *args_g), iters)
-    _, k3_ms = timed(lambda: dgm._filter_axes(X, [0, 1, 2], 3, False, dev), iters)
-    _, k4_ms = timed(lambda: dgm._filter_axes(dxs, [0, 1, 2], 3, True, dev), iters)
 
-    vox = float(n) ** 3
+    def level1(fn, n_it):
+        L.edhip_profile_dominant(1)
+        ts = []
+        for _ in range(n_it):
+            fn()
+            us = L.edhip_profile_last_us()
+            if us > 0:
+                ts.append(us)
+        L.edhip_profile_dominant(0)
+        if not ts:
+            return None, None
+        return sum(ts) / len(ts), sorted(ts)[len(ts) // 2]
+
+    k1_us, k1_med = level1(k1, max(30, iters))
+    k2_us, k2_med = level1(k2, max(30, iters))
+    if k1_us is None:
+        k1_us, k1_med = k1_ms * 1e3, k1_ms * 1e3
+    if k2_us is None:
+        k2_us, k2_med = k2_ms * 1e3, k2_ms * 1e3
+    _, k3_ms = timed(lambda: dgm._filter_axes(X, vol_axes, 3, False, dev), iters)
+    _, k4_ms = timed(lambda: dgm._filter_axes(dxs, vol_axes, 3, True, dev), iters)
+
+    vox = float(B) * float(n) ** 3
     algo_bytes = ALGO_BYTES_PER_VOXEL * vox
-    achieved = algo_bytes / (dom_us * 1e-6) / 1e9         # GB/s
-    traffic = None
+
+    def commit_id():
+        try:
+            import subprocess
+            return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
+                                           stderr=subprocess.DEVNULL).decode().strip()
+        except Exception:
+            return None
+
+    traffic_db = {}
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get("k1_forward_bytes_per_launch")
+                traffic_db = json.load(f)
         except Exception:
-            traffic = None
+            traffic_db = {}
+
+    def kernel_obj(tag, name, us, med, call_ms):
+        achieved = algo_bytes / (us * 1e-6) / 1e9          # GB/s
+        t = traffic_db.get("kernels", {}).get(tag) if not cfg5 and n == N_SIDE else None
+        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4),
+                "traffic": t.get("bytes_per_launch") if t else None,
+                "traffic_measured_at": t.get("commit") if t else None,
+                "kernel": name,
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "avg_launch_us": round(us, 2), "median_launch_us": round(med, 2),
+                "whole_call_avg_us": round(call_ms * 1e3, 2)}
+
+    k1_obj = kernel_obj("K1", "K1 forward deform: hot_fwd_kernel<3,false> (deform_hot.hip; the strip launch of "
+                        "one edhip_deform gradient=0 call on the prefiltered input; whole_call adds the "
+                        "tables kernel and the two spill passes)", k1_us, k1_med, k1_ms)
+    k2_obj = kernel_obj("K2", "K2 gradient scatter-add: hot_grad_kernel<3,false> (deform_hot.hip; the strip "
+                        "launch of one edhip_deform gradient=1 call; whole_call adds the tables kernel and "
+                        "the two spill passes)", k2_us, k2_med, k2_ms)
+    dominant = k2_obj if k2_us >= k1_us else k1_obj
+    dominant = dict(dominant)
+    dominant["note"] = ("dominant = largest per-step GPU time among K1, K2 and the six prefilter passes "
+                        "(K3/K4: %.1f / %.1f us per axis pass); HBM is the bounding roofline by definition "
+                        "(gather / scatter, no MFMA); both tile kernels are LDS- and issue-bound today, "
+                        "see DESIGN.md 5" % (k3_ms * 1e3 / 3, k4_ms * 1e3 / 3))
+    ms_per_step = elapsed / args.steps * 1e3
+    step_bytes = 64.0 * vox
+    step_obj = {"bound": "hbm", "algorithmic_bytes_per_step": int(step_bytes),
+                "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 4),
+                "note": "64 B/voxel = prefilter 24 + forward 8 + gradient 8 + transposed prefilter 24"}
 
     if rank == 0:
+        if cfg5:
+            workload = ("cfg5 shard: %d volumes of %d^3 float32 per GPU, one 5x5x5 grid (sigma %.3g) each, "
+                        "order 3, mode mirror, prefilter on, deform_grid_batch + "
+                        "deform_grid_gradient_batch per step" % (B, n, sigma))
+        else:
+            workload = ("cfg2: 3D %dx%dx%d float32, 5x5x5 grid sigma 5, order 3, mode mirror, prefilter "
+                        "on, deform_grid + deform_grid_gradient per step, one volume per GPU" % (n, n, n))
         res = {
-            "metric": "Mvoxels/s fwd+grad, 256^3 fp32 order=3",
+            "metric": "Mvoxels/s fwd+grad, 256^3 fp32 order=3" if not cfg5 else
+                      "Mvoxels/s fwd+grad, batch of 128^3 fp32 order=3",
             "value": round(world * vox * args.steps / elapsed / 1e6, 2),
             "unit": "Mvoxels/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cfg2: 3D %dx%dx%d float32, 5x5x5 grid sigma 5, order 3, "
-                                   "mode mirror, prefilter on, deform_grid + deform_grid_gradient "
-                                   "per step, one volume per GPU" % (n, n, n),
-                       "parallelism": "1 volume per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                         "kernel": "K1 forward deform: deform_tile3_fwd_kernel<float,3,true,0> (the strip launch of one edhip_deform gradient=0 call on the prefiltered input; whole_call adds the tables kernel and the two spill passes)",
-                         "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "avg_launch_us": round(dom_us, 2),
-                         "median_launch_us": round(dom_med, 2),
-                         "whole_call_avg_us": round(k1_ms * 1e3, 2),
-                         "note": "HBM is the bounding roofline by definition (gather / interpolate, no "
-                                 "MFMA); the kernel is VALU-issue-bound today: ~390 VALU instructions "
-                                 "per voxel (fp64 coordinates + 64-tap separable gather), see DESIGN.md 5"},
+            "config": {"workload": workload,
+                       "parallelism": "%s per GPU, no collective" % ("%d volumes" % B if cfg5 else "1 volume")},
+            "roofline": dominant,
+            "north_star_kernel": k1_obj,
+            "step_roofline": step_obj,
+            "commit": commit_id(),
             "phases_ms": {"deform_grid": round(fwd_ms, 4), "deform_grid_gradient": round(grad_ms, 4),
                           "K1_forward": round(k1_ms, 4), "K2_gradient": round(k2_ms, 4),
                           "K3_prefilter_3axes": round(k3_ms, 4),

@@ -1,8 +1,14 @@
 """
-World-size-2 test of the N > 1 path on CPU (gloo): volumes are sharded by rank with no data-path
-collective; the optional hand-back gathers outputs on one rank.  The per-volume compute function
-is injected -- here the CPU oracle, so that the test needs no GPU -- exactly where the product
-calls elasticdeform_amd.deform_grid on a GPU box.
+World-size-2 tests of the N > 1 path (gloo).
+
+CPU (`-m "not gpu"`): volumes are sharded by rank with no data-path collective; with the batch on
+one rank the control grids are broadcast and volumes / outputs travel as tensors, point to point
+(scatter_from / gather_to).  The compute function is injected -- the CPU oracle -- so that the test
+needs no GPU: the sharding arithmetic and the collectives are what is tested.
+
+GPU (`-m gpu`): the same two ranks share the one GPU of the test box and run the PRODUCT compute
+(deform_grid_batch / deform_grid_gradient_batch on CUDA tensors) under the process group; results
+must equal the single-process call bit for bit (forward) / to float rounding (gradient).
 """
 import os
 import socket
@@ -10,7 +16,8 @@ import socket
 import numpy as np
 import pytest
 
-from elasticdeform_amd.distributed import deform_batch, shard_bounds
+from elasticdeform_amd.distributed import (deform_batch, deform_batch_sharded, gather_batch,
+                                           scatter_batch, shard_bounds)
 
 
 def test_shard_bounds_partition():
@@ -86,4 +93,106 @@ def test_two_ranks_gloo(tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(2, port, 5, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def _sharded_worker(rank, world, port, n, out_dir):
+    import torch
+    import torch.distributed as dist
+    from oracle import ed_oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        X = rng.random((n, 9, 10, 11)).astype(np.float32)
+        D = rng.standard_normal((n, 3, 3, 3, 3)) * 1.5
+        kw = dict(order=3, mode="mirror")
+        want = np.stack([orc.deform_grid(X[b], D[b], **kw) for b in range(n)])
+
+        def compute(xs, ds, **k):       # the CPU oracle in place of the HIP batch kernels
+            return torch.from_numpy(np.stack([orc.deform_grid(xs[b].numpy(), ds[b].numpy(), **k)
+                                              for b in range(xs.shape[0])]))
+        dev = torch.device("cpu")
+        lo, hi = shard_bounds(n, rank, world)
+        # (1) data-loader case: every rank holds its shard, no communication
+        out = deform_batch_sharded(torch.from_numpy(X[lo:hi]), torch.from_numpy(D[lo:hi]), device=dev,
+                                   compute=compute, **kw)
+        np.testing.assert_array_equal(out.numpy(), want[lo:hi])
+        # (2) the batch lives on rank 1: grids broadcast, volumes scattered, outputs gathered on rank 0
+        full = deform_batch_sharded(torch.from_numpy(X) if rank == 1 else None,
+                                    torch.from_numpy(D) if rank == 1 else None,
+                                    scatter_from=1, gather_to=0, device=dev, compute=compute, **kw)
+        if rank == 0:
+            np.testing.assert_array_equal(full.numpy(), want)
+        else:
+            assert full is None
+        # (3) the building blocks, uneven shards
+        mine = scatter_batch(torch.from_numpy(X) if rank == 0 else None, 0, dev)
+        np.testing.assert_array_equal(mine.numpy(), X[lo:hi])
+        back = gather_batch(mine, n, 1)
+        if rank == 1:
+            np.testing.assert_array_equal(back.numpy(), X)
+        dist.barrier()
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_tensor_collectives(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(2, port, 5, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    import elasticdeform_amd as ed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)            # both ranks share the one GPU of the test box
+        dev = torch.device("cuda", 0)
+        n = 5
+        rng = np.random.default_rng(77)
+        X = torch.from_numpy(rng.random((n, 40, 36, 44)).astype(np.float32))
+        D = torch.from_numpy(rng.standard_normal((n, 3, 3, 3, 3)) * 2.0)
+        dY = torch.from_numpy(rng.random((n, 40, 36, 44)).astype(np.float32))
+        kw = dict(order=3, mode="mirror")
+        # single-process result of the product, computed by every rank for itself
+        want = ed.deform_grid_batch(X.to(dev), D.to(dev), **kw)
+        gwant = ed.deform_grid_gradient_batch(dY.to(dev), D.to(dev), **kw)
+        lo, hi = shard_bounds(n, rank, world)
+        out = deform_batch_sharded(X[lo:hi].to(dev), D[lo:hi].to(dev), **kw)
+        assert out.is_cuda and torch.equal(out, want[lo:hi])
+        full = deform_batch_sharded(X.to(dev) if rank == 0 else None, D.to(dev) if rank == 0 else None,
+                                    scatter_from=0, gather_to=1, **kw)
+        if rank == 1:
+            assert full.is_cuda and torch.equal(full, want)
+        else:
+            assert full is None
+        g = deform_batch_sharded(dY.to(dev) if rank == 1 else None, D.to(dev) if rank == 1 else None,
+                                 gradient=True, scatter_from=1, gather_to=1, **kw)
+        if rank == 1:
+            assert float((g - gwant).abs().max()) <= 1e-5 * max(1.0, float(gwant.abs().max()))
+        # the per-volume interface with the default compute (deform_grid) and a tensor gather
+        vols = [X[i].to(dev) for i in range(n)]
+        full = deform_batch(vols, [D[i] for i in range(n)], gather_to=0, **kw)
+        if rank == 0:
+            for i in range(n):
+                assert torch.equal(full[i], want[i])
+        dist.barrier()
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_with_the_product_compute(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
