@@ -485,6 +485,8 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
                     __syncthreads();         // B2: retires this wave's copies (vmcnt) and everyone's
 
                 // ---- phase D: gather -------------------------------------------------------------
+                // (both voxels in one branch-free block, for the scheduler to overlap one voxel's LDS
+                // reads with the other's arithmetic, was tried: 128 VGPRs + 192 bytes of scratch, 407 us)
                 const int plane = by * pitch;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -532,11 +534,11 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
 // into fixed-point LDS cells with integer atomics and flushed with one float atomic per touched
 // source element (see deform_tile.hip for the scale's no-overflow bound).
 // ================================================================================================
-template <int ORDER, bool AFFINE, int GRAD_WAVES>
+template <int ORDER, bool AFFINE, int GRAD_WAVES, int TX>
 __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotGeom hg)
 {
     constexpr int NT = ORDER + 1;
-    constexpr int TX = 16, NV = 4, ZSTEP = 2;
+    constexpr int NV = TX / 4, ZSTEP = 8 / NV;       // TX 16: 4 voxels per lane; TX 8: 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     HotStrip sp;
     if (!hot_strip(hg, sp))
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int xx = tid & 15, yy = (tid >> 4) & 7, zq = tid >> 7;
+    const int xx = tid & (TX - 1), yy = (tid / TX) & 7, zq = tid / (TX * 8);
     const int ntile = (sp.ntile * kT + TX - 1) / TX;
     float* dx = hg.vol_w + sp.sample * hg.vol_bstride;
     const float* __restrict__ dy = hg.img_r + sp.sample * hg.img_bstride;
@@ -620,7 +622,9 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
         if (!any)
             continue;      // nothing to scatter (uniform)
         // 16 lanes of a row hit 16 consecutive cells; pitch 8 * odd keeps neighbouring rows apart
-        const int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
+        int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
+        if (hg.dbg & 1024)      // experiment: row offsets of 16 banks (mod 32): 34 % fewer conflict
+            pitch = ext[2] <= 16 ? 16 : (ext[2] <= 48 ? 48 : 0);     // cycles, but the box doubles
         const int by = ext[1];
         const int nrows = ext[0] * by;
         const int nbox = nrows * pitch;
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
                     gv = sel ? gval[k] : gv;
                     act = sel ? active[k] : act;
                 }
-                if (!act || gv == 0.f)
+                if (!act || gv == 0.f || (hg.dbg & 128))
                     continue;
                 float w0[NT], w1[NT], w2[NT];
                 weights_from_frac<float, ORDER>(f0, w0);
@@ -737,10 +741,14 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
             // flush: half a wave per box row, lanes along x -- one float atomic per touched source
             // element, runs of consecutive addresses (deform.c:791-813: mirror-mapped at the edges)
             {
-                const int sub = tid & 31;
-                const int rslot = tid >> 5;                    // 8 rows per pass
-                const int dz = 8 / by, dyy = 8 - dz * by;      // uniform
+                constexpr int FL = TX == 8 ? 16 : 32;          // lanes per box row
+                constexpr int FR = kBlock / FL;                // rows per pass
+                const int sub = tid & (FL - 1);
+                const int rslot = tid / FL;
+                const int dz = FR / by, dyy = FR - dz * by;    // uniform
                 int zr = (int)(((float)rslot + 0.5f) / (float)by), yr = rslot - zr * by;
+                if (hg.dbg & 64)
+                    zr = ext[0];
                 while (zr < ext[0]) {
                     const int* row = box + (zr * by + yr) * pitch;
                     int rowoff;
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
                     else
                         rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
                                  mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
-                    for (int xi = sub; xi < ext[2]; xi += 32) {
+                    for (int xi = sub; xi < ext[2]; xi += FL) {
                         const int acc = row[xi];
                         if (acc != 0) {
                             const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
@@ -773,11 +781,9 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
 {
     if (gradient) {
         if (hg.has_affine)
-            hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 3>), dim3(nblk), dim3(kBlock), lds, stream, hg);
-        else if (getenv("EDHIP_GRAD_W4"))
-            hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+            hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
         else
-            hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 3>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+            hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
     } else {
         if (hg.has_affine)
             hipLaunchKernelGGL((hot_fwd_kernel<ORDER, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
@@ -806,8 +812,11 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box)
     const size_t off = (kOffQ + q + 15) & ~(size_t)15;
     *off_box = (int)off;
     if (gradient) {
-        *box_cap = kGradBoxBytes / 4;
-        const size_t total = off + kGradBoxBytes;
+        size_t box = kGradBoxBytes;
+        if (const char* kb = getenv("EDHIP_GRAD_BOX_KB"))
+            box = (size_t)atoi(kb) * 1024;
+        *box_cap = (int)(box / 4);
+        const size_t total = off + box;
         return total <= 64 * 1024 ? total : 0;
     }
     // forward: two shifted float copies; 4 workgroups per CU -> 40960 bytes each (wide control

@@ -1270,6 +1270,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 hg.ncpx = tg.ncpx;
                 hg.mode = tg.mode;
                 hg.has_affine = tg.has_affine;
+                hg.dbg = tg.dbg;
                 hg.cval = (float)ve.cval;
                 hg.nstep = ve.nstep;
                 hg.nsteps = ve.nsteps;
