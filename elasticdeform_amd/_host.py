@@ -201,7 +201,7 @@ class Plan(object):
     non-array arguments of _deform_grid.deform_grid (_deform_grid.c:108-118)."""
 
     __slots__ = ("axis", "naxis", "deform_shape", "output_shapes", "output_offset", "order",
-                 "mode", "cval", "inverse_affine")
+                 "mode", "cval", "inverse_affine", "prepared")
 
     def __init__(self, Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom):
         # same order of checks as deform_grid.py:135-152 / :246-266
@@ -217,6 +217,49 @@ class Plan(object):
         inv = inverse_of_affine(affine, self.naxis)
         self.inverse_affine = compose_rotation_zoom(
             rotate, zoom, inv, [self.output_shapes[0][d] for d in self.axis[0]])
+        self.prepared = None         # ctypes form of the arrays above, attached by the caller
+
+
+# ---- plan cache ------------------------------------------------------------------------------------
+# Normalising the arguments of one call costs ~15 us of Python (more than a small volume's kernels);
+# training loops repeat the same call with new data, so plans are memoised on everything they depend
+# on: shapes and the non-array arguments.  Only successfully validated plans are stored.
+_PLAN_CACHE = {}
+_PLAN_CACHE_MAX = 128
+
+
+def _freeze(v):
+    if isinstance(v, (list, tuple)):
+        return (type(v).__name__,) + tuple(_freeze(x) for x in v)
+    if isinstance(v, slice):
+        return ('slice', v.start, v.stop, v.step)
+    if isinstance(v, numpy.ndarray):
+        return ('nd', v.shape, str(v.dtype), v.tobytes())
+    if hasattr(v, 'detach') and hasattr(v, 'cpu'):        # torch.Tensor (affine convenience)
+        a = v.detach().cpu().numpy()
+        return ('nd', a.shape, str(a.dtype), a.tobytes())
+    if isinstance(v, (int, float, str, bool, type(None))):
+        return (type(v).__name__, v)
+    raise TypeError('unhashable plan argument')
+
+
+def cached_plan(Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom):
+    """Plan(...) memoised on (input shapes, displacement shape, every non-array argument)."""
+    try:
+        key = (tuple(tuple(int(d) for d in x.shape) for x in Xs),
+               tuple(int(d) for d in displacement.shape) if is_array(displacement) else None,
+               _freeze(order), _freeze(mode), _freeze(cval), _freeze(crop), _freeze(axis),
+               _freeze(affine), _freeze(rotate), _freeze(zoom))
+        hit = _PLAN_CACHE.get(key)
+    except (TypeError, AttributeError):
+        return Plan(Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
+    if hit is not None:
+        return hit
+    plan = Plan(Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
+    if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+        _PLAN_CACHE.clear()
+    _PLAN_CACHE[key] = plan
+    return plan
 
 
 # ---- crop-aware prefilter (SURVEY.md section 8(f), rank 1) --------------------------------------

@@ -38,7 +38,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libedhip.so
 
 # every symbol include/edhip.h declares
 EXPORTS = ('edhip_version', 'edhip_status_string', 'edhip_device_count', 'edhip_deform',
-           'edhip_deform_batch', 'edhip_deform_batch_strided', 'edhip_source_box', 'edhip_spline_filter1d', 'edhip_release_scratch', 'edhip_profile_dominant',
+           'edhip_deform_batch', 'edhip_deform_batch_strided', 'edhip_source_box', 'edhip_spline_filter1d',
+           'edhip_spline_filter_axes', 'edhip_release_scratch', 'edhip_profile_dominant',
            'edhip_profile_last_us')
 
 
@@ -110,6 +111,11 @@ def load():
         L.edhip_spline_filter1d.argtypes = [
             ctypes.POINTER(EdhipArray), ctypes.POINTER(EdhipArray), ctypes.c_int, ctypes.c_int,
             ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        L.edhip_spline_filter_axes.restype = ctypes.c_int
+        L.edhip_spline_filter_axes.argtypes = [
+            ctypes.POINTER(EdhipArray), ctypes.POINTER(EdhipArray), ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
+            ctypes.c_char_p, ctypes.c_size_t]
         _lib = L
     return _lib
 
@@ -138,35 +144,55 @@ def describe(data_ptr, dtype_name, shape, strides_bytes):
     return EdhipArray(data_ptr, code, nd, _I64x8(*shape), _I64x8(*strides_bytes))
 
 
+class DeformArgs(object):
+    """The host-side parameter arrays of one edhip_deform call (axis, orders, modes, cvals, crop
+    offsets, inverse affine) converted to ctypes once; a cached Plan keeps them, so repeated calls
+    with the same arguments skip the NumPy / ctypes conversions."""
+    __slots__ = ("n", "naxis", "axis", "orders", "modes", "cvals", "off", "aff")
+
+    def __init__(self, n, axis, orders, modes, cvals, output_offset, inverse_affine):
+        axis = numpy.ascontiguousarray(numpy.asarray(axis, dtype=numpy.int32).reshape(n, -1))
+        self.n = n
+        self.naxis = int(axis.shape[1])
+        self.axis = (ctypes.c_int32 * axis.size)(*[int(v) for v in axis.reshape(-1)])
+        self.orders = (ctypes.c_int32 * n)(*[int(v) for v in orders])
+        self.modes = (ctypes.c_int32 * n)(*[int(v) for v in modes])
+        self.cvals = (ctypes.c_double * n)(*[float(v) for v in cvals])
+        self.off = None
+        if output_offset is not None:
+            self.off = (ctypes.c_int64 * len(output_offset))(*[int(v) for v in output_offset])
+        self.aff = None
+        if inverse_affine is not None:
+            flat = numpy.ascontiguousarray(inverse_affine, dtype=numpy.float64).reshape(-1)
+            self.aff = (ctypes.c_double * flat.size)(*[float(v) for v in flat])
+
+
+_errbuf = threading.local()
+
+
+def _buf():
+    b = getattr(_errbuf, "b", None)
+    if b is None:
+        b = _errbuf.b = ctypes.create_string_buffer(256)
+    return b
+
+
 def deform(gradient, in_descs, disp_desc, output_offset, out_descs, axis, orders, modes, cvals,
-           inverse_affine, flags, stream):
+           inverse_affine, flags, stream, prepared=None):
     """edhip_deform -- argument for argument `_deform_grid.deform_grid(_grad)` of the reference
-    (_deform_grid.c:108-118) with descriptors in place of arrays, plus flags and the HIP stream."""
+    (_deform_grid.c:108-118) with descriptors in place of arrays, plus flags and the HIP stream.
+    `prepared`: a DeformArgs built earlier from the same parameter arrays."""
     L = load()
     n = len(in_descs)
-    axis = numpy.ascontiguousarray(numpy.asarray(axis, dtype=numpy.int32).reshape(n, -1))
-    naxis = axis.shape[1]
+    a = prepared if prepared is not None else DeformArgs(n, axis, orders, modes, cvals, output_offset,
+                                                         inverse_affine)
     ins = (EdhipArray * n)(*in_descs)
     outs = (EdhipArray * n)(*out_descs)
-    orders = numpy.ascontiguousarray(orders, dtype=numpy.int32)
-    modes = numpy.ascontiguousarray(modes, dtype=numpy.int32)
-    cvals = numpy.ascontiguousarray(cvals, dtype=numpy.float64)
-    off = aff = None
-    if output_offset is not None:
-        off_arr = numpy.ascontiguousarray(output_offset, dtype=numpy.int64)
-        off = off_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
-    if inverse_affine is not None:
-        aff_arr = numpy.ascontiguousarray(inverse_affine, dtype=numpy.float64)
-        aff = aff_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    buf = ctypes.create_string_buffer(256)
-    status = L.edhip_deform(
-        int(bool(gradient)), n, ins, ctypes.byref(disp_desc), off, outs, naxis,
-        axis.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-        orders.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-        modes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-        cvals.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), aff, int(flags),
-        ctypes.c_void_p(stream), buf, 256)
-    raise_for_status(status, buf)
+    buf = _buf()
+    status = L.edhip_deform(1 if gradient else 0, n, ins, ctypes.byref(disp_desc), a.off, outs, a.naxis,
+                            a.axis, a.orders, a.modes, a.cvals, a.aff, int(flags), stream, buf, 256)
+    if status:
+        raise_for_status(status, buf)
 
 
 def deform_batch(gradient, in_descs, disp_descs, output_offset, out_descs, axis, order, mode, cval,
@@ -242,11 +268,23 @@ def source_box(disp_desc, in_len, out_len, output_offset, inverse_affine, flags,
 def spline_filter1d(in_desc, out_desc, axis, order, transpose, flags, stream):
     """edhip_spline_filter1d"""
     L = load()
-    buf = ctypes.create_string_buffer(256)
+    buf = _buf()
     status = L.edhip_spline_filter1d(ctypes.byref(in_desc), ctypes.byref(out_desc), int(axis),
-                                     int(order), int(bool(transpose)), int(flags),
-                                     ctypes.c_void_p(stream), buf, 256)
-    raise_for_status(status, buf)
+                                     int(order), int(bool(transpose)), int(flags), stream, buf, 256)
+    if status:
+        raise_for_status(status, buf)
+
+
+def spline_filter_axes(in_desc, out_desc, axes, order, transpose, flags, stream):
+    """edhip_spline_filter_axes: the whole chain (first pass in -> out, the rest in place) in one call"""
+    L = load()
+    n = len(axes)
+    buf = _buf()
+    status = L.edhip_spline_filter_axes(ctypes.byref(in_desc), ctypes.byref(out_desc), n,
+                                        (ctypes.c_int32 * n)(*axes), int(order), int(bool(transpose)),
+                                        int(flags), stream, buf, 256)
+    if status:
+        raise_for_status(status, buf)
 
 
 def release_scratch():

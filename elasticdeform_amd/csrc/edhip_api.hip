@@ -608,4 +608,23 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
     return EDHIP_OK;
 }
 
+int edhip_spline_filter_axes(const edhip_array* input, const edhip_array* output, int naxes,
+                             const int32_t* axes, int order, int transpose, uint32_t flags,
+                             void* hip_stream, char* err, size_t errlen)
+{
+    if (err && errlen)
+        err[0] = 0;
+    if (naxes < 0 || (naxes > 0 && !axes))
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis list");
+    ed::StreamGuard guard((hipStream_t)hip_stream);
+    for (int i = 0; i < naxes; ++i) {
+        // the reference's loop (deform_grid.py:157-162, :279-284): input -> output, then in place
+        const int st = edhip_spline_filter1d(i == 0 ? input : output, output, axes[i], order, transpose, flags,
+                                             hip_stream, err, errlen);
+        if (st != EDHIP_OK)
+            return st;
+    }
+    return EDHIP_OK;
+}
+
 }  // extern "C"

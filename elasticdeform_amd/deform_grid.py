@@ -102,6 +102,14 @@ def _desc(t):
     return _lib.describe(t.data_ptr(), _dtype_name(t), t.shape, [s * es for s in t.stride()])
 
 
+def _prepared(plan, n):
+    """ctypes form of the plan's parameter arrays, built once per (cached) plan"""
+    if plan.prepared is None:
+        plan.prepared = _lib.DeformArgs(n, plan.axis, plan.order, plan.mode, plan.cval, plan.output_offset,
+                                        plan.inverse_affine)
+    return plan.prepared
+
+
 def _desc_sample0(t):
     """Descriptor of sample 0 of a stacked tensor (B, ...) and the byte distance between samples."""
     es = t.element_size()
@@ -113,7 +121,7 @@ def _stream(device):
     return _torch().cuda.current_stream(device).cuda_stream
 
 
-def _filter_axes(x, axes, order, transpose, device, overwrite=False):
+def _filter_axes(x, axes, order, transpose, device, overwrite=False, stream=None):
     """Chain of 1-D spline filters over `axes` -- the reference's loop at deform_grid.py:157-162
     (forward) / :279-284 (transpose).  The reference filters x -> x_f and then x_f in place; so does
     this chain for lines of up to 256 samples, and it ping-pongs between two buffers for longer ones
@@ -122,7 +130,8 @@ def _filter_axes(x, axes, order, transpose, device, overwrite=False):
     axes = list(axes)
     if not axes:
         return x
-    stream = _stream(device)
+    if stream is None:
+        stream = _stream(device)
     # Lines that fit the whole-line tile kernels are filtered in place from the second pass on
     # (like the reference; one temporary instead of two keeps the step's working set smaller);
     # longer lines ping-pong, because in place the block-recompute kernels cannot split a line.
@@ -131,9 +140,13 @@ def _filter_axes(x, axes, order, transpose, device, overwrite=False):
         bufs = [x, None]            # x is the caller's own temporary (dX): every pass in place
     else:
         bufs = [torch.empty_like(x), torch.empty_like(x) if (len(axes) > 1 and not inplace) else None]
+    if inplace:
+        # one library call for the whole chain: x -> bufs[0], then in place
+        _lib.spline_filter_axes(_desc(x), _desc(bufs[0]), axes, order, transpose, _flags, stream)
+        return bufs[0]
     src = x
     for i, d in enumerate(axes):
-        dst = bufs[0] if inplace else bufs[i & 1]
+        dst = bufs[i & 1]
         _lib.spline_filter1d(_desc(src), _desc(dst), d, order, transpose, _flags, stream)
         src = dst
     return src
@@ -251,11 +264,12 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
     mode / cval / axis may be per-input lists.  Returns the deformed array, or a list for a list.
     """
     Xs = _host.normalize_inputs(X)
-    plan = _host.Plan(Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
+    plan = _host.cached_plan(Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
 
     torch = _torch()
     device = _device_for(list(Xs) + [displacement])
     with torch.cuda.device(device):
+        stream = _stream(device)
         Xd = [_to_device(x, device) for x in Xs]
         dd = _to_device(displacement, device)
 
@@ -271,7 +285,7 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
                 xf = x
                 in_descs.append(_desc(x))
             elif wins[i] is None:
-                xf = _filter_axes(x, plan.axis[i], int(plan.order[i]), False, device)
+                xf = _filter_axes(x, plan.axis[i], int(plan.order[i]), False, device, stream=stream)
                 in_descs.append(_desc(xf))
             else:
                 xf = _filter_axes(_window_view(x, plan.axis[i], wins[i]), plan.axis[i],
@@ -285,7 +299,7 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
 
         _lib.deform(False, in_descs, _desc(df), plan.output_offset,
                     [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine, _flags | dflag, _stream(device))
+                    plan.inverse_affine, _flags | dflag, stream, prepared=_prepared(plan, len(Xd)))
         res = [_from_device(o, x) for o, x in zip(outs, Xs)]
     return res if isinstance(X, list) else res[0]
 
@@ -309,8 +323,8 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
 
     # every argument check runs before anything touches the device, in the reference's order
     # (deform_grid.py:246-266): a bad displacement / order / crop raises what the reference raises
-    plan = _host.Plan([_host.ShapeOnly(s) for s in X_shape], displacement, order, mode, cval, crop,
-                      axis, affine, rotate, zoom)
+    plan = _host.cached_plan([_host.ShapeOnly(s) for s in X_shape], displacement, order, mode, cval, crop,
+                             axis, affine, rotate, zoom)
     if [tuple(s) for s in plan.output_shapes] != [tuple(dy.shape) for dy in dYs]:
         raise ValueError("X_shape does not match output shape and cropping. "
                          "Expected output shape is %s, but %s given."
@@ -327,9 +341,10 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         dd = _to_device(displacement, device)
         df, dflag = _prefilter_displacement(dd, device)
 
+        stream = _stream(device)
         _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
                     [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine, _flags | dflag, _stream(device))
+                    plan.inverse_affine, _flags | dflag, stream, prepared=_prepared(plan, len(dXs)))
 
         # gradient of the prefilter: its transpose along each deformed axis (deform_grid.py:276-286).
         # With a crop the scatter only touched a box of dX: the transposed filter runs on that box
@@ -342,7 +357,8 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
             if not (prefilter and plan.order[i] > 1):
                 dXf.append(x)
             elif wins[i] is None:
-                dXf.append(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device, overwrite=True))
+                dXf.append(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device, overwrite=True,
+                                        stream=stream))
             else:
                 view = _window_view(x, plan.axis[i], wins[i])
                 view.copy_(_filter_axes(view, plan.axis[i], int(plan.order[i]), True, device))

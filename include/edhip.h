@@ -251,6 +251,17 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output,
                           uint32_t flags, void* hip_stream,
                           char* err, size_t errlen);
 
+/*
+ * The filter chain of one array in one call: edhip_spline_filter1d along axes[0] from `input` into
+ * `output`, then along axes[1..] in place in `output` -- the loop of deform_grid.py:157-162 (forward)
+ * and :279-284 (transpose).  input may equal output (every pass in place).  One host call instead of
+ * naxes (the per-call host overhead matters for small volumes).
+ */
+int edhip_spline_filter_axes(const edhip_array* input, const edhip_array* output,
+                             int naxes, const int32_t* axes, int order, int transpose,
+                             uint32_t flags, void* hip_stream,
+                             char* err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif
