@@ -23,7 +23,11 @@ RAW_DISPLACEMENT_MAX_POINTS = 4096
 DTYPE_CODES = {
     'bool': 0, 'uint8': 1, 'int8': 2, 'uint16': 3, 'int16': 4, 'uint32': 5, 'int32': 6,
     'uint64': 7, 'int64': 8, 'float32': 9, 'float64': 10,
+    # reduced-precision storage: an extension the host layer only uses after an explicit opt-in
+    # (the reference rejects half precision, deform.c:742-747)
+    'float16': 11, 'bfloat16': 12,
 }
+REDUCED_DTYPES = ('float16', 'bfloat16')
 
 # enum edhip_status -> the exception class the reference raises for that condition
 _STATUS_EXC = {

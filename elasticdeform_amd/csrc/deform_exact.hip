@@ -30,6 +30,28 @@ __device__ __forceinline__ void atomic_accumulate(char* p, int dt, double t)
     case EDHIP_U32: atomicAdd((unsigned int*)p, (unsigned int)trunc_i64(t)); break;
     case EDHIP_I64: atomicAdd((unsigned long long*)p, (unsigned long long)trunc_i64(t)); break;
     case EDHIP_U64: atomicAdd((unsigned long long*)p, (unsigned long long)trunc_u64(t)); break;
+    case EDHIP_F16:
+    case EDHIP_BF16: {
+        // 16-bit float lane of a 32-bit word: *(T*)p += (T)t, each add rounded to the storage type
+        const uintptr_t a = (uintptr_t)p;
+        unsigned int* word = (unsigned int*)(a & ~(uintptr_t)3);
+        const unsigned int shift = (unsigned int)(a & 2) * 8;
+        uint16_t add_bits;
+        store_cast((char*)&add_bits, dt, t);
+        const double addend = load_as_double((const char*)&add_bits, dt);
+        if (addend == 0.0)
+            break;
+        unsigned int old = *word, assumed;
+        do {
+            assumed = old;
+            const uint16_t cur = (uint16_t)(assumed >> shift);
+            uint16_t upd;
+            store_cast((char*)&upd, dt, load_as_double((const char*)&cur, dt) + addend);
+            const unsigned int next = (assumed & ~(0xffffu << shift)) | ((unsigned int)upd << shift);
+            old = atomicCAS(word, assumed, next);
+        } while (old != assumed);
+        break;
+    }
     default: {
         // 8- and 16-bit lanes of a 32-bit word: wrap-around add inside the lane via CAS
         const int bytes = (dt == EDHIP_U16 || dt == EDHIP_I16) ? 2 : 1;

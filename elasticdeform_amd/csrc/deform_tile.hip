@@ -1410,7 +1410,7 @@ static int label_elem_size(int dt)
 {
     switch (dt) {
     case EDHIP_BOOL: case EDHIP_U8: case EDHIP_I8: return 1;
-    case EDHIP_U16: case EDHIP_I16: return 2;
+    case EDHIP_U16: case EDHIP_I16: case EDHIP_F16: case EDHIP_BF16: return 2;
     case EDHIP_U32: case EDHIP_I32: case EDHIP_F32: return 4;
     default: return 8;
     }

@@ -19,9 +19,22 @@ namespace ed {
 // ---------------------------------------------------------------------------------------------
 // element access.  (double)*(T*)p  -- deform.c:282-285
 // ---------------------------------------------------------------------------------------------
+// bfloat16 <-> float: the upper 16 bits of a binary32; round to nearest even on the way down
+__device__ __forceinline__ float bf16_to_float(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t float_to_bf16(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u)
+        return (uint16_t)((u >> 16) | 0x40);                  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
 __device__ __forceinline__ double load_as_double(const char* p, int dt)
 {
     switch (dt) {
+    case EDHIP_F16: return (double)(float)*(const _Float16*)p;
+    case EDHIP_BF16: return (double)bf16_to_float(*(const uint16_t*)p);
     case EDHIP_BOOL:
     case EDHIP_U8: return (double)*(const uint8_t*)p;
     case EDHIP_I8: return (double)*(const int8_t*)p;
@@ -65,6 +78,8 @@ __device__ __forceinline__ uint64_t trunc_u64(double t)
 __device__ __forceinline__ void store_cast(char* p, int dt, double t)
 {
     switch (dt) {
+    case EDHIP_F16: *(_Float16*)p = (_Float16)(float)t; break;
+    case EDHIP_BF16: *(uint16_t*)p = float_to_bf16((float)t); break;
     case EDHIP_BOOL:
     case EDHIP_U8: *(uint8_t*)p = (uint8_t)trunc_i32(t); break;
     case EDHIP_I8: *(int8_t*)p = (int8_t)trunc_i32(t); break;
@@ -88,6 +103,8 @@ __device__ __forceinline__ void store_forward(char* p, int dt, double t)
     case EDHIP_BOOL: *(uint8_t*)p = (uint8_t)trunc_i32(t); return;
     case EDHIP_F32: *(float*)p = (float)t; return;
     case EDHIP_F64: *(double*)p = t; return;
+    case EDHIP_F16:
+    case EDHIP_BF16: store_cast(p, dt, t); return;
     case EDHIP_U8: hi = 255.0; break;
     case EDHIP_U16: hi = 65535.0; break;
     case EDHIP_U32: hi = 4294967295.0; break;

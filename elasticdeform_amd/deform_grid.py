@@ -39,6 +39,31 @@ def set_arithmetic(kind):
     return prev
 
 
+_reduced = os.environ.get('EDHIP_REDUCED_PRECISION', '') not in ('', '0')
+
+
+def set_reduced_precision(enabled):
+    """Opt in to reduced-precision I/O (off by default, where
+    float16 input raises 'data type not supported' exactly like the reference, deform.c:742-747):
+
+    * float16 / bfloat16 volumes (torch tensors; numpy float16): stored in 16 bits, computed in
+      float32 -- prefilter, interpolation and the gradient's scatter all run on the widened values
+      and only the final result is rounded (to nearest even) to the storage type.  Result =
+      round_storage(float32 pipeline(widen(X))).
+    * integer images with order > 1: the reference prefilters them INTO their integer dtype
+      (deform_grid.py:158), which destroys the interpolation (off by up to 225 grey
+      levels on uint8).  With the opt-in the prefilter and the interpolation run in float32 and the
+      result is stored with the reference's own rounding / clamping rule (deform.c:292-306).  This
+      deliberately DIFFERS from the reference for such images; order 0 / 1 are unaffected.
+
+    With arithmetic 'exact' 16-bit volumes go through the fp64 kernels in their storage type
+    (rounded after every filter axis, like every dtype there).  Returns the previous setting."""
+    global _reduced
+    prev = _reduced
+    _reduced = bool(enabled)
+    return prev
+
+
 def _torch():
     import torch
     return torch
@@ -54,7 +79,7 @@ def _dtype_name(t):
         torch = _torch()
         _TORCH_NAMES = {getattr(torch, n): n for n in _lib.DTYPE_CODES if hasattr(torch, n)}
     name = _TORCH_NAMES.get(t.dtype)
-    if name is None:
+    if name is None or (name in _lib.REDUCED_DTYPES and not _reduced):
         raise RuntimeError('data type not supported')     # deform.c:744,891 (float16, complex ...)
     return name
 
@@ -76,7 +101,7 @@ def _to_device(x, device):
     bridge allows it (the reference accepts arbitrary strides, _deform_grid.c:12-15)."""
     torch = _torch()
     if isinstance(x, numpy.ndarray):
-        if x.dtype.name not in _lib.DTYPE_CODES:
+        if x.dtype.name not in _lib.DTYPE_CODES or (x.dtype.name in _lib.REDUCED_DTYPES and not _reduced):
             raise RuntimeError('data type not supported')
         if not x.dtype.isnative or not x.flags.aligned or any(s < 0 for s in x.strides) \
                 or not x.flags.writeable:
@@ -95,6 +120,38 @@ def _from_device(t, like):
     if like.device != t.device:
         return t.to(like.device)
     return t
+
+
+_INT_RANGE = {'uint8': (0.0, 255.0), 'uint16': (0.0, 65535.0), 'uint32': (0.0, 4294967295.0),
+              'int8': (-128.0, 127.0), 'int16': (-32768.0, 32767.0), 'int32': (-2147483648.0, 2147483647.0)}
+
+
+def _widen(t, order, prefilter):
+    """Reduced-precision opt-in: the float32 stand-in of a 16-bit float volume, or of an integer
+    image that would lose its prefilter to integer rounding; None when `t` runs as it is."""
+    if not _reduced or (_flags & _lib.FLAG_EXACT):
+        return None
+    name = _TORCH_NAMES.get(t.dtype) if _TORCH_NAMES else None
+    if name is None:
+        name = _dtype_name(t)
+    if name in _lib.REDUCED_DTYPES or (name in _INT_RANGE and order > 1 and prefilter):
+        return t.to(_torch().float32)
+    return None
+
+
+def _narrow(t32, like):
+    """float32 result -> the storage dtype of `like`: round to nearest even for 16-bit floats; the
+    reference's store rule for integers (deform.c:292-306: round half away from zero, clamp)."""
+    torch = _torch()
+    name = _dtype_name(like)
+    if name in _lib.REDUCED_DTYPES:
+        return t32.to(like.dtype)
+    lo, hi = _INT_RANGE[name]
+    r = torch.where(t32 > 0, t32 + 0.5, t32 - 0.5) if lo < 0 else torch.where(t32 > 0, t32 + 0.5, torch.zeros_like(t32))
+    # float32 cannot hold 2^31 - 1 / 2^32 - 1: clamp in float64 for the 32-bit types
+    if hi > 1e9:
+        r = r.double()
+    return r.clamp_(lo, hi).trunc_().to(like.dtype)
 
 
 def _desc(t):
@@ -270,7 +327,11 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
     device = _device_for(list(Xs) + [displacement])
     with torch.cuda.device(device):
         stream = _stream(device)
-        Xd = [_to_device(x, device) for x in Xs]
+        Xs_dev = [_to_device(x, device) for x in Xs]
+        # reduced-precision opt-in: 16-bit float volumes (and integer images with order > 1) are
+        # computed in float32 and narrowed at the end
+        wide = [_widen(x, int(plan.order[i]), prefilter) for i, x in enumerate(Xs_dev)]
+        Xd = [w if w is not None else x for w, x in zip(wide, Xs_dev)]
         dd = _to_device(displacement, device)
 
         # the displacement is always prefiltered (deform_grid.py:166-169); the inputs along their
@@ -300,6 +361,7 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
         _lib.deform(False, in_descs, _desc(df), plan.output_offset,
                     [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
                     plan.inverse_affine, _flags | dflag, stream, prepared=_prepared(plan, len(Xd)))
+        outs = [_narrow(o, xs) if w is not None else o for o, xs, w in zip(outs, Xs_dev, wide)]
         res = [_from_device(o, x) for o, x in zip(outs, Xs)]
     return res if isinstance(X, list) else res[0]
 
@@ -333,7 +395,9 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
     torch = _torch()
     device = _device_for(list(dYs) + [displacement])
     with torch.cuda.device(device):
-        dYd = [_to_device(dy, device) for dy in dYs]
+        dY_dev = [_to_device(dy, device) for dy in dYs]
+        wide = [_widen(dy, int(plan.order[i]), prefilter) for i, dy in enumerate(dY_dev)]
+        dYd = [w if w is not None else dy for w, dy in zip(wide, dY_dev)]
         # gradient accumulators start at zero (deform_grid.py:243)
         dXs = [torch.zeros(tuple(int(v) for v in s), dtype=dy.dtype, device=device)
                for s, dy in zip(X_shape, dYd)]
@@ -363,6 +427,7 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
                 view = _window_view(x, plan.axis[i], wins[i])
                 view.copy_(_filter_axes(view, plan.axis[i], int(plan.order[i]), True, device))
                 dXf.append(x)
+        dXf = [_narrow(x, dy) if w is not None else x for x, dy, w in zip(dXf, dY_dev, wide)]
         res = [_from_device(x, dy) for x, dy in zip(dXf, dYs)]
     return res if isinstance(dY, list) else res[0]
 

@@ -55,7 +55,8 @@ extern "C" {
 #define EDHIP_MAX_INPUTS 64
 
 /* dtype codes: the 13 NumPy types the reference switches over (deform.c:716-741,863-887,
- * 907-919) collapse to these 11 distinct machine types on LP64 (long == long long). */
+ * 907-919) collapse to 11 distinct machine types on LP64 (long == long long); two 16-bit floating
+ * point storage types are an extension. */
 enum edhip_dtype {
     EDHIP_BOOL = 0, /* npy_bool  (unsigned char; store is a plain C cast, deform.c:287-290,907) */
     EDHIP_U8 = 1,
@@ -68,7 +69,13 @@ enum edhip_dtype {
     EDHIP_I64 = 8,
     EDHIP_F32 = 9,
     EDHIP_F64 = 10,
-    EDHIP_NUM_DTYPES = 11
+    /* reduced-precision storage -- NOT part of the reference's
+     * contract, which rejects half precision with "data type not supported" (deform.c:742-747); the
+     * host shim only hands these over when the caller opted in.  Arithmetic stays fp64 / fp32:
+     * values are widened on load and rounded to nearest-even on store. */
+    EDHIP_F16 = 11, /* IEEE binary16 */
+    EDHIP_BF16 = 12, /* bfloat16 */
+    EDHIP_NUM_DTYPES = 13
 };
 
 /* boundary modes, same integer codes as the reference (from_scipy.h:38-47,

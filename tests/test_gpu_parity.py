@@ -788,3 +788,72 @@ def test_single_launch_batch_equals_item_by_item(dtype):
             del os.environ["EDHIP_BATCH_LOOP"]
         eps = 1e-5 if dtype == np.float32 else 1e-11
         assert float((g1 - g2).abs().max()) <= eps * max(1.0, float(g2.abs().max())), (c["shape"], kw)
+
+
+# ---- reduced-precision I/O: an opt-in extension --------------------------
+
+def test_reduced_precision_io_opt_in():
+    """float16 / bfloat16 volumes: rejected by default like in the reference (deform.c:742-747);
+    with set_reduced_precision(True) the result is the float32 pipeline on the widened data rounded
+    to the storage type -- checked against the fp64 oracle on the widened data, within 1 ulp of the
+    storage type.  Integer images with order > 1 keep their interpolation (float32 prefilter) and
+    are stored with the reference's rounding rule: equal to the oracle run on the float image and
+    rounded, up to one grey level at exact ties.  'exact' arithmetic runs 16-bit storage natively
+    through the fp64 kernels."""
+    rng = np.random.default_rng(41)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    disp = rng.standard_normal((3, 3, 3, 3)) * 2.0
+    X32 = rng.random((30, 34, 40)).astype(np.float32)
+    with pytest.raises(RuntimeError, match="data type not supported"):
+        ed.deform_grid(torch.from_numpy(X32).to(dev).half(), disp)
+    prev = ed.set_reduced_precision(True)
+    try:
+        for tdt, ulp in ((torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)):
+            Xh = torch.from_numpy(X32).to(dev).to(tdt)
+            wide = Xh.float().cpu().numpy().astype(np.float64)
+            for kw in (dict(order=3, mode="mirror"), dict(order=1, mode="constant", cval=0.5),
+                       dict(order=0, mode="nearest"), dict(order=3, mode="wrap", crop=(slice(2, 20), slice(0, 30), slice(5, 33)))):
+                got = ed.deform_grid(Xh, disp, **kw)
+                assert got.dtype == tdt and got.is_cuda
+                want = orc.deform_grid(wide, disp, **kw)
+                err = np.abs(got.float().cpu().numpy().astype(np.float64) - want)
+                assert err.max() <= ulp * np.maximum(1.0, np.abs(want)).max() * 1.01 + 2e-5, (tdt, kw, err.max())
+            # gradient: dY in 16 bits, dX returned in 16 bits
+            dY = torch.from_numpy(rng.random(X32.shape).astype(np.float32)).to(dev).to(tdt)
+            g = ed.deform_grid_gradient(dY, disp, order=3, mode="mirror")
+            assert g.dtype == tdt
+            gw = orc.deform_grid_gradient(dY.float().cpu().numpy().astype(np.float64), disp, order=3, mode="mirror")
+            scale = max(1.0, np.abs(gw).max())
+            assert np.abs(g.float().cpu().numpy() - gw).max() <= ulp * scale * 1.01 + 2e-5
+        # numpy float16 in -> numpy float16 out
+        out = ed.deform_grid(X32.astype(np.float16), disp, order=3)
+        assert isinstance(out, np.ndarray) and out.dtype == np.float16
+        # integer image, order 3: float32 prefilter, the reference's store rule
+        for dt in (np.uint8, np.int16):
+            Xi = (rng.random((28, 30, 33)) * 200).astype(dt)
+            got = ed.deform_grid(Xi, disp, order=3, mode="mirror")
+            assert got.dtype == dt
+            y = orc.deform_grid(Xi.astype(np.float64), disp, order=3, mode="mirror")
+            want = np.where(y > 0, y + 0.5, y - 0.5 if np.dtype(dt).kind == "i" else 0.0)
+            info = np.iinfo(dt)
+            want = np.clip(want, info.min, info.max).astype(np.int64)
+            assert np.abs(got.astype(np.int64) - want).max() <= 1
+            assert (got.astype(np.int64) != want).mean() < 1e-3
+            if dt == np.uint8:
+                # and it is NOT what the reference does with such an image: its uint8 prefilter wraps
+                # the negative coefficients (SURVEY.md a9)
+                ref_like = orc.deform_grid(Xi, disp, order=3, mode="mirror")
+                assert np.abs(ref_like.astype(np.int64) - want).max() > 5
+        # 'exact' arithmetic: 16-bit storage handled natively by the fp64 kernels
+        ed.set_arithmetic("exact")
+        Xh = torch.from_numpy(X32).to(dev).half()
+        got = ed.deform_grid(Xh, disp, order=1, mode="mirror", prefilter=False)
+        want = orc.deform_grid(Xh.float().cpu().numpy().astype(np.float64), disp, order=1, mode="mirror", prefilter=False)
+        assert got.dtype == torch.float16
+        assert np.abs(got.float().cpu().numpy() - want).max() <= 2.0 ** -10 * 1.01
+        lab = ed.deform_grid(Xh, disp, order=0, mode="nearest")
+        np.testing.assert_array_equal(lab.float().cpu().numpy(),
+                                      orc.deform_grid(Xh.float().cpu().numpy(), disp, order=0, mode="nearest"))
+    finally:
+        ed.set_reduced_precision(prev)
+        ed.set_arithmetic("auto")

@@ -71,9 +71,19 @@ def test_validation_errors_map_to_reference_exceptions():
     # unsupported dtypes never reach the library: the descriptor builder refuses them with the
     # reference's message (deform.c:744,891)
     with pytest.raises(RuntimeError, match="data type not supported"):
-        _lib.describe(0x1000, "float16", (4, 4), (8, 2))
-    with pytest.raises(RuntimeError, match="data type not supported"):
         _lib.describe(0x1000, "complex64", (4, 4), (32, 8))
+    # float16 / bfloat16 are storage types of the C ABI (an extension); the public API hands them
+    # over only after set_reduced_precision(True) and otherwise answers like the reference
+    assert _lib.describe(0x1000, "float16", (4, 4), (8, 2)).dtype == 11
+    assert _lib.describe(0x1000, "bfloat16", (4, 4), (8, 2)).dtype == 12
+    import importlib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    torch = pytest.importorskip("torch")
+    assert not dgm._reduced
+    with pytest.raises(RuntimeError, match="data type not supported"):
+        dgm._dtype_name(torch.zeros(2, dtype=torch.float16))
+    with pytest.raises(RuntimeError, match="data type not supported"):
+        dgm._dtype_name(torch.zeros(2, dtype=torch.bfloat16))
 
 
 def test_filter_validation():
