@@ -84,6 +84,8 @@ struct HotStrip {
 
 __device__ __forceinline__ bool hot_strip(const HotGeom& hg, HotStrip& sp)
 {
+    // (a second level with these kernels -- one spilled tile per work item in a 64 KiB block -- was
+    // tried and lost to the general level-2 kernel: a full prologue per tile, two workgroups per CU)
     // strips are dealt to the 8 XCDs in contiguous chunks (block b runs on XCD b % 8)
     const int b = blockIdx.x;
     const int per = (hg.total_strips + 7) >> 3;
@@ -101,7 +103,8 @@ __device__ __forceinline__ bool hot_strip(const HotGeom& hg, HotStrip& sp)
     return true;
 }
 
-__device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& sp, char* smem)
+__device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& sp, char* smem,
+                                             bool copy_q = true)
 {
     const int tid = threadIdx.x;
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
@@ -112,7 +115,7 @@ __device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& 
         for (int e = tid; e < kStrip * kT * 12; e += kBlock)
             dst[e] = e < avail ? src[e] : 0;
     }
-    {   // Q rows: (zi, yy) -> (oz, oy); 4 threads per row, 16 bytes at a time
+    if (copy_q) {   // Q rows: (zi, yy) -> (oz, oy); 4 threads per row, 16 bytes at a time
         const int row16 = 2 * hg.ncpx;                   // 16-byte pieces per row (32 bytes per column)
         const int r = tid >> 2;
         const int oz = min(sp.tz * kT + (r >> 3), hg.out_len[0] - 1);
@@ -324,8 +327,11 @@ __device__ __forceinline__ void hot_tile_coords(const HotGeom& hg, const HotPara
 // asynchronous LDS-DMA, and the coordinates + bounding box of tile t + 1 are computed while they are
 // in flight; the gather of tile t follows the barrier that retires the copies.
 template <int ORDER, bool AFFINE, int ABL = 0>
-__global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
+__global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(const HotGeom hg)
 {
+    // coordinates of tile t + 1 computed under tile t's copies (orders 4 / 5: the extra live state spills)
+    constexpr bool PIPE = !(ABL & 4096) && ORDER <= 3;
+    constexpr bool QGLOBAL = (ABL & 1024) != 0; // experiment: Q rows read from global memory (L1), not LDS
     constexpr int NT = ORDER + 1;
     constexpr int kPadX = NT & 1;          // even orders read one zero-weight padding tap
     constexpr int NTX = NT + kPadX;
@@ -333,12 +339,12 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
     HotStrip sp;
     if (!hot_strip(hg, sp))
         return;
-    hot_prologue(hg, sp, smem);
+    hot_prologue(hg, sp, smem, !QGLOBAL);
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
     const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
-    float* box0 = reinterpret_cast<float*>(smem + hg.off_box);
+    float* box0 = reinterpret_cast<float*>(smem + (QGLOBAL ? kOffQ : hg.off_box));
     float* box1 = box0 + hg.box_cap;      // cap = 56 (mod 64): the two copies sit on disjoint banks
 
     const int tid = threadIdx.x;
@@ -357,7 +363,12 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
     for (int i = 0; i < 2; ++i) {
         const int zi = wave + 4 * i;
         oz[i] = sp.tz * kT + zi;
-        qrow[i] = smem + kOffQ + (zi * kT + yy) * (32 * hg.ncpx);
+        if (QGLOBAL)
+            qrow[i] = reinterpret_cast<const char*>(
+                hg.q + sp.sample * hg.q_bstride +
+                ((long long)min(oz[i], hg.out_len[0] - 1) * hg.out_len[1] + min(oy, hg.out_len[1] - 1)) * (4 * hg.ncpx));
+        else
+            qrow[i] = smem + kOffQ + (zi * kT + yy) * (32 * hg.ncpx);
         vzy[i] = oz[i] < hg.out_len[0] && oy < hg.out_len[1];
         obase[i] = oz[i] * hg.img_sz + oy * hg.img_sy + sp.tx0 * kT + xx;
     }
@@ -374,11 +385,15 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
     int start[2][3];
     float frac[2][3];
     bool valid[2], constant[2];
-    hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx, sred, qrow, oz, oy, sp.tx0 * kT, xx, lane, vzy, Pzy,
-                                        start, frac, valid, constant);
+    if (PIPE)
+        hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx, sred, qrow, oz, oy, sp.tx0 * kT, xx, lane, vzy, Pzy,
+                                            start, frac, valid, constant);
 
     for (int ti = 0; ti < sp.ntile; ++ti) {
         int* red = sred + (ti % 3) * 8;
+        if (!PIPE)
+            hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx + ti * kT, red, qrow, oz, oy, (sp.tx0 + ti) * kT, xx,
+                                                lane, vzy, Pzy, start, frac, valid, constant);
         __syncthreads();   // B1: box known; every gather of the previous tile is done
         int b0[3] = {red[0], red[1], red[2]};
         int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
@@ -416,7 +431,24 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
 
         // ---- phase C: stage the source box into LDS (two copies, the second shifted by one) ----------
         auto stage = [&](const float* src) {
-            if (interior) {
+            if (interior && pitch == 16 && (ABL & 16)) {
+                // experiment (ABL & 16): one 16-byte load per chunk, the shifted copy built in
+                // registers -- element 4 of the shifted chunk is the neighbouring lane's first element
+                // (the four lanes of a row are a DPP quad).  Half the loads of fetching both copies,
+                // two ds_write_b128 instead of two LDS-DMA copies: 248 us against 240 us (not used).
+                const int q = tid & 3;
+                const float inv_by = 1.0f / (float)by;
+                for (int r = tid >> 2; r < nrows; r += kBlock / 4) {
+                    const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                    const float* g = src + ((b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2] + 4 * q);
+                    const F4u v0 = *reinterpret_cast<const F4u*>(g);
+                    const float nx = __int_as_float(__builtin_amdgcn_update_dpp(
+                        0, __float_as_int(v0.x), 0xF9 /* quad_perm:[1,2,3,3] */, 0xf, 0xf, false));
+                    float* lp = box0 + r * 16 + 4 * q;
+                    *reinterpret_cast<float4*>(lp) = make_float4(v0.x, v0.y, v0.z, v0.w);
+                    *reinterpret_cast<float4*>(lp + hg.box_cap) = make_float4(v0.y, v0.z, v0.w, nx);
+                }
+            } else if (interior) {
                 // LDS-DMA: one wave-instruction fills 1 KiB = RW consecutive box rows (16 rows of 64
                 // bytes, or 5 rows of 192 bytes with lanes 60-63 idle); lane -> (row, 16-byte chunk)
                 const int cpr = pitch >> 2;
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
         int nstart[2][3];
         float nfrac[2][3];
         bool nvalid[2] = {false, false}, nconstant[2] = {false, false};
-        if (ti + 1 < sp.ntile)
+        if (PIPE && ti + 1 < sp.ntile)
             hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx + (ti + 1) * kT, sred + ((ti + 1) % 3) * 8, qrow, oz,
                                                 oy, (sp.tx0 + ti + 1) * kT, xx, lane, vzy, Pzy, nstart, nfrac,
                                                 nvalid, nconstant);
@@ -481,7 +513,7 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
                         stage(vol + vol_off);
                     }
                 }
-                if (staged && !(ABL & 32))
+                if (staged && (!(ABL & 32) || (ABL & 512)))
                     __syncthreads();         // B2: retires this wave's copies (vmcnt) and everyone's
 
                 // ---- phase D: gather -------------------------------------------------------------
@@ -516,14 +548,16 @@ __global__ __launch_bounds__(kBlock, 4) void hot_fwd_kernel(const HotGeom hg)
                 }
             }
         }
+        if (PIPE) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            valid[i] = nvalid[i];
-            constant[i] = nconstant[i];
+            for (int i = 0; i < 2; ++i) {
+                valid[i] = nvalid[i];
+                constant[i] = nconstant[i];
 #pragma unroll
-            for (int h = 0; h < 3; ++h) {
-                start[i][h] = nstart[i][h];
-                frac[i][h] = nfrac[i][h];
+                for (int h = 0; h < 3; ++h) {
+                    start[i][h] = nstart[i][h];
+                    frac[i][h] = nfrac[i][h];
+                }
             }
         }
     }
@@ -540,6 +574,7 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
     constexpr int NT = ORDER + 1;
     constexpr int NV = TX / 4, ZSTEP = 8 / NV;       // TX 16: 4 voxels per lane; TX 8: 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int phase = 0;
     HotStrip sp;
     if (!hot_strip(hg, sp))
         return;
@@ -563,7 +598,6 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
     const int qstep = ZSTEP * kT * 32 * hg.ncpx;
     const int oz0 = sp.tz * kT + zq;
     const bool vy = oy < hg.out_len[1];
-    int phase = 0;
 
     for (int ti = 0; ti < ntile; ++ti) {
         int* red = sred + (ti % 3) * 8;
@@ -791,7 +825,7 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
             if constexpr (ORDER == 3) {
                 switch (atoi(getenv("EDHIP_HOT_ABL"))) {
 #define ED_ABL_CASE(A) case A: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, A>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
-                ED_ABL_CASE(256) ED_ABL_CASE(258) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
+                ED_ABL_CASE(16) ED_ABL_CASE(1024) ED_ABL_CASE(4096) ED_ABL_CASE(5120) ED_ABL_CASE(7168) ED_ABL_CASE(3072) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
 #undef ED_ABL_CASE
                 default: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
                 }
@@ -822,6 +856,16 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box)
     // forward: two shifted float copies; 4 workgroups per CU -> 40960 bytes each (wide control
     // grids: a 64 KiB block, fewer workgroups per CU)
     size_t budget = 40 * 1024;
+    if (const char* abl = getenv("EDHIP_HOT_ABL")) {      // experiments (see hot_fwd_kernel)
+        const int a = atoi(abl);
+        if (a & 1024) {                                    // Q rows stay in global memory
+            *off_box = kOffQ;
+            size_t cap = (((a & 2048) ? 32 : 40) * 1024 - kOffQ) / 8;
+            cap = ((cap - 56) / 64) * 64 + 56;
+            *box_cap = (int)cap;
+            return kOffQ + 2 * 4 * cap;
+        }
+    }
     if (off + 2 * 4 * 2488 > budget)
         budget = 64 * 1024;
     if (off + 2 * 4 * 2488 > budget)

@@ -1230,15 +1230,15 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         return e;
     }
     // ---- level 1: strips, small boxes, highest occupancy ------------------------------------------
+    bool hot_done = false;
+    HotGeom hg;
     profile_mark(false, stream);
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips * nb + 7) / 8) * 8);
         constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
-        bool hot_done = false;
         if constexpr (std::is_same<T, float>::value && ORDER >= 1) {
             // float32, unit stride along x on both sides: the benchmark kernels of deform_hot.hip
             if (tg.in_stride[2] == 1 && tg.out_stride[2] == 1 && !(tg.dbg & 512) && !getenv("EDHIP_NO_HOT")) {
-                HotGeom hg;
                 memset(&hg, 0, sizeof(hg));
                 hg.vol_r = reinterpret_cast<const float*>(ve.in);
                 hg.vol_w = reinterpret_cast<float*>(const_cast<char*>(ve.in));
@@ -1289,6 +1289,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     else if (he != hipErrorNotSupported)
                         e = he;
                 }
+
             }
         }
         if (hot_done || e != hipSuccess)
