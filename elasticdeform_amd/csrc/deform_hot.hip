@@ -339,6 +339,8 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
     HotStrip sp;
     if (!hot_strip(hg, sp))
         return;
+    // (per-workgroup issue priorities (s_setprio) and a staggered start of the workgroups of a CU, to
+    // push co-resident workgroups into complementary phases, were tried: no change)
     hot_prologue(hg, sp, smem, !QGLOBAL);
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
