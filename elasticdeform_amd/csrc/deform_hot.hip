@@ -104,7 +104,7 @@ __device__ __forceinline__ bool hot_strip(const HotGeom& hg, HotStrip& sp)
 }
 
 __device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& sp, char* smem,
-                                             bool copy_q = true)
+                                             bool copy_q = true, int nthreads = kBlock)
 {
     const int tid = threadIdx.x;
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
@@ -112,10 +112,10 @@ __device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& 
         const int* src = reinterpret_cast<const int*>(hg.xt + sp.tx0 * kT);
         int* dst = reinterpret_cast<int*>(smem + kOffTabX);
         const int avail = (hg.out_len[2] - sp.tx0 * kT) * 12;
-        for (int e = tid; e < kStrip * kT * 12; e += kBlock)
+        for (int e = tid; e < kStrip * kT * 12; e += nthreads)
             dst[e] = e < avail ? src[e] : 0;
     }
-    if (copy_q) {   // Q rows: (zi, yy) -> (oz, oy); 4 threads per row, 16 bytes at a time
+    if (copy_q && tid < 256) {   // Q rows: (zi, yy) -> (oz, oy); 4 threads per row, 16 bytes at a time
         const int row16 = 2 * hg.ncpx;                   // 16-byte pieces per row (32 bytes per column)
         const int r = tid >> 2;
         const int oz = min(sp.tz * kT + (r >> 3), hg.out_len[0] - 1);
@@ -222,13 +222,14 @@ __device__ __forceinline__ void hot_step_offsets(const HotParams* hp, long long 
 // 64-tap (order 3) separable gather of one voxel from the staged box; PITCH is a template argument so
 // that the row offsets are immediates.  `bp` points at tap (0, 0, 0) in the copy whose shift matches
 // the parity of the window's x start: every x-run is a sequence of aligned ds_read_b64.
-template <int ORDER, int PITCH, bool FENCE = false>
+template <int ORDER, int PITCH, bool FENCE = false, int DUP = 0>
 __device__ __forceinline__ float hot_gather(const float* bp, int plane, const float* w0, const float* w1,
                                             const float* w2)
 {
     constexpr int NT = ORDER + 1;
     constexpr int NTX = NT + (NT & 1);
     float a0 = 0.f;
+    float d0 = 0.f;      // DUP (experiment): a second, independent copy of the arithmetic / of the reads
 #pragma unroll
     for (int l0 = 0; l0 < NT; ++l0) {
         const float* pp = bp + l0 * plane;
@@ -236,7 +237,7 @@ __device__ __forceinline__ float hot_gather(const float* bp, int plane, const fl
 #pragma unroll
         for (int l1 = 0; l1 < NT; ++l1) {
             const float* rp = pp + l1 * PITCH;
-            float a2 = 0.f;
+            float a2 = 0.f, d2 = 0.f;
 #pragma unroll
             for (int l2 = 0; l2 < NTX; l2 += 2) {
                 const float2 pr = *reinterpret_cast<const float2*>(rp + l2);
@@ -244,12 +245,22 @@ __device__ __forceinline__ float hot_gather(const float* bp, int plane, const fl
                     ED_NO_DS_MERGE();
                 a2 = fmaf(w2[l2], pr.x, a2);
                 a2 = fmaf(w2[l2 + 1], pr.y, a2);
+                if (DUP == 1) {          // twice the FMAs on the same data
+                    d2 = fmaf(w1[l2 % NT], pr.x, d2);
+                    d2 = fmaf(w0[(l2 + 1) % NT], pr.y, d2);
+                }
+                if (DUP == 2) {          // twice the LDS reads (a second box row), one extra add
+                    const float2 qr = *reinterpret_cast<const float2*>(rp + l2 + 4 * PITCH * 0 + plane * 4);
+                    d2 += qr.x;
+                }
             }
             a1 = fmaf(w1[l1], a2, a1);
+            if (DUP)
+                d0 = fmaf(w1[l1], d2, d0);
         }
         a0 = fmaf(w0[l0], a1, a0);
     }
-    return a0;
+    return DUP ? a0 + d0 * 1e-30f : a0;
 }
 
 // ================================================================================================
@@ -266,12 +277,12 @@ __device__ __forceinline__ void glds16(const float* g, float* lds)
 
 // phases A + B of one tile for this lane's two voxels: coordinates, then the bounding box of the
 // tile's tap windows reduced into the LDS slots `red` (min x3, max x3)
-template <int ORDER, bool AFFINE, int ABL>
+template <int ORDER, bool AFFINE, int ABL, int NV>
 __device__ __forceinline__ void hot_tile_coords(const HotGeom& hg, const HotParams* hp, const AxTab* tabx,
-                                                int* red, const char* const (&qrow)[2], const int (&oz)[2],
-                                                int oy, int ox0, int xx, int lane, const bool (&vzy)[2],
-                                                const double (&Pzy)[3][2], int (&start)[2][3],
-                                                float (&frac)[2][3], bool (&valid)[2], bool (&constant)[2])
+                                                int* red, const char* const (&qrow)[NV], const int (&oz)[NV],
+                                                int oy, int ox0, int xx, int lane, const bool (&vzy)[NV],
+                                                const double (&Pzy)[3][NV], int (&start)[NV][3],
+                                                float (&frac)[NV][3], bool (&valid)[NV], bool (&constant)[NV])
 {
     constexpr int kPadX = (ORDER + 1) & 1;
     const int ox = ox0 + xx;
@@ -289,7 +300,7 @@ __device__ __forceinline__ void hot_tile_coords(const HotGeom& hg, const HotPara
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
     int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int b[3] = {oz[i] + hg.off[0], oy + hg.off[1], ox + hg.off[2]};
         double P[3] = {0.0, 0.0, 0.0};
         if (AFFINE) {
@@ -326,9 +337,12 @@ __device__ __forceinline__ void hot_tile_coords(const HotGeom& hg, const HotPara
 // Tile loop, software-pipelined: once the box of tile t is known its staging copies are issued as
 // asynchronous LDS-DMA, and the coordinates + bounding box of tile t + 1 are computed while they are
 // in flight; the gather of tile t follows the barrier that retires the copies.
-template <int ORDER, bool AFFINE, int ABL = 0>
-__global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(const HotGeom hg)
+template <int ORDER, bool AFFINE, int ABL = 0, int NTH = kBlock, int WAVES = ((ABL & 2048) ? 5 : 4)>
+__global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
 {
+    // NTH = 256: two voxels per lane (z = wave, wave + 4); NTH = 512: one voxel per lane, eight waves
+    constexpr int NV = 512 / NTH;
+    constexpr int NW = NTH / 64;
     // coordinates of tile t + 1 computed under tile t's copies (orders 4 / 5: the extra live state spills)
     constexpr bool PIPE = !(ABL & 4096) && ORDER <= 3;
     constexpr bool QGLOBAL = (ABL & 1024) != 0; // experiment: Q rows read from global memory (L1), not LDS
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
         return;
     // (per-workgroup issue priorities (s_setprio) and a staggered start of the workgroups of a CU, to
     // push co-resident workgroups into complementary phases, were tried: no change)
-    hot_prologue(hg, sp, smem, !QGLOBAL);
+    hot_prologue(hg, sp, smem, !QGLOBAL, NTH);
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
@@ -358,12 +372,12 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
 
     // per-lane values that stay fixed along the strip
     const int oy = sp.ty * kT + yy;
-    const char* qrow[2];
-    int oz[2], obase[2];
-    bool vzy[2];
+    const char* qrow[NV];
+    int oz[NV], obase[NV];
+    bool vzy[NV];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int zi = wave + 4 * i;
+    for (int i = 0; i < NV; ++i) {
+        const int zi = wave + NW * i;
         oz[i] = sp.tz * kT + zi;
         if (QGLOBAL)
             qrow[i] = reinterpret_cast<const char*>(
@@ -374,27 +388,32 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
         vzy[i] = oz[i] < hg.out_len[0] && oy < hg.out_len[1];
         obase[i] = oz[i] * hg.img_sz + oy * hg.img_sy + sp.tx0 * kT + xx;
     }
-    double Pzy[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};     // affine: A[h][0] oz + A[h][1] oy + A[h][3] + off_h
+    double Pzy[3][NV];     // affine: A[h][0] oz + A[h][1] oy + A[h][3] + off_h
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            Pzy[h][i] = 0.0;
     if (AFFINE) {
 #pragma unroll
         for (int h = 0; h < 3; ++h)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NV; ++i)
                 Pzy[h][i] = fma(hp->affine[h * 4 + 0], (double)oz[i],
                                 fma(hp->affine[h * 4 + 1], (double)oy, hp->affine[h * 4 + 3] + hp->offd[h]));
     }
 
-    int start[2][3];
-    float frac[2][3];
-    bool valid[2], constant[2];
+    int start[NV][3];
+    float frac[NV][3];
+    bool valid[NV], constant[NV];
     if (PIPE)
-        hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx, sred, qrow, oz, oy, sp.tx0 * kT, xx, lane, vzy, Pzy,
+        hot_tile_coords<ORDER, AFFINE, ABL, NV>(hg, hp, tabx, sred, qrow, oz, oy, sp.tx0 * kT, xx, lane, vzy, Pzy,
                                             start, frac, valid, constant);
 
     for (int ti = 0; ti < sp.ntile; ++ti) {
         int* red = sred + (ti % 3) * 8;
         if (!PIPE)
-            hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx + ti * kT, red, qrow, oz, oy, (sp.tx0 + ti) * kT, xx,
+            hot_tile_coords<ORDER, AFFINE, ABL, NV>(hg, hp, tabx + ti * kT, red, qrow, oz, oy, (sp.tx0 + ti) * kT, xx,
                                                 lane, vzy, Pzy, start, frac, valid, constant);
         __syncthreads();   // B1: box known; every gather of the previous tile is done
         int b0[3] = {red[0], red[1], red[2]};
@@ -440,7 +459,7 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
                 // two ds_write_b128 instead of two LDS-DMA copies: 248 us against 240 us (not used).
                 const int q = tid & 3;
                 const float inv_by = 1.0f / (float)by;
-                for (int r = tid >> 2; r < nrows; r += kBlock / 4) {
+                for (int r = tid >> 2; r < nrows; r += NTH / 4) {
                     const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                     const float* g = src + ((b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2] + 4 * q);
                     const F4u v0 = *reinterpret_cast<const F4u*>(g);
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
                 const int lrow = pitch == 16 ? lane >> 2 : (lane * 21846) >> 18;      // lane / 12
                 const int q = lane - lrow * cpr;
                 const float inv_by = 1.0f / (float)by;
-                for (int r0 = wave * RW; r0 < nrows; r0 += 4 * RW) {
+                for (int r0 = wave * RW; r0 < nrows; r0 += NW * RW) {
                     const int r = r0 + lrow;
                     const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                     if (lrow < RW && r < nrows && yr < ext[1]) {
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
                 // with the taps of a window that sticks out (deform.c:791-813)
                 const float inv_by = 1.0f / (float)by;
                 const int sub = tid & 7;
-                for (int r = tid >> 3; r < nrows; r += kBlock / 8) {
+                for (int r = tid >> 3; r < nrows; r += NTH / 8) {
                     const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                     if (yr >= ext[1])
                         continue;            // padding row of the plane
@@ -498,11 +517,14 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
             stage(vol + vol_off);
 
         // ---- phases A + B of the NEXT tile, while the copies are in flight ------------------------
-        int nstart[2][3];
-        float nfrac[2][3];
-        bool nvalid[2] = {false, false}, nconstant[2] = {false, false};
+        int nstart[NV][3];
+        float nfrac[NV][3];
+        bool nvalid[NV], nconstant[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            nvalid[i] = nconstant[i] = false;
         if (PIPE && ti + 1 < sp.ntile)
-            hot_tile_coords<ORDER, AFFINE, ABL>(hg, hp, tabx + (ti + 1) * kT, sred + ((ti + 1) % 3) * 8, qrow, oz,
+            hot_tile_coords<ORDER, AFFINE, ABL, NV>(hg, hp, tabx + (ti + 1) * kT, sred + ((ti + 1) % 3) * 8, qrow, oz,
                                                 oy, (sp.tx0 + ti + 1) * kT, xx, lane, vzy, Pzy, nstart, nfrac,
                                                 nvalid, nconstant);
 
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
                 // reads with the other's arithmetic, was tried: 128 VGPRs + 192 bytes of scratch, 407 us)
                 const int plane = by * pitch;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NV; ++i) {
                     if (!valid[i])
                         continue;
                     float val;
@@ -541,8 +563,9 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
                         const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1], rx = start[i][2] - b0[2];
                         // aligned pairs from the copy whose shift matches the parity of rx
                         const float* bp = ((rx & 1) ? box1 - 1 : box0) + ((rz * by + ry) * pitch + rx);
-                        val = pitch == 16 ? hot_gather<ORDER, 16, (ABL & 128) != 0>(bp, plane, w0, w1, w2)
-                                          : hot_gather<ORDER, 48, (ABL & 128) != 0>(bp, plane, w0, w1, w2);
+                        constexpr int DUP = (ABL & 8192) ? 1 : ((ABL & 16384) ? 2 : 0);
+                        val = pitch == 16 ? hot_gather<ORDER, 16, (ABL & 128) != 0, DUP>(bp, plane, w0, w1, w2)
+                                          : hot_gather<ORDER, 48, (ABL & 128) != 0, DUP>(bp, plane, w0, w1, w2);
                     }
                     // streaming store (a tile writes 32-byte row segments; see deform_tile.hip)
                     if (!(ABL & 64) || val == -12345.678f)
@@ -552,7 +575,7 @@ __global__ __launch_bounds__(kBlock, (ABL & 2048) ? 5 : 4) void hot_fwd_kernel(c
         }
         if (PIPE) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 valid[i] = nvalid[i];
                 constant[i] = nconstant[i];
 #pragma unroll
@@ -827,12 +850,16 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
             if constexpr (ORDER == 3) {
                 switch (atoi(getenv("EDHIP_HOT_ABL"))) {
 #define ED_ABL_CASE(A) case A: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, A>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
-                ED_ABL_CASE(16) ED_ABL_CASE(1024) ED_ABL_CASE(4096) ED_ABL_CASE(5120) ED_ABL_CASE(7168) ED_ABL_CASE(3072) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
+                ED_ABL_CASE(8192) ED_ABL_CASE(16384) ED_ABL_CASE(16512) ED_ABL_CASE(128) ED_ABL_CASE(16) ED_ABL_CASE(1024) ED_ABL_CASE(4096) ED_ABL_CASE(5120) ED_ABL_CASE(7168) ED_ABL_CASE(3072) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
 #undef ED_ABL_CASE
                 default: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
                 }
             }
-        } else
+        } else if (getenv("EDHIP_HOT_NTH512") && atoi(getenv("EDHIP_HOT_NTH512")) == 8)
+            hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, 0, 512, 8>), dim3(nblk), dim3(512), lds, stream, hg);
+        else if (getenv("EDHIP_HOT_NTH512"))
+            hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, 0, 512, 6>), dim3(nblk), dim3(512), lds, stream, hg);
+        else
             hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg);
     }
     return hipGetLastError();

@@ -72,7 +72,7 @@ enum {
     L_READ_B64, L_READ_B64_MIS, L_READ2_B32_MIS, L_READ_B32, L_READ_B128, L_ADD_U32, L_ADD_U32_16OF64, L_ADD_U32_Q1,
     L_ADD_RTN, L_ADD_K16, L_ADD_K32, L_ADD_SAME2, L_ADD_SAME4, L_ADD_STRIDE2, L_ADD_U32_FIRST16, L_READ_B64_RAND,
     L_READ2_B64, L_READ_B64_X2, L_ADD_K16_64, L_ADD_K32_64, L_ADD_ROWS24, L_ADD_ROWS16, L_ADD_ROWS48, L_ADD_ROWS40,
-    L_READ_B64_2WAY, L_READ_B64_ROWS, L_WRITE_B128, L_NTESTS
+    L_READ_B64_2WAY, L_READ_B64_ROWS, L_WRITE_B128, L_READ_B64_Q4, L_READ_B128_Q4, L_READ_B64_BCAST, L_NTESTS
 };
 static const char* kLNames[] = {
     "ds_read_b64 aligned", "ds_read_b64 4B-misaligned", "ds_read2_b32 4B-aligned pair", "ds_read_b32", "ds_read_b128",
@@ -84,7 +84,9 @@ static const char* kLNames[] = {
     "ds_add_u32 16-lane groups 64 dwords apart", "ds_add_u32 32-lane groups 64 dwords apart",
     "ds_add_u32 4 rows of 16, pitch 24", "ds_add_u32 4 rows of 16, pitch 16", "ds_add_u32 4 rows of 16, pitch 48",
     "ds_add_u32 4 rows of 16, pitch 40", "ds_read_b64 2-way bank conflict (lane, lane+16 same banks)",
-    "ds_read_b64 8 rows x 8 lanes pitch 16 dwords (K1 regular)", "ds_write_b128"};
+    "ds_read_b64 8 rows x 8 lanes pitch 16 dwords (K1 regular)", "ds_write_b128",
+    "ds_read_b64 every 4th lane active", "ds_read_b128 every 4th lane active",
+    "ds_read_b64 8 lanes per address (broadcast)"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void lds_kernel(float* out, int iters, long long* cyc)
@@ -119,11 +121,15 @@ __global__ __launch_bounds__(256) void lds_kernel(float* out, int iters, long lo
     case L_READ_B64_2WAY: addr = base + ((lane & 15) * 2 + (lane >> 4) * 64) * 4; break;
     case L_READ_B64_ROWS: addr = base + ((lane & 7) * 2 + (lane >> 3) * 16) * 4; break;
     case L_WRITE_B128: addr = base + lane * 16; break;
+    case L_READ_B64_Q4: addr = base + lane * 8; break;
+    case L_READ_B128_Q4: addr = base + lane * 16; break;
+    case L_READ_B64_BCAST: addr = base + (lane >> 3) * 160; break;
     default: addr = base + lane * 4; break;
     }
     bool on = true;
     if (OP == L_ADD_U32_16OF64) on = (lane & 3) == 0;
     if (OP == L_ADD_U32_Q1 || OP == L_ADD_U32_FIRST16) on = lane < 16;
+    if (OP == L_READ_B64_Q4 || OP == L_READ_B128_Q4) on = (lane & 3) == 0;
     unsigned acc = 0;
     unsigned long long acc64 = 0;
     long long t0 = __builtin_readcyclecounter();
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void lds_kernel(float* out, int iters, long lo
                 for (int k = 0; k < 8; ++k)
                     acc64 += v[k];
             } else if (OP == L_READ_B64 || OP == L_READ_B64_MIS || OP == L_READ_B64_RAND || OP == L_READ_B64_2WAY ||
-                       OP == L_READ_B64_ROWS) {
+                       OP == L_READ_B64_ROWS || OP == L_READ_B64_Q4 || OP == L_READ_B64_BCAST) {
                 unsigned long long v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256) void lds_kernel(float* out, int iters, long lo
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     acc += v[k];
-            } else if (OP == L_READ_B128) {
+            } else if (OP == L_READ_B128 || OP == L_READ_B128_Q4) {
                 typedef unsigned u4 __attribute__((ext_vector_type(4)));
                 u4 v[4];
 #pragma unroll
@@ -264,7 +270,7 @@ static int run_lds(float* out, long long* cyc, hipEvent_t a, hipEvent_t b)
                 CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
             }
         }
-        const int per_it = (OP == L_READ_B128 || OP == L_READ2_B64 || OP == L_WRITE_B128) ? 4 : 8;
+        const int per_it = (OP == L_READ_B128 || OP == L_READ2_B64 || OP == L_WRITE_B128 || OP == L_READ_B128_Q4) ? 4 : 8;
         const double instr_cu = (double)iters * per_it * 4 * occ;      // wave-instructions per CU
         printf("%-58s waves/CU=%2d  %8.3f ms  ns per wave-instr per CU %6.3f  (x2.4 = %5.2f cycles)\n",
                kLNames[OP], 4 * occ, best, best * 1e6 / instr_cu, best * 1e6 / instr_cu * 2.4);
