@@ -23,6 +23,11 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err);
 // Drains the devices that own scratch and frees every cached buffer.
 void workspace_release_all();
 
+// Requests above 320 MiB are served by a stream-ordered allocation (hipMallocAsync) that is not
+// cached: workspace_trim() -- called when an API call has enqueued its work -- releases it with
+// hipFreeAsync behind the kernels that use it.
+void workspace_trim(hipStream_t stream);
+
 // Serialises the host side of API calls that target the same (device, stream): the workspace of a
 // stream is shared by consecutive calls (control grid, tables, spill lists), so two host threads
 // enqueueing on ONE stream -- torch's default stream is shared by all Python threads, and ctypes
@@ -39,6 +44,7 @@ public:
 
 private:
     void* mutex_;
+    hipStream_t stream_;
 };
 
 }  // namespace ed

@@ -11,14 +11,19 @@ namespace {
 struct Buffer {
     void* ptr = nullptr;
     size_t cap = 0;
+    bool transient = false;      // allocated stream-ordered for one oversized call; freed by workspace_trim
 };
+// Requests above this are not kept: the float32 order-4/5 cascade asks for a dense temporary of the
+// array's size (up to 1 GiB here) and the exact filter for 256 MiB; cached per stream they stay
+// pinned until edhip_release_scratch and a job with many streams can run out of memory.
+constexpr size_t kKeepBytes = (size_t)320 << 20;
 std::mutex g_mutex;
 std::map<std::pair<int, hipStream_t>, Buffer> g_buffers;
 // one host-side lock per (device, stream); entries are never erased, so the pointers stay valid
 std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::recursive_mutex>> g_stream_locks;
 }  // namespace
 
-StreamGuard::StreamGuard(hipStream_t stream) : mutex_(nullptr)
+StreamGuard::StreamGuard(hipStream_t stream) : mutex_(nullptr), stream_(stream)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -36,8 +41,10 @@ StreamGuard::StreamGuard(hipStream_t stream) : mutex_(nullptr)
 
 StreamGuard::~StreamGuard()
 {
-    if (mutex_)
+    if (mutex_) {
+        workspace_trim(stream_);         // an oversized scratch buffer does not outlive its call
         static_cast<std::recursive_mutex*>(mutex_)->unlock();
+    }
 }
 
 void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
@@ -54,16 +61,34 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
     if (b.cap >= bytes && b.ptr)
         return b.ptr;
     if (b.ptr) {
-        // earlier kernels on this stream may still be using the old buffer
-        e = hipStreamSynchronize(stream);
-        if (e == hipSuccess)
-            e = hipFree(b.ptr);
+        if (b.transient) {
+            e = hipFreeAsync(b.ptr, stream);      // stream-ordered behind the kernels that used it
+        } else {
+            // earlier kernels on this stream may still be using the old buffer: the one place where
+            // the library waits for the stream (documented in edhip.h)
+            e = hipStreamSynchronize(stream);
+            if (e == hipSuccess)
+                e = hipFree(b.ptr);
+        }
         b.ptr = nullptr;
         b.cap = 0;
+        b.transient = false;
         if (e != hipSuccess) {
             *err = e;
             return nullptr;
         }
+    }
+    if (bytes > kKeepBytes) {
+        // oversized, one call only: stream-ordered allocation, released by workspace_trim() when the
+        // call has enqueued its work (no host synchronisation, nothing stays pinned)
+        e = hipMallocAsync(&b.ptr, bytes, stream);
+        if (e == hipSuccess) {
+            b.cap = bytes;
+            b.transient = true;
+            return b.ptr;
+        }
+        (void)hipGetLastError();
+        b.ptr = nullptr;             // fall through to the plain allocation
     }
     // grow geometrically, 1 MiB granularity
     size_t want = bytes + bytes / 4;
@@ -83,6 +108,21 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
     return b.ptr;
 }
 
+void workspace_trim(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_buffers.find(std::make_pair(dev, stream));
+    if (it == g_buffers.end() || !it->second.ptr || !it->second.transient)
+        return;
+    (void)hipFreeAsync(it->second.ptr, stream);
+    it->second.ptr = nullptr;
+    it->second.cap = 0;
+    it->second.transient = false;
+}
+
 void workspace_release_all()
 {
     int cur = 0;
@@ -95,7 +135,10 @@ void workspace_release_all()
         // already have been destroyed by its owner, so the whole device is drained)
         if (hipSetDevice(kv.first.first) == hipSuccess) {
             (void)hipDeviceSynchronize();
-            (void)hipFree(kv.second.ptr);
+            if (kv.second.transient)
+                (void)hipFreeAsync(kv.second.ptr, kv.first.second);
+            else
+                (void)hipFree(kv.second.ptr);
         }
         kv.second.ptr = nullptr;
         kv.second.cap = 0;

@@ -8,7 +8,13 @@ What differs is where the work happens: every array is (moved to) MI355X HBM and
 pipeline -- B-spline prefilter of the inputs and of the displacement grid, the per-voxel
 deformation, and for the gradient the scatter-add plus the transposed prefilter -- runs as
 hand-written HIP kernels behind the C ABI of include/edhip.h, enqueued on the current HIP stream
-with no host synchronisation.
+with no host synchronisation (one exception, documented in include/edhip.h: the first call on a
+stream that needs more scratch than that stream's cached workspace holds waits for the stream once).
+
+Limits that differ from the reference (status EDHIP_ERR_UNSUPPORTED / EDHIP_ERR_INVALID ->
+RuntimeError): at most 4 deformed axes (the reference takes any number, _deform_grid.c:158-175) and
+8 array dimensions; a deformed axis of length 1 is refused (the reference divides by I - 1 = 0 there,
+deform.c:643, and yields inf / NaN coordinates that map to cval).
 
 * numpy.ndarray in  -> numpy.ndarray out (one H2D and one D2H copy; the drop-in path)
 * torch.Tensor in   -> torch.Tensor out on the same device (CUDA tensors never touch the host)

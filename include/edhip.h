@@ -29,7 +29,12 @@
  * Ownership: the caller allocates every array; the library borrows them for the duration of the
  * enqueued work and owns only a small scratch workspace per (device, stream), grown on demand.
  * Calls are asynchronous with respect to the host: work is enqueued on `hip_stream` and the
- * function returns; there is no implicit device synchronisation.  Apart from that mutex-guarded
+ * function returns; there is no implicit device synchronisation -- with one exception: when a call
+ * needs MORE scratch than the stream's cached workspace holds, growing it waits for that stream once
+ * (hipStreamSynchronize + hipFree + hipMalloc; not allowed under stream capture: warm the workspace
+ * up with one call before capturing).  Requests above 320 MiB (the dense temporary of the float32
+ * order-4/5 prefilter cascade on long lines, the fp64 line buffer of the exact filter on large
+ * arrays) are stream-ordered allocations that are released when the call has enqueued its work.  Apart from that mutex-guarded
  * workspace cache the library keeps no mutable global state, so it is re-entrant and may be
  * called concurrently from several host threads on different streams / devices
  * (reference: single-threaded, GIL released for the whole call, deform.c:377-379).
