@@ -44,7 +44,10 @@ constexpr int kGradBoxBytes = 24 * 1024;       // K2: fixed-point cells per tile
 // (4 instructions instead of 1) and wraps the single-lane atomics in a wave-reduction loop -- together
 // ~200 instructions per wave and tile, a quarter of the kernel's VALU work.  The six chains are
 // interleaved, which also covers the DPP read-after-write hazard (2 wait states) without s_nop.
-// All 64 lanes must be active.
+// All 64 lanes must be active.  The LDS atomics are issued from inline assembly, which the compiler's
+// s_waitcnt bookkeeping does not see: every barrier that publishes the slots is preceded by
+// lds_atomics_done() (without it the barrier can be passed while they are still in flight -- found
+// by tests/fuzz/fuzz_hot.py as rare garbage voxels in the non-pipelined order-4 / 5 builds).
 #define ED_RED6(OP, CTRL)                                  \
     "v_min_i32_dpp %0, %0, %0 " CTRL "\n\t"                \
     "v_min_i32_dpp %1, %1, %1 " CTRL "\n\t"                \
@@ -76,6 +79,7 @@ __device__ __forceinline__ void box_reduce_to_lds(int* red, int lane, int (&lo)[
     }
 }
 #undef ED_RED6
+__device__ __forceinline__ void lds_atomics_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ---- strip prologue: x table, Q rows, uniform parameters -> LDS ----------------------------------------
 struct HotStrip {
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         if (!PIPE)
             hot_tile_coords<ORDER, AFFINE, ABL, NV>(hg, hp, tabx + ti * kT, red, qrow, oz, oy, (sp.tx0 + ti) * kT, xx,
                                                 lane, vzy, Pzy, start, frac, valid, constant);
+        lds_atomics_done();
         __syncthreads();   // B1: box known; every gather of the previous tile is done
         int b0[3] = {red[0], red[1], red[2]};
         int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
@@ -672,6 +677,7 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
             }
         }
         box_reduce_to_lds(red, lane, lo, hi);
+        lds_atomics_done();
         __syncthreads();   // B1: box known; the previous tile's flush is done
         const int b0[3] = {red[0], red[1], red[2]};
         const int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};

@@ -69,10 +69,18 @@ for case in range(ncases):
             dY = rng.random(want.shape).astype(dtype)
             gw = orc.deform_grid_gradient(dY, disp, X_shape=full, **kw)
             gg = ed.deform_grid_gradient(dY, disp, X_shape=full, **kw)
-            amp = 8.0 ** nd if (order > 1 and kw["prefilter"]) else 1.0
             gs = max(1.0, float(np.abs(gw).max())) if gw.size else 1.0
             err = float(np.abs(gg.astype(np.float64) - gw.astype(np.float64)).max()) if gw.size else 0.0
-            assert err <= tol * amp * gs * 2, "gradient max abs err %.3e (scale %.3g, amp %g)" % (err, gs, amp)
+            if dtype == np.float32 and gw.size:
+                # measured bound (tests/test_gpu_parity.py:_f32_grad_check): no further from the exact
+                # gradient than 4x the reference's own float32 evaluation
+                truth = orc.deform_grid_gradient(dY.astype(np.float64), disp, X_shape=full, **kw)
+                eref = float(np.abs(gw.astype(np.float64) - truth).max())
+                egpu = float(np.abs(gg.astype(np.float64) - truth).max())
+                assert egpu <= 4 * eref + 4 * np.finfo(np.float32).eps * gs, \
+                    "gradient err vs exact %.3e, reference's own %.3e (scale %.3g)" % (egpu, eref, gs)
+            else:
+                assert err <= tol * gs * 2, "gradient max abs err %.3e (scale %.3g)" % (err, gs)
         else:
             np.testing.assert_array_equal(got, want)
     except Exception as e:      # noqa: BLE001

@@ -857,3 +857,24 @@ def test_reduced_precision_io_opt_in():
     finally:
         ed.set_reduced_precision(prev)
         ed.set_arithmetic("auto")
+
+
+@pytest.mark.parametrize("order", [4, 5, 3])
+def test_box_reduction_barrier_regression(order):
+    """Regression for a race found by tests/fuzz/fuzz_hot.py: the hot kernels fold a wave's
+    bounding box into LDS with atomics issued from inline assembly, which the compiler's s_waitcnt
+    bookkeeping does not see -- the barrier that publishes the box could be passed while they were
+    in flight (non-pipelined order-4 / 5 builds: rare NaN / garbage voxels under load).  Repeated
+    runs of a loaded launch must be bit-identical to each other and to the per-sample calls."""
+    rng = np.random.default_rng(16)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, shape, pts = 5, (73, 46, 60), (4, 5, 5)
+    X = torch.from_numpy(rng.random((B,) + shape).astype(np.float32)).to(dev)
+    D = torch.from_numpy(rng.standard_normal((B, 3) + pts) * 2.0).to(dev)
+    kw = dict(order=order, mode="nearest", prefilter=False)
+    one = torch.stack([ed.deform_grid(X[k], D[k], **kw) for k in range(B)])
+    assert torch.isfinite(one).all()
+    np.testing.assert_allclose(one[2].cpu().numpy(), orc.deform_grid(X[2].cpu().numpy(), D[2].cpu().numpy(), **kw),
+                               **F32_TOL)
+    for _ in range(6):
+        assert torch.equal(ed.deform_grid_batch(X, D, **kw), one)
