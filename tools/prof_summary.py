@@ -21,7 +21,8 @@ def main(db, out=None):
     for r in rows:
         lines.append("%-8.2f %-7d %-12.1f %-10.2f %-10.2f %-10.2f %-5s %-5s %-7s %-8s %-10s %-5s %s"
                      % (100.0 * r[2] / total, r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3,
-                        r[6], r[7], r[8], r[9], r[10], r[11], r[0]))
+                        r[6], r[7], r[8], r[9], r[10], r[11],
+                        r[0] if len(r[0]) <= 200 else r[0][:197] + "..."))
     text = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(text)
