@@ -29,6 +29,15 @@
 #include "ed_params.h"
 #include "ed_tile.h"
 
+#ifndef ED_K2_U1
+#define ED_K2_U1 1
+#endif
+#ifndef ED_K2_U2
+#define ED_K2_U2 1
+#endif
+#define ED_PRAGMA(x) _Pragma(#x)
+#define ED_UNROLL(n) ED_PRAGMA(unroll n)
+
 namespace ed {
 namespace tile {
 
@@ -79,19 +88,24 @@ __device__ __forceinline__ void box_reduce_to_lds(int* red, int lane, int (&lo)[
     }
 }
 #undef ED_RED6
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ void lds_atomics_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every wave
+// would sit out the round trip of the global stores / atomics it has just issued (about 2-4 us per
+// tile) although nothing in the workgroup reads those addresses back.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- strip prologue: x table, Q rows, uniform parameters -> LDS ----------------------------------------
 struct HotStrip {
     int tz, ty, tx0, ntile, sample;
 };
 
-__device__ __forceinline__ bool hot_strip(const HotGeom& hg, HotStrip& sp)
+__device__ __forceinline__ bool hot_strip(const HotGeom& hg, HotStrip& sp, int b)
 {
     // (a second level with these kernels -- one spilled tile per work item in a 64 KiB block -- was
     // tried and lost to the general level-2 kernel: a full prologue per tile, two workgroups per CU)
     // strips are dealt to the 8 XCDs in contiguous chunks (block b runs on XCD b % 8)
-    const int b = blockIdx.x;
     const int per = (hg.total_strips + 7) >> 3;
     int s = (b & 7) * per + (b >> 3);
     if (s >= hg.total_strips)
@@ -107,10 +121,9 @@ __device__ __forceinline__ bool hot_strip(const HotGeom& hg, HotStrip& sp)
     return true;
 }
 
-__device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& sp, char* smem,
+__device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& sp, char* smem, int tid,
                                              bool copy_q = true, int nthreads = kBlock)
 {
-    const int tid = threadIdx.x;
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
     {   // x table: 64 entries x 48 bytes = 768 dwords
         const int* src = reinterpret_cast<const int*>(hg.xt + sp.tx0 * kT);
@@ -355,11 +368,11 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
     constexpr int NTX = NT + kPadX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     HotStrip sp;
-    if (!hot_strip(hg, sp))
+    if (!hot_strip(hg, sp, blockIdx.x))
         return;
     // (per-workgroup issue priorities (s_setprio) and a staggered start of the workgroups of a CU, to
     // push co-resident workgroups into complementary phases, were tried: no change)
-    hot_prologue(hg, sp, smem, !QGLOBAL, NTH);
+    hot_prologue(hg, sp, smem, threadIdx.x, !QGLOBAL, NTH);
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
             hot_tile_coords<ORDER, AFFINE, ABL, NV>(hg, hp, tabx + ti * kT, red, qrow, oz, oy, (sp.tx0 + ti) * kT, xx,
                                                 lane, vzy, Pzy, start, frac, valid, constant);
         lds_atomics_done();
-        __syncthreads();   // B1: box known; every gather of the previous tile is done
+        if (hg.dbg & 2048) __syncthreads(); else lds_barrier();   // B1: box known; every gather of the previous tile is done
         int b0[3] = {red[0], red[1], red[2]};
         int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
         bool any = red[3] >= red[0];
@@ -598,24 +611,32 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
 // into fixed-point LDS cells with integer atomics and flushed with one float atomic per touched
 // source element (see deform_tile.hip for the scale's no-overflow bound).
 // ================================================================================================
-template <int ORDER, bool AFFINE, int GRAD_WAVES, int TX>
-__global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotGeom hg)
+template <int ORDER, bool AFFINE, int GRAD_WAVES, int TX, int NGRP = 1>
+__global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(const HotGeom hg)
 {
     constexpr int NT = ORDER + 1;
     constexpr int NV = TX / 4, ZSTEP = 8 / NV;       // TX 16: 4 voxels per lane; TX 8: 2
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem0[];
+    // NGRP 2 (experiment): two groups of four waves, each with a strip and an LDS region of its
+    // own, one barrier interval apart -- group 1 scatters (LDS atomics) while group 0 flushes and
+    // computes coordinates (VALU), instead of four workgroups marching through the phases together
+    const int grp = NGRP == 2 ? (int)(threadIdx.x >> 8) : 0;
+    const int tid = threadIdx.x & (kBlock - 1);
+    char* smem = smem0 + grp * hg.lds_grp;
     int phase = 0;
     HotStrip sp;
-    if (!hot_strip(hg, sp))
+    const int bidx = NGRP == 2 ? (int)(((blockIdx.x >> 3) * 2 + grp) * 8 + (blockIdx.x & 7)) : (int)blockIdx.x;
+    if (!hot_strip(hg, sp, bidx))
         return;
-    hot_prologue(hg, sp, smem);
+    hot_prologue(hg, sp, smem, tid);
+    if (NGRP == 2 && grp == 1)
+        __syncthreads();
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
     const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
     int* box = reinterpret_cast<int*>(smem + hg.off_box);
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int xx = tid & (TX - 1), yy = (tid / TX) & 7, zq = tid / (TX * 8);
@@ -633,6 +654,14 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
         int* red = sred + (ti % 3) * 8;
         const int ox = sp.tx0 * kT + ti * TX + xx;
         const bool vx = ox < hg.out_len[2];
+        const int ooff0 = oz0 * hg.img_sz + oy * hg.img_sy + ox;
+        const int ostep = ZSTEP * hg.img_sz;
+
+        // dY of the first step: issued here so that its HBM round trip runs under the coordinates
+        float gpre[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            gpre[i] = (vy && vx && oz0 + ZSTEP * i < hg.out_len[0]) ? dy[ooff0 + i * ostep] : 0.f;
 
         double tw[4];
         int tib[4];
@@ -651,13 +680,11 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
                 Pxy[h] = fma(hp->affine[h * 4 + 2], (double)ox,
                              fma(hp->affine[h * 4 + 1], (double)oy, hp->affine[h * 4 + 3] + hp->offd[h]));
         }
-        int start[NV][3];
-        float frac[NV][3];
-        bool active[NV];
-        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-        int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        // One voxel at a time, nothing kept per voxel: the window starts are computed here for the
+        // box and again in the scatter pass (the same instructions on the same inputs), so that the
+        // kernel holds one voxel's registers instead of four (it spilled 33-79 VGPRs to scratch,
+        // and every reload sat on the critical path of its wave).
+        auto voxel = [&](int i, int* start, float* frac) -> bool {
             const int oz = oz0 + ZSTEP * i;
             const int b[3] = {oz + hg.off[0], oy + hg.off[1], ox + hg.off[2]};
             double P[3] = {0.0, 0.0, 0.0};
@@ -666,22 +693,30 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
                 for (int h = 0; h < 3; ++h)
                     P[h] = fma(hp->affine[h * 4 + 0], (double)oz, Pxy[h]);
             }
-            const bool cst = hot_coords<ORDER, AFFINE>(hg, hp, qrow0 + i * qstep, tw, tib, b, P, start[i], frac[i]);
-            active[i] = vy && vx && oz < hg.out_len[0] && !cst;     // constant voxels contribute nothing (:928)
-            if (active[i]) {
+            const bool cst = hot_coords<ORDER, AFFINE>(hg, hp, qrow0 + i * qstep, tw, tib, b, P, start, frac);
+            return vy && vx && oz < hg.out_len[0] && !cst;     // constant voxels contribute nothing (:928)
+        };
+        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+ED_UNROLL(ED_K2_U1)
+        for (int i = 0; i < NV; ++i) {
+            int start[3];
+            float frac[3];
+            if (voxel(i, start, frac)) {
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
-                    lo[h] = min(lo[h], start[i][h]);
-                    hi[h] = max(hi[h], start[i][h] + ORDER);
+                    lo[h] = min(lo[h], start[h]);
+                    hi[h] = max(hi[h], start[h] + ORDER);
                 }
             }
         }
         box_reduce_to_lds(red, lane, lo, hi);
-        lds_atomics_done();
-        __syncthreads();   // B1: box known; the previous tile's flush is done
-        const int b0[3] = {red[0], red[1], red[2]};
-        const int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
-        const bool any = red[3] >= red[0];
+        lds_barrier();     // B1: box known; the previous tile's flush is done
+        // wave-uniform box: kept in SGPRs
+        const int b0[3] = {uni(red[0]), uni(red[1]), uni(red[2])};
+        const int bhi[3] = {uni(red[3]), uni(red[4]), uni(red[5])};
+        const int ext[3] = {bhi[0] - b0[0] + 1, bhi[1] - b0[1] + 1, bhi[2] - b0[2] + 1};
+        const bool any = bhi[0] >= b0[0];
         if (tid < 6)
             sred[((ti + 2) % 3) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
         if (!any)
@@ -703,17 +738,13 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
         }
         const bool interior = b0[0] >= 0 && b0[0] + ext[0] <= hg.in_len[0] && b0[1] >= 0 &&
                               b0[1] + ext[1] <= hg.in_len[1] && b0[2] >= 0 && b0[2] + ext[2] <= hg.in_len[2];
-        int ooff[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            ooff[i] = (oz0 + ZSTEP * i) * hg.img_sz + oy * hg.img_sy + ox;
 
         for (long long ss = 0; ss < hg.nsteps; ++ss, ++phase) {
             long long vol_off = 0, img_off = 0;
             if (hg.nstep)
                 hot_step_offsets(hp, ss, vol_off, img_off);
             if (ss > 0)
-                __syncthreads();         // previous step's flush is done with the box
+                lds_barrier();           // previous step's flush is done with the box
             // zero the accumulators
             for (int e = tid * 4; e < nbox; e += kBlock * 4)
                 *reinterpret_cast<int4*>(box + e) = make_int4(0, 0, 0, 0);
@@ -722,20 +753,49 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
             float* dst = dx + vol_off;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                gval[i] = active[i] ? dy[img_off + ooff[i]] : 0.f;
-                if ((__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000) {
-                    // inf / NaN gradient: no fixed-point scale exists -- this voxel scatters its
-                    // taps with float atomics straight to global memory (rare, rolled loops)
-                    float w0[NT], w1[NT], w2[NT];
-                    weights_from_frac<float, ORDER>(frac[i][0], w0);
-                    weights_from_frac<float, ORDER>(frac[i][1], w1);
-                    weights_from_frac<float, ORDER>(frac[i][2], w2);
+                const bool inb = vy && vx && oz0 + ZSTEP * i < hg.out_len[0];
+                gval[i] = ss == 0 ? gpre[i] : (inb ? dy[img_off + ooff0 + i * ostep] : 0.f);
+                // inf / NaN gradients have no fixed-point scale: left out of the sum, scattered with
+                // float atomics below
+                gm += (__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(gval[i]);
+            }
+            gm = wave_sum(gm);
+            float* gsum = reinterpret_cast<float*>(smem + kOffSum) + (phase & 1) * 4;
+            if (lane == 0)
+                gsum[wave] = gm;
+            lds_barrier();               // B2: box zeroed, sum known
+            const float gtot = unif((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
+            // |sum in a cell| <= max tap weight * sum over the tile of |dY|: this scale cannot overflow
+            constexpr double kWmax = ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : (ORDER == 3 ? 0.2963
+                                    : (ORDER == 4 ? 0.2150 : 0.1664));
+            const float scale = gtot > 0.f ? unif((float)((2147483648.0 - 1024.0) / (kWmax * 1.001 * (double)gtot))) : 0.f;
+            const float inv_scale = gtot > 0.f ? unif(1.f / scale) : 0.f;
+
+ED_UNROLL(ED_K2_U2)
+            for (int i = 0; i < NV; ++i) {
+                float gv = gval[0];
+#pragma unroll
+                for (int k = 1; k < NV; ++k)
+                    gv = i == k ? gval[k] : gv;
+                if (gv == 0.f || (hg.dbg & 128))
+                    continue;
+                int st[3];
+                float fr[3];
+                if (!voxel(i, st, fr))
+                    continue;
+                float w0[NT], w1[NT], w2[NT];
+                weights_from_frac<float, ORDER>(fr[0], w0);
+                weights_from_frac<float, ORDER>(fr[1], w1);
+                weights_from_frac<float, ORDER>(fr[2], w2);
+                if ((__float_as_int(gv) & 0x7f800000) == 0x7f800000) {
+                    // inf / NaN gradient: this voxel scatters its taps with float atomics straight
+                    // to global memory (rare, rolled loop)
 #pragma unroll 1
                     for (int t = 0; t < NT * NT * NT; ++t) {
                         const int l0 = t / (NT * NT), l1 = (t / NT) % NT, l2 = t % NT;
-                        const int zs = mirror_i32(start[i][0] + l0, hg.in_len[0]);
-                        const int ys = mirror_i32(start[i][1] + l1, hg.in_len[1]);
-                        const int xs = mirror_i32(start[i][2] + l2, hg.in_len[2]);
+                        const int zs = mirror_i32(st[0] + l0, hg.in_len[0]);
+                        const int ys = mirror_i32(st[1] + l1, hg.in_len[1]);
+                        const int xs = mirror_i32(st[2] + l2, hg.in_len[2]);
                         float wp = w0[0], wq = w1[0], wr = w2[0];
 #pragma unroll
                         for (int l = 1; l < NT; ++l) {
@@ -743,50 +803,11 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
                             wq = l1 == l ? w1[l] : wq;
                             wr = l2 == l ? w2[l] : wr;
                         }
-                        unsafeAtomicAdd(dst + (zs * hg.vol_sz + ys * hg.vol_sy + xs), gval[i] * wp * wq * wr);
+                        unsafeAtomicAdd(dst + (zs * hg.vol_sz + ys * hg.vol_sy + xs), gv * wp * wq * wr);
                     }
-                    gval[i] = 0.f;
-                }
-                gm += fabsf(gval[i]);
-            }
-            gm = wave_sum(gm);
-            float* gsum = reinterpret_cast<float*>(smem + kOffSum) + (phase & 1) * 4;
-            if (lane == 0)
-                gsum[wave] = gm;
-            __syncthreads();             // B2: box zeroed, sum known
-            const float gtot = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
-            if (gtot == 0.f)
-                continue;                // all-zero gradient tile (uniform)
-            // |sum in a cell| <= max tap weight * sum over the tile of |dY|: this scale cannot overflow
-            constexpr double kWmax = ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : (ORDER == 3 ? 0.2963
-                                    : (ORDER == 4 ? 0.2150 : 0.1664));
-            const float scale = (float)((2147483648.0 - 1024.0) / (kWmax * 1.001 * (double)gtot));
-            const float inv_scale = 1.f / scale;
-
-#pragma unroll 2
-            for (int i = 0; i < NV; ++i) {
-                int st0 = start[0][0], st1 = start[0][1], st2 = start[0][2];
-                float f0 = frac[0][0], f1 = frac[0][1], f2 = frac[0][2], gv = gval[0];
-                bool act = active[0];
-#pragma unroll
-                for (int k = 1; k < NV; ++k) {
-                    const bool sel = i == k;
-                    st0 = sel ? start[k][0] : st0;
-                    st1 = sel ? start[k][1] : st1;
-                    st2 = sel ? start[k][2] : st2;
-                    f0 = sel ? frac[k][0] : f0;
-                    f1 = sel ? frac[k][1] : f1;
-                    f2 = sel ? frac[k][2] : f2;
-                    gv = sel ? gval[k] : gv;
-                    act = sel ? active[k] : act;
-                }
-                if (!act || gv == 0.f || (hg.dbg & 128))
                     continue;
-                float w0[NT], w1[NT], w2[NT];
-                weights_from_frac<float, ORDER>(f0, w0);
-                weights_from_frac<float, ORDER>(f1, w1);
-                weights_from_frac<float, ORDER>(f2, w2);
-                const int rz = st0 - b0[0], ry = st1 - b0[1], rx = st2 - b0[2];
+                }
+                const int rz = st[0] - b0[0], ry = st[1] - b0[1], rx = st[2] - b0[2];
                 int* bp = box + (rz * by + ry) * pitch + rx;
                 const float gs = gv * scale;
 #pragma unroll
@@ -802,38 +823,42 @@ __global__ __launch_bounds__(kBlock, GRAD_WAVES) void hot_grad_kernel(const HotG
                     }
                 }
             }
-            __syncthreads();             // B3: all contributions are in
+            lds_barrier();               // B3: all contributions are in
             // flush: half a wave per box row, lanes along x -- one float atomic per touched source
             // element, runs of consecutive addresses (deform.c:791-813: mirror-mapped at the edges)
             {
                 constexpr int FL = TX == 8 ? 16 : 32;          // lanes per box row
                 constexpr int FR = kBlock / FL;                // rows per pass
-                const int sub = tid & (FL - 1);
+                constexpr int FU = 4;                          // rows in flight per lane: the LDS reads of
+                const int sub = tid & (FL - 1);                // FU rows are issued before the first atomic
                 const int rslot = tid / FL;
-                const int dz = FR / by, dyy = FR - dz * by;    // uniform
-                int zr = (int)(((float)rslot + 0.5f) / (float)by), yr = rslot - zr * by;
-                if (hg.dbg & 64)
-                    zr = ext[0];
-                while (zr < ext[0]) {
-                    const int* row = box + (zr * by + yr) * pitch;
-                    int rowoff;
-                    if (interior)
-                        rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
-                    else
-                        rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
-                                 mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
-                    for (int xi = sub; xi < ext[2]; xi += FL) {
-                        const int acc = row[xi];
-                        if (acc != 0) {
-                            const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
-                            unsafeAtomicAdd(dst + (rowoff + xs), (float)acc * inv_scale);
+                const float inv_by = 1.f / (float)by;
+                const int nr = (hg.dbg & 64) ? 0 : nrows;
+                for (int xo = 0; xo < ext[2]; xo += FL) {
+                    const int xi = xo + sub;
+                    const bool xin = xi < ext[2];
+                    const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
+                    for (int r0 = rslot; r0 < nr; r0 += FU * FR) {
+                        int acc[FU];
+#pragma unroll
+                        for (int k = 0; k < FU; ++k) {
+                            const int r = r0 + k * FR;
+                            acc[k] = (xin && r < nr) ? box[r * pitch + xi] : 0;
                         }
-                    }
-                    zr += dz;
-                    yr += dyy;
-                    if (yr >= by) {
-                        yr -= by;
-                        zr += 1;
+#pragma unroll
+                        for (int k = 0; k < FU; ++k) {
+                            if (acc[k] != 0) {
+                                const int r = r0 + k * FR;
+                                const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                                int rowoff;
+                                if (interior)
+                                    rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
+                                else
+                                    rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
+                                             mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+                                unsafeAtomicAdd(dst + (rowoff + xs), (float)acc[k] * inv_scale);
+                            }
+                        }
                     }
                 }
             }
@@ -845,7 +870,19 @@ template <int ORDER>
 hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t lds, hipStream_t stream)
 {
     if (gradient) {
-        if (hg.has_affine)
+        static const int duo = getenv("EDHIP_GRAD_DUO") ? atoi(getenv("EDHIP_GRAD_DUO")) : 0;
+        if (duo && !hg.has_affine && ORDER == 3) {
+            if constexpr (ORDER == 3) {
+                auto kern = hot_grad_kernel<ORDER, false, 4, 16, 2>;
+                static bool once = false;
+                if (!once) {
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    once = true;
+                }
+                const unsigned per = nblk / 8;
+                hipLaunchKernelGGL(kern, dim3(8 * ((per + 1) / 2)), dim3(2 * kBlock), 2 * (size_t)hg.lds_grp, stream, hg);
+            }
+        } else if (hg.has_affine)
             hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
         else
             hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);

@@ -1282,6 +1282,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 for (int k = 0; k < 12; ++k)
                     hg.affine[k] = tg.affine[k];
                 const size_t hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box);
+                hg.lds_grp = (int)((hlds + 15) & ~(size_t)15);
                 if (hlds) {
                     const hipError_t he = launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
                     if (he == hipSuccess)

@@ -362,6 +362,7 @@ struct HotGeom {
     int tiles[3];
     int strips_x, strip_tiles, nstrips, total_strips, ntiles;
     int ncpx, box_cap, off_box, mode, has_affine;
+    int lds_grp;          // bytes of LDS per wave group (K2, two groups per workgroup)
     int dbg;                  // experiment switches (EDHIP_TILE_DBG), 0 in production
     float cval;
     int nstep;

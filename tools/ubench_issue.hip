@@ -72,7 +72,7 @@ enum {
     L_READ_B64, L_READ_B64_MIS, L_READ2_B32_MIS, L_READ_B32, L_READ_B128, L_ADD_U32, L_ADD_U32_16OF64, L_ADD_U32_Q1,
     L_ADD_RTN, L_ADD_K16, L_ADD_K32, L_ADD_SAME2, L_ADD_SAME4, L_ADD_STRIDE2, L_ADD_U32_FIRST16, L_READ_B64_RAND,
     L_READ2_B64, L_READ_B64_X2, L_ADD_K16_64, L_ADD_K32_64, L_ADD_ROWS24, L_ADD_ROWS16, L_ADD_ROWS48, L_ADD_ROWS40,
-    L_READ_B64_2WAY, L_READ_B64_ROWS, L_WRITE_B128, L_READ_B64_Q4, L_READ_B128_Q4, L_READ_B64_BCAST, L_NTESTS
+    L_READ_B64_2WAY, L_READ_B64_ROWS, L_WRITE_B128, L_READ_B64_Q4, L_READ_B128_Q4, L_READ_B64_BCAST, L_ADD_U64, L_ADD_U64_ROWS, L_ADD_U64_S16, L_ADD_F32, L_ADD_U64_SAME2, L_NTESTS
 };
 static const char* kLNames[] = {
     "ds_read_b64 aligned", "ds_read_b64 4B-misaligned", "ds_read2_b32 4B-aligned pair", "ds_read_b32", "ds_read_b128",
@@ -86,7 +86,8 @@ static const char* kLNames[] = {
     "ds_add_u32 4 rows of 16, pitch 40", "ds_read_b64 2-way bank conflict (lane, lane+16 same banks)",
     "ds_read_b64 8 rows x 8 lanes pitch 16 dwords (K1 regular)", "ds_write_b128",
     "ds_read_b64 every 4th lane active", "ds_read_b128 every 4th lane active",
-    "ds_read_b64 8 lanes per address (broadcast)"};
+    "ds_read_b64 8 lanes per address (broadcast)", "ds_add_u64 64 lanes consecutive 8B", "ds_add_u64 4 rows of 16 lanes, pitch 24 dwords",
+    "ds_add_u64 stride 16 B", "ds_add_f32 64 lanes", "ds_add_u64 2 lanes per address"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void lds_kernel(float* out, int iters, long long* cyc)
@@ -124,6 +125,10 @@ __global__ __launch_bounds__(256) void lds_kernel(float* out, int iters, long lo
     case L_READ_B64_Q4: addr = base + lane * 8; break;
     case L_READ_B128_Q4: addr = base + lane * 16; break;
     case L_READ_B64_BCAST: addr = base + (lane >> 3) * 160; break;
+    case L_ADD_U64: addr = base + lane * 8; break;
+    case L_ADD_U64_ROWS: addr = base + ((lane & 15) * 2 + (lane >> 4) * 24) * 4; break;
+    case L_ADD_U64_S16: addr = base + lane * 16; break;
+    case L_ADD_U64_SAME2: addr = base + (lane >> 1) * 8; break;
     default: addr = base + lane * 4; break;
     }
     bool on = true;
@@ -209,6 +214,16 @@ __global__ __launch_bounds__(256) void lds_kernel(float* out, int iters, long lo
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     acc += v[k];
+            } else if (OP == L_ADD_U64 || OP == L_ADD_U64_ROWS || OP == L_ADD_U64_S16 || OP == L_ADD_U64_SAME2) {
+                const unsigned long long val = (unsigned long long)it * 0x100000001ull;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    asm volatile("ds_add_u64 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(k * 1024) : "memory");
+            } else if (OP == L_ADD_F32) {
+                const float val = (float)it;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(k * 512) : "memory");
             } else {
                 const unsigned val = it;
 #pragma unroll
