@@ -373,6 +373,8 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
     // (per-workgroup issue priorities (s_setprio) and a staggered start of the workgroups of a CU, to
     // push co-resident workgroups into complementary phases, were tried: no change)
     hot_prologue(hg, sp, smem, threadIdx.x, !QGLOBAL, NTH);
+    if (hg.dbg & 8192)
+        return;       // experiment: launch + prologue only
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
     int* sred = reinterpret_cast<int*>(smem + kOffRed);
@@ -628,7 +630,12 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
     const int bidx = NGRP == 2 ? (int)(((blockIdx.x >> 3) * 2 + grp) * 8 + (blockIdx.x & 7)) : (int)blockIdx.x;
     if (!hot_strip(hg, sp, bidx))
         return;
+    // the accumulator cells start at zero and every flush leaves the cells it read at zero again
+    for (int e = tid * 4; e < hg.box_cap; e += kBlock * 4)
+        *reinterpret_cast<int4*>(smem + hg.off_box + e * 4) = make_int4(0, 0, 0, 0);
     hot_prologue(hg, sp, smem, tid);
+    if (hg.dbg & 8192)
+        return;       // experiment: launch + prologue only
     if (NGRP == 2 && grp == 1)
         __syncthreads();
 
@@ -710,8 +717,23 @@ ED_UNROLL(ED_K2_U1)
                 }
             }
         }
+        // sum of |dY| over the tile (first step): published with the box, under the same barrier
+        float gval[NV];
+        {
+            float gm = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                gval[i] = gpre[i];
+                // inf / NaN gradients have no fixed-point scale: left out of the sum, scattered with
+                // float atomics below
+                gm += (__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(gval[i]);
+            }
+            gm = wave_sum(gm);
+            if (lane == 0)
+                reinterpret_cast<float*>(smem + kOffSum)[(phase & 1) * 4 + wave] = gm;
+        }
         box_reduce_to_lds(red, lane, lo, hi);
-        lds_barrier();     // B1: box known; the previous tile's flush is done
+        lds_barrier();     // B1: box and sum known; the previous tile's flush is done (cells back at zero)
         // wave-uniform box: kept in SGPRs
         const int b0[3] = {uni(red[0]), uni(red[1]), uni(red[2])};
         const int bhi[3] = {uni(red[3]), uni(red[4]), uni(red[5])};
@@ -743,33 +765,30 @@ ED_UNROLL(ED_K2_U1)
             long long vol_off = 0, img_off = 0;
             if (hg.nstep)
                 hot_step_offsets(hp, ss, vol_off, img_off);
-            if (ss > 0)
-                lds_barrier();           // previous step's flush is done with the box
-            // zero the accumulators
-            for (int e = tid * 4; e < nbox; e += kBlock * 4)
-                *reinterpret_cast<int4*>(box + e) = make_int4(0, 0, 0, 0);
-            float gval[NV];
-            float gm = 0.f;
             float* dst = dx + vol_off;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const bool inb = vy && vx && oz0 + ZSTEP * i < hg.out_len[0];
-                gval[i] = ss == 0 ? gpre[i] : (inb ? dy[img_off + ooff0 + i * ostep] : 0.f);
-                // inf / NaN gradients have no fixed-point scale: left out of the sum, scattered with
-                // float atomics below
-                gm += (__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(gval[i]);
-            }
-            gm = wave_sum(gm);
             float* gsum = reinterpret_cast<float*>(smem + kOffSum) + (phase & 1) * 4;
-            if (lane == 0)
-                gsum[wave] = gm;
-            lds_barrier();               // B2: box zeroed, sum known
+            if (ss > 0) {
+                // later steps (channels) of the same tile: their own sum, after the previous flush
+                float gm = 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const bool inb = vy && vx && oz0 + ZSTEP * i < hg.out_len[0];
+                    gval[i] = inb ? dy[img_off + ooff0 + i * ostep] : 0.f;
+                    gm += (__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(gval[i]);
+                }
+                gm = wave_sum(gm);
+                if (lane == 0)
+                    gsum[wave] = gm;
+                lds_barrier();           // sum known; the previous step's flush is done with the box
+            }
             const float gtot = unif((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
             // |sum in a cell| <= max tap weight * sum over the tile of |dY|: this scale cannot overflow
-            constexpr double kWmax = ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : (ORDER == 3 ? 0.2963
-                                    : (ORDER == 4 ? 0.2150 : 0.1664));
-            const float scale = gtot > 0.f ? unif((float)((2147483648.0 - 1024.0) / (kWmax * 1.001 * (double)gtot))) : 0.f;
-            const float inv_scale = gtot > 0.f ? unif(1.f / scale) : 0.f;
+            // (the 0.1 % margin covers the two roundings of the reciprocal and the product)
+            constexpr float kC = (float)((2147483648.0 - 1024.0) /
+                                         ((ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : ORDER == 3 ? 0.2963
+                                           : ORDER == 4 ? 0.2150 : 0.1664) * 1.001));
+            const float scale = gtot > 0.f ? fminf(kC * __frcp_rn(gtot), 3.0e38f) : 0.f;
+            const float inv_scale = gtot > 0.f ? __frcp_rn(scale) : 0.f;
 
 ED_UNROLL(ED_K2_U2)
             for (int i = 0; i < NV; ++i) {
@@ -843,7 +862,10 @@ ED_UNROLL(ED_K2_U2)
 #pragma unroll
                         for (int k = 0; k < FU; ++k) {
                             const int r = r0 + k * FR;
-                            acc[k] = (xin && r < nr) ? box[r * pitch + xi] : 0;
+                            // read and reset in one LDS operation (ds_wrxchg_rtn_b32)
+                            acc[k] = (xin && r < nr) ? __hip_atomic_exchange(&box[r * pitch + xi], 0, __ATOMIC_RELAXED,
+                                                                             __HIP_MEMORY_SCOPE_WORKGROUP)
+                                                     : 0;
                         }
 #pragma unroll
                         for (int k = 0; k < FU; ++k) {
@@ -928,6 +950,8 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box)
     // forward: two shifted float copies; 4 workgroups per CU -> 40960 bytes each (wide control
     // grids: a 64 KiB block, fewer workgroups per CU)
     size_t budget = 40 * 1024;
+    if (const char* kb = getenv("EDHIP_HOT_FWD_KB"))      // experiment: fewer workgroups per CU
+        budget = (size_t)atoi(kb) * 1024;
     if (const char* abl = getenv("EDHIP_HOT_ABL")) {      // experiments (see hot_fwd_kernel)
         const int a = atoi(abl);
         if (a & 1024) {                                    // Q rows stay in global memory
