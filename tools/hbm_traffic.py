@@ -2,9 +2,10 @@
 """FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, one counter per pass) -> profiles/hbm_traffic.json.
 usage: hbm_traffic.py <pmc dir> <commit>.  Raw counters are in KB per dispatch.  Calibration
 (profiles/r01_traffic_calibration.txt): FETCH_SIZE counts 64-byte requests at face value and reports
-half of the bytes of >=128-byte contiguous pieces; both hot kernels read their volumes in 64-byte
-pieces (box rows / 16-lane dY rows), so no doubling is applied; WRITE_SIZE is exact for full
-streams and 32-byte runs."""
+half of the bytes of wide streams; K1 reads its volume with 16-byte lanes in 64-byte runs (face value:
+rd16_runs), K2 reads dY with 4-byte lanes in 64-byte rows, which the counter reports at HALF
+(profiles/r02_traffic_calibration.txt, rd4_k2rows): the missing half of the 64 MiB of dY is added
+back for K2 (`fetch_correction_kb`).  WRITE_SIZE is exact for full streams and 32-byte runs."""
 import collections
 import csv
 import glob
@@ -20,11 +21,13 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/time_k12.py (the bench workload: "
                "256^3 float32, order 3, mirror, sigma 5), mean per dispatch, KB -> bytes",
        "algorithmic_bytes_per_launch": 134217728, "kernels": {}}
-for tag, key in (("K1", "hot_fwd_kernel<3, false, 0>"), ("K2", "hot_grad_kernel<3, false")):
+for tag, key in (("K1", "hot_fwd_kernel<3, false, 0,"), ("K2", "hot_grad_kernel<3, false")):
     for name, c in vals.items():
         if key in name and c.get("FETCH_SIZE") and c.get("WRITE_SIZE"):
             fkb = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
             wkb = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
-            out["kernels"][tag] = {"kernel": name, "fetch_kb": round(fkb), "write_kb": round(wkb),
-                                   "bytes_per_launch": int((fkb + wkb) * 1024), "commit": commit}
+            corr = 32768 if tag == "K2" else 0       # KB: the uncounted half of dY (256^3 float32)
+            out["kernels"][tag] = {"kernel": name, "fetch_kb": round(fkb), "fetch_correction_kb": corr,
+                                   "write_kb": round(wkb),
+                                   "bytes_per_launch": int((fkb + corr + wkb) * 1024), "commit": commit}
 print(json.dumps(out, indent=1))

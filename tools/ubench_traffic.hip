@@ -52,6 +52,25 @@ __global__ void wr4_stream(float* buf, size_t n)
     size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     for (; id < n; id += (size_t)gridDim.x * blockDim.x) buf[id] = 1.0f;
 }
+// read: K2's dY pattern.  buf is [rows][256 floats]; a wave-instruction reads 4 rows x 16 floats.
+// MAP 0: lane = 16 * row + x (round 1 / early round 2); MAP 1: the 16-lane groups hold even / odd x
+// of rows (y, y + 2) -- the mapping hot_grad_kernel uses.  Every element is read exactly once.
+template <int MAP>
+__global__ void rd4_k2rows(const float* buf, size_t nrows, float* sink)
+{
+    const int l = threadIdx.x & 63;
+    const int xx = MAP ? 2 * (l & 7) + ((l >> 4) & 1) : (l & 15);
+    const int yy = MAP ? ((l >> 5) & 1) + 2 * ((l >> 3) & 1) : (l >> 4);
+    size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t nitems = (nrows / 4) * 16;       // (row group, 16-float chunk)
+    float acc = 0;
+    for (size_t it = wave; it < nitems; it += nwaves) {
+        const size_t rg = it / 16, ch = it % 16;
+        acc += buf[(rg * 4 + yy) * 256 + ch * 16 + xx];
+    }
+    if (acc == -1.f) *sink = acc;
+}
 int main()
 {
     const size_t bytes = (size_t)1 << 30;       // 1 GiB: larger than the 256 MiB Infinity Cache
@@ -61,6 +80,8 @@ int main()
     hipLaunchKernelGGL(rd4_stream, dim3(4096), dim3(256), 0, 0, buf, nf, sink);
     hipLaunchKernelGGL(rd16_stream, dim3(4096), dim3(256), 0, 0, (const float4*)buf, n16, sink);
     hipLaunchKernelGGL(rd16_runs, dim3(4096), dim3(256), 0, 0, buf, n16, 1031, sink);
+    hipLaunchKernelGGL(rd4_k2rows<0>, dim3(4096), dim3(256), 0, 0, buf, nf / 256, sink);
+    hipLaunchKernelGGL(rd4_k2rows<1>, dim3(4096), dim3(256), 0, 0, buf, nf / 256, sink);
     hipLaunchKernelGGL(wr4_stream, dim3(4096), dim3(256), 0, 0, buf, nf);
     hipLaunchKernelGGL(wr4_runs32, dim3(4096), dim3(256), 0, 0, buf, nf);
     CK(hipDeviceSynchronize());
