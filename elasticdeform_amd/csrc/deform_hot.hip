@@ -266,7 +266,14 @@ __device__ __forceinline__ float hot_gather(const float* bp, int plane, const fl
             float a2 = 0.f, d2 = 0.f;
 #pragma unroll
             for (int l2 = 0; l2 < NTX; l2 += 2) {
-                const float2 pr = *reinterpret_cast<const float2*>(rp + l2);
+                float2 pr;
+                if (DUP == 3) {          // experiment: two ds_read_b32 (what a single, unshifted copy needs)
+                    pr.x = rp[l2];
+                    ED_NO_DS_MERGE();
+                    pr.y = rp[l2 + 1];
+                    ED_NO_DS_MERGE();
+                } else
+                    pr = *reinterpret_cast<const float2*>(rp + l2);
                 if (FENCE)
                     ED_NO_DS_MERGE();
                 a2 = fmaf(w2[l2], pr.x, a2);
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
                         const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1], rx = start[i][2] - b0[2];
                         // aligned pairs from the copy whose shift matches the parity of rx
                         const float* bp = ((rx & 1) ? box1 - 1 : box0) + ((rz * by + ry) * pitch + rx);
-                        constexpr int DUP = (ABL & 8192) ? 1 : ((ABL & 16384) ? 2 : 0);
+                        constexpr int DUP = (ABL & 32768) ? 3 : (ABL & 8192) ? 1 : ((ABL & 16384) ? 2 : 0);
                         val = pitch == 16 ? hot_gather<ORDER, 16, (ABL & 128) != 0, DUP>(bp, plane, w0, w1, w2)
                                           : hot_gather<ORDER, 48, (ABL & 128) != 0, DUP>(bp, plane, w0, w1, w2);
                     }
@@ -930,7 +937,7 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
             if constexpr (ORDER == 3) {
                 switch (atoi(getenv("EDHIP_HOT_ABL"))) {
 #define ED_ABL_CASE(A) case A: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, A>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
-                ED_ABL_CASE(8192) ED_ABL_CASE(16384) ED_ABL_CASE(16512) ED_ABL_CASE(128) ED_ABL_CASE(16) ED_ABL_CASE(1024) ED_ABL_CASE(4096) ED_ABL_CASE(5120) ED_ABL_CASE(7168) ED_ABL_CASE(3072) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
+                ED_ABL_CASE(32768) ED_ABL_CASE(8192) ED_ABL_CASE(16384) ED_ABL_CASE(16512) ED_ABL_CASE(128) ED_ABL_CASE(16) ED_ABL_CASE(1024) ED_ABL_CASE(4096) ED_ABL_CASE(5120) ED_ABL_CASE(7168) ED_ABL_CASE(3072) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
 #undef ED_ABL_CASE
                 default: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
                 }

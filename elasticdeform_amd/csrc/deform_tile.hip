@@ -276,6 +276,11 @@ __device__ __forceinline__ void step_offsets(const IOView& v, int64_t ss, int64_
 // ================================================================================================
 // ABL: compile-time ablation switches for profiling (0 in production): 1 skip staging loads,
 // 2 skip gather, 4 skip coordinates, 16 prologue only, 32 skip staging entirely, 64 skip the output store
+// (Tried: level 3 folded into the level-2 kernels -- the direct path called where a tile overflows
+// the 48 KiB box too; one 4 us launch less per call, but the level-2 forward kernel loses registers
+// to it: 159 -> 198 us at sigma = 10, where 6000 tiles take this path.  And the grid prefilter fused
+// into the tables kernel (every block filters its own LDS copy of a small raw grid; one 8 us launch
+// less): no measurable change of the 256^3 step in an A/B on one box, 0.7935 against 0.7961 ms.)
 template <typename T, int ORDER, bool PAIR, int ABL = 0>
 __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridGeom g,
                                                                      const IOView v,
@@ -1346,6 +1351,14 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         hipLaunchKernelGGL((deform_tile3_direct_kernel<T, ORDER, GRAD, true>), dim3(nsp), dim3(kBlock),
                            0, stream, g, ve, t3);
         e = hipGetLastError();
+    }
+    if (e == hipSuccess && getenv("EDHIP_PRINT_SPILL")) {      // debugging aid: tiles per level
+        int c1 = 0, c2 = 0;
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(&c1, list_a, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c2, list_b, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "edhip: %s tiles %lld, level-2 %d, level-3 %d\n", GRAD ? "K2" : "K1",
+                (long long)(ntiles * nb), c1, c2);
     }
     return e;
     }   // floating point T
