@@ -13,7 +13,7 @@ import threading
 import numpy
 
 MAX_DIMS = 8
-MAX_AXES = 4
+MAX_AXES = 7
 
 FLAG_AUTO, FLAG_EXACT, FLAG_FAST = 0, 1, 2
 FLAG_RAW_DISPLACEMENT = 4      # edhip_deform prefilters the control grid itself (<= 4096 points)

@@ -311,6 +311,11 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
     case 2: EDHIP_EXACT(2); break;
     case 3: EDHIP_EXACT(3); break;
     case 4: EDHIP_EXACT(4); break;
+    // five to seven deformed axes: the same kernel (digit counters over the (order + 1)^naxis taps);
+    // rare shapes, no tuning -- they exist so that every array the C ABI can describe is served
+    case 5: EDHIP_EXACT(5); break;
+    case 6: EDHIP_EXACT(6); break;
+    case 7: EDHIP_EXACT(7); break;
     default: return hipErrorInvalidValue;
     }
 #undef EDHIP_EXACT
@@ -337,7 +342,7 @@ hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream)
     case 2: hipLaunchKernelGGL(source_box_kernel<2>, grid, dim3(256), lds, stream, g, box); break;
     case 3: hipLaunchKernelGGL(source_box_kernel<3>, grid, dim3(256), lds, stream, g, box); break;
     case 4: hipLaunchKernelGGL(source_box_kernel<4>, grid, dim3(256), lds, stream, g, box); break;
-    default: return hipErrorInvalidValue;
+    default: return hipErrorNotSupported;       // > 4 axes: callers filter the whole array
     }
     return hipGetLastError();
 }

@@ -462,7 +462,7 @@ int edhip_source_box(const edhip_array* displacement, const int64_t* in_len, con
     e = launch_source_box(g, dbox, stream);
     if (e == hipErrorNotSupported)
         return fail(err, errlen, EDHIP_ERR_UNSUPPORTED,
-                    "edhip_source_box: control grids are limited to 7680 values");
+                    "edhip_source_box: control grids are limited to 7680 values and 4 deformed axes");
     if (e != hipSuccess)
         return hip_fail(err, errlen, e, "source box launch");
     int hbox[2 * kMaxAxes];

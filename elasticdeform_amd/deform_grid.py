@@ -12,8 +12,8 @@ with no host synchronisation (one exception, documented in include/edhip.h: the 
 stream that needs more scratch than that stream's cached workspace holds waits for the stream once).
 
 Limits that differ from the reference (status EDHIP_ERR_UNSUPPORTED / EDHIP_ERR_INVALID ->
-RuntimeError): at most 4 deformed axes (the reference takes any number, _deform_grid.c:158-175) and
-8 array dimensions; a deformed axis of length 1 is refused (the reference divides by I - 1 = 0 there,
+RuntimeError): at most 8 array dimensions, hence at most 7 deformed axes (the control grid has one
+dimension more; the reference takes whatever NumPy does, _deform_grid.c:158-175); a deformed axis of length 1 is refused (the reference divides by I - 1 = 0 there,
 deform.c:643, and yields inf / NaN coordinates that map to cval).
 
 * numpy.ndarray in  -> numpy.ndarray out (one H2D and one D2H copy; the drop-in path)
@@ -234,8 +234,8 @@ def _crop_windows(plan, shapes, dtypes, disp_desc, dflag, crop, prefilter, devic
     todo = [i for i in range(n) if plan.order[i] > 1 and dtypes[i] in ('float32', 'float64')]
     if not todo:
         return wins
-    if disp_desc.ndim < 2 or numpy.prod(list(disp_desc.shape)[:disp_desc.ndim]) > 7680:
-        return wins                 # edhip_source_box keeps the control grid in LDS
+    if disp_desc.ndim < 2 or disp_desc.ndim > 5 or numpy.prod(list(disp_desc.shape)[:disp_desc.ndim]) > 7680:
+        return wins                 # edhip_source_box: control grid in LDS, up to 4 deformed axes
     ax0 = plan.axis[0]
     in_len = [int(shapes[0][a]) for a in ax0]
     out_len = [int(plan.output_shapes[0][a]) for a in ax0]

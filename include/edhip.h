@@ -56,7 +56,7 @@ extern "C" {
 
 #define EDHIP_VERSION 100        /* 0.1.0 */
 #define EDHIP_MAX_DIMS 8         /* max ndim of any array (reference: NPY_MAXDIMS) */
-#define EDHIP_MAX_AXES 4         /* max number of deformed axes handled on the GPU */
+#define EDHIP_MAX_AXES 7         /* max number of deformed axes: the control grid has naxis + 1 <= EDHIP_MAX_DIMS dims */
 #define EDHIP_MAX_INPUTS 64
 
 /* dtype codes: the 13 NumPy types the reference switches over (deform.c:716-741,863-887,
@@ -100,7 +100,7 @@ enum edhip_status {
     EDHIP_ERR_DTYPE = 2,       /* "data type not supported"       -> RuntimeError  (deform.c:744,891,922)   */
     EDHIP_ERR_MEMORY = 3,      /* scratch allocation failed       -> MemoryError   (deform.c:394-398 ...)   */
     EDHIP_ERR_DEVICE = 4,      /* a HIP call / kernel launch failed -> RuntimeError                         */
-    EDHIP_ERR_UNSUPPORTED = 5  /* legal in the reference, outside this build's GPU limits (naxis > 4 ...)   */
+    EDHIP_ERR_UNSUPPORTED = 5  /* legal in the reference, outside this build's limits (more than 8 dims ...)   */
 };
 
 /* arithmetic selection for edhip_deform / edhip_spline_filter1d */

@@ -95,6 +95,19 @@ def small_cases():
                              None, 0))
         cases.append(_simple("H4d_o%d_constant" % order, (5, 4, 6, 5), (2, 3, 2, 3), np.float64,
                              order, "constant", None, 0, sigma=1.0))
+    # 5 to 7 deformed axes (the reference takes any number, _deform_grid.c:158-175; 8-dimensional
+    # arrays allow 7 here)
+    for order in (1, 3):
+        cases.append(_simple("H5d_o%d_mirror" % order, (4, 3, 4, 3, 5), (2, 2, 3, 2, 2), np.float64,
+                             order, "mirror", None, 0, sigma=1.0))
+    cases.append(_simple("H5d_o3_reflect_f32", (4, 3, 4, 3, 5), (2, 2, 3, 2, 2), np.float32, 3,
+                         "reflect", None, 0, sigma=1.0))
+    cases.append(_simple("H6d_o2_constant", (3, 3, 3, 2, 3, 4), (2, 2, 2, 2, 2, 2), np.float64, 2,
+                         "constant", None, 0, sigma=0.7))
+    cases.append(_simple("H7d_o1_nearest", (2, 3, 2, 2, 3, 2, 3), (2, 2, 2, 2, 2, 2, 2), np.float64, 1,
+                         "nearest", None, 0, sigma=0.7))
+    cases.append(_simple("H5d_o0_int16", (4, 3, 4, 3, 5), (2, 2, 3, 2, 2), "int16", 0, "nearest", None,
+                         0, sigma=1.0, grad=False))
     # C: integer / bool dtypes (rounding, clamping, prefilter-in-storage-dtype behaviour)
     for dt in ("int16", "uint8", "bool", "int32", "uint16", "int64", "int8", "uint32", "uint64"):
         for order in (0, 1, 3):

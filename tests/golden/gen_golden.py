@@ -38,9 +38,13 @@ def main():
     import scipy
     import scipy.ndimage
 
+    # GOLDEN_ONLY=small: regenerate small.npz only (the BASELINE-sized cases take minutes of CPU)
+    only_small = os.environ.get("GOLDEN_ONLY") == "small"
     stores = {"small": {}, "big": {}}
     t0 = time.time()
     for case in C.all_cases():
+        if only_small and case["big"]:
+            continue
         X, disp, kw = case["make"]()
         store = stores["big" if case["big"] else "small"]
         out = ref.deform_grid(X, disp, **kw)
@@ -83,6 +87,14 @@ def main():
         filt["tr_o3_%s" % dt] = g
 
     np.savez_compressed(os.path.join(HERE, "small.npz"), **stores["small"])
+    if only_small:
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        meta["n_small"] = len(stores["small"])
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        print("small.npz", os.path.getsize(os.path.join(HERE, "small.npz")) // 1024, "KiB")
+        return 0
     np.savez_compressed(os.path.join(HERE, "big.npz"), **stores["big"])
     np.savez_compressed(os.path.join(HERE, "filters.npz"), **filt)
     meta = dict(reference="gvtulder/elasticdeform v0.5.1 (/root/reference @ 2025-02-22)",

@@ -68,7 +68,9 @@ def _f32_grad_check(g, w, truth, flat=True):
     flat bound: there the REFERENCE's own float32 result is further than that from the exact
     gradient (measured on the MI355X run of this suite: 2.8e-5 on a 2x2x2 volume, 2e-4 at scale 5.9
     for order 5 in 4-D -- its per-axis float32 rounding of the transposed prefilter), so no
-    float32 implementation can be within 1e-5 of it except by copying its rounding order."""
+    float32 implementation can be within 1e-5 of it except by copying its rounding order.  The
+    golden cases with 5 or more deformed axes drop it for the same reason (H5d_o3_reflect_f32: the
+    reference is 1.7e-4 from the exact gradient at scale 4.4, the GPU 2.4e-4 to 3.0e-4)."""
     assert g.dtype == np.float32 and w.dtype == np.float32 and g.shape == w.shape == truth.shape
     scale = max(1.0, float(np.abs(truth).max()))
     err_ref = float(np.abs(w.astype(np.float64) - truth).max())
@@ -110,7 +112,7 @@ def test_forward_and_gradient_vs_golden(case, golden):
             assert g.dtype == w.dtype and g.shape == w.shape
             if w.dtype == np.float32:
                 truth = truth or _grad_truth(dY, disp, X, kw, case)
-                _f32_grad_check(g, w, truth[i])
+                _f32_grad_check(g, w, truth[i], flat=disp.shape[0] <= 4)
             else:
                 np.testing.assert_allclose(g, w, rtol=1e-10, atol=1e-10)
 
@@ -131,7 +133,7 @@ def test_exact_arithmetic_is_bit_equal(case, golden):
         for i, (g, w) in enumerate(zip(_pick(case, _aslist(grad)), golden.outputs(case, "grad"))):
             if w.dtype == np.float32:
                 truth = truth or _grad_truth(dY, disp, X, kw, case)
-                _f32_grad_check(g, w, truth[i])
+                _f32_grad_check(g, w, truth[i], flat=disp.shape[0] <= 4)
             elif w.dtype == np.float64:
                 np.testing.assert_allclose(g, w, rtol=1e-12, atol=1e-12)
             else:
