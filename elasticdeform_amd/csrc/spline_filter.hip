@@ -13,6 +13,7 @@
 // is across lines).  The fp64 working copy of the lines lives in a line-interleaved scratch
 // buffer ws[i * nlines + line], so that the 64 lanes of a wave, which hold 64 different lines,
 // always touch 64 consecutive doubles -- coalesced whatever the filtered axis is.
+#include <cstdlib>
 #include "ed_device.h"
 #include "ed_params.h"
 
@@ -40,15 +41,22 @@ __device__ __forceinline__ LineAddr line_address(const FilterParams& p, int64_t 
 
 // forward prefilter of one line (SciPy: gain, then per pole causal init / causal recursion /
 // anti-causal init / anti-causal recursion)
+// LDSWS: the fp64 working copy of the block's lines sits in LDS ([len][blockDim] doubles, the same
+// line-interleaved layout) instead of the global scratch buffer: short lines (small volumes, integer
+// volumes of any rank) otherwise pay a dependent global round trip per sample -- 28 us per pass for a
+// 32^3 volume, more than the deformation itself.  Same operations in the same order: same bits.
+template <bool LDSWS>
 __global__ __launch_bounds__(256) void prefilter_kernel(const FilterParams p, const int64_t line0,
                                                         const int64_t nl)
 {
+    extern __shared__ double lws[];
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nl)
         return;
     const LineAddr a = line_address(p, line0 + j);
     const int64_t n = p.len;
-    double* ws = p.ws + j;      // element i at ws[i * nl]
+    const int64_t wst = LDSWS ? (int64_t)blockDim.x : nl;
+    double* ws = LDSWS ? lws + threadIdx.x : p.ws + j;      // element i at ws[i * wst]
     if (n < 2 || p.npoles == 0) {
         for (int64_t i = 0; i < n; ++i)
             store_cast(a.out + i * p.out_axis_stride, p.out_dtype,
@@ -56,15 +64,15 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const FilterParams p, co
         return;
     }
     for (int64_t i = 0; i < n; ++i)
-        ws[i * nl] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype) * p.gain;
+        ws[i * wst] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype) * p.gain;
     for (int h = 0; h < p.npoles; ++h) {
         const double z = p.pole[h];
         const double zn1 = p.pole_pow[h];
         // exact mirror initialisation of the causal filter
-        double c0 = ws[0] + zn1 * ws[(n - 1) * nl];
+        double c0 = ws[0] + zn1 * ws[(n - 1) * wst];
         double zi = z;
         for (int64_t i = 1; i < n - 1; ++i) {
-            c0 += zi * (ws[i * nl] + zn1 * ws[(n - 1 - i) * nl]);
+            c0 += zi * (ws[i * wst] + zn1 * ws[(n - 1 - i) * wst]);
             zi *= z;
         }
         c0 /= 1 - zn1 * zn1;
@@ -72,8 +80,8 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const FilterParams p, co
         // causal recursion c[i] += z c[i-1]; keep the last two values for the anti-causal init
         double prev = c0, prev2 = c0;
         for (int64_t i = 1; i < n; ++i) {
-            const double c = ws[i * nl] + z * prev;
-            ws[i * nl] = c;
+            const double c = ws[i * wst] + z * prev;
+            ws[i * wst] = c;
             prev2 = prev;
             prev = c;
         }
@@ -83,29 +91,32 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const FilterParams p, co
         if (last)
             store_cast(a.out + (n - 1) * p.out_axis_stride, p.out_dtype, next);
         else
-            ws[(n - 1) * nl] = next;
+            ws[(n - 1) * wst] = next;
         for (int64_t i = n - 2; i >= 0; --i) {
-            const double c = z * (next - ws[i * nl]);
+            const double c = z * (next - ws[i * wst]);
             if (last)
                 store_cast(a.out + i * p.out_axis_stride, p.out_dtype, c);
             else
-                ws[i * nl] = c;
+                ws[i * wst] = c;
             next = c;
         }
     }
 }
 
 // transpose of the prefilter on one line -- deform.c:1116-1156
+template <bool LDSWS>
 __global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterParams p,
                                                                   const int64_t line0,
                                                                   const int64_t nl)
 {
+    extern __shared__ double lws[];
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nl)
         return;
     const LineAddr a = line_address(p, line0 + j);
     const int64_t len = p.len;
-    double* ws = p.ws + j;
+    const int64_t wst = LDSWS ? (int64_t)blockDim.x : nl;
+    double* ws = LDSWS ? lws + threadIdx.x : p.ws + j;
     if (len <= 1 || p.npoles == 0) {
         for (int64_t i = 0; i < len; ++i)
             store_cast(a.out + i * p.out_axis_stride, p.out_dtype,
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterPa
         return;
     }
     for (int64_t i = 0; i < len; ++i)
-        ws[i * nl] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype);
+        ws[i * wst] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype);
     for (int h = 0; h < p.npoles; ++h) {
         const double q = p.pole[h];
         const bool last = h == p.npoles - 1;
@@ -123,19 +134,19 @@ __global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterPa
         double prev = -q * x0;
         ws[0] = prev;
         for (int64_t ll = 1; ll < len - 1; ++ll) {
-            const double x = ws[ll * nl];
+            const double x = ws[ll * wst];
             sum = q * (sum + x);
             prev = q * (prev - x);
-            ws[ll * nl] = prev;
+            ws[ll * wst] = prev;
         }
-        sum = (q / (q * q - 1.0)) * (sum + ws[(len - 1) * nl]);
-        double up = ws[(len - 2) * nl] + q * sum;     // ln[len-2] += p*sum
-        ws[(len - 1) * nl] = sum;                     // ln[len-1]  = sum
+        sum = (q / (q * q - 1.0)) * (sum + ws[(len - 1) * wst]);
+        double up = ws[(len - 2) * wst] + q * sum;     // ln[len-2] += p*sum
+        ws[(len - 1) * wst] = sum;                     // ln[len-1]  = sum
         // adjoint of the causal recursion: ln[ll] += p * ln[ll+1], ll = len-2 .. 0
         double next = sum;
         for (int64_t ll = len - 2; ll >= 0; --ll) {
-            const double cur = (ll == len - 2 ? up : ws[ll * nl]) + q * next;
-            ws[ll * nl] = cur;
+            const double cur = (ll == len - 2 ? up : ws[ll * wst]) + q * next;
+            ws[ll * wst] = cur;
             next = cur;
         }
         // adjoint of the causal initial sum (next == ln[0] here)
@@ -145,11 +156,11 @@ __global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterPa
             if (last)
                 store_cast(a.out, p.out_dtype, l0 * p.gain);
             for (int64_t ll = 1; ll < len; ++ll) {
-                const double c = ws[ll * nl] + zn * l0;
+                const double c = ws[ll * wst] + zn * l0;
                 if (last)
                     store_cast(a.out + ll * p.out_axis_stride, p.out_dtype, c * p.gain);
                 else
-                    ws[ll * nl] = c;
+                    ws[ll * wst] = c;
                 zn *= q;
             }
         } else {
@@ -157,21 +168,21 @@ __global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterPa
             const double iz = 1.0 / q;
             double z2n = p.pole_pow[h];
             const double l0 = next / (1.0 - z2n * z2n);
-            const double tail = ws[(len - 1) * nl] + z2n * l0;
+            const double tail = ws[(len - 1) * wst] + z2n * l0;
             z2n *= z2n * iz;
             if (last) {
                 store_cast(a.out, p.out_dtype, l0 * p.gain);
                 store_cast(a.out + (len - 1) * p.out_axis_stride, p.out_dtype, tail * p.gain);
             } else {
                 ws[0] = l0;
-                ws[(len - 1) * nl] = tail;
+                ws[(len - 1) * wst] = tail;
             }
             for (int64_t ll = 1; ll <= len - 2; ++ll) {
-                const double c = ws[ll * nl] + (zn + z2n) * l0;
+                const double c = ws[ll * wst] + (zn + z2n) * l0;
                 if (last)
                     store_cast(a.out + ll * p.out_axis_stride, p.out_dtype, c * p.gain);
                 else
-                    ws[ll * nl] = c;
+                    ws[ll * wst] = c;
                 zn *= q;
                 z2n *= iz;
             }
@@ -259,6 +270,24 @@ hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
 {
     if (p.nlines <= 0 || p.len <= 0)
         return hipSuccess;
+    // lines of up to 128 samples: working copy in LDS (64 KiB: 256 threads x 32 samples ... 64 x 128),
+    // all lines in one launch, the global scratch buffer is not touched
+    static const bool no_ldsws = getenv("EDHIP_FILTER_NO_LDSWS") != nullptr;      // A/B switch
+    if (p.len <= 128 && !no_ldsws) {
+        const int blk = p.len <= 32 ? 256 : (p.len <= 64 ? 128 : 64);
+        const size_t lds = (size_t)p.len * blk * sizeof(double);
+        const int64_t nblk = (p.nlines + blk - 1) / blk;
+        if (nblk <= 0x7fffffffLL) {
+            const dim3 grid((unsigned)nblk);
+            if (p.transpose)
+                hipLaunchKernelGGL(prefilter_transpose_kernel<true>, grid, dim3(blk), lds, stream, p,
+                                   (int64_t)0, p.nlines);
+            else
+                hipLaunchKernelGGL(prefilter_kernel<true>, grid, dim3(blk), lds, stream, p, (int64_t)0,
+                                   p.nlines);
+            return hipGetLastError();
+        }
+    }
     const int block = 256;
     // p.ws holds p.ws_lines lines; walk the lines in chunks of that size (same stream, so the
     // chunks reuse the scratch buffer in order)
@@ -267,9 +296,9 @@ hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
         const int64_t nl = p.nlines - line0 < chunk ? p.nlines - line0 : chunk;
         const dim3 grid((unsigned)((nl + block - 1) / block));
         if (p.transpose)
-            hipLaunchKernelGGL(prefilter_transpose_kernel, grid, dim3(block), 0, stream, p, line0, nl);
+            hipLaunchKernelGGL(prefilter_transpose_kernel<false>, grid, dim3(block), 0, stream, p, line0, nl);
         else
-            hipLaunchKernelGGL(prefilter_kernel, grid, dim3(block), 0, stream, p, line0, nl);
+            hipLaunchKernelGGL(prefilter_kernel<false>, grid, dim3(block), 0, stream, p, line0, nl);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
