@@ -21,7 +21,7 @@ def timed(fn, iters=20):
 
 
 rng = np.random.default_rng(0)
-for n in (16, 32, 48, 63, 100, 128):
+for n in [int(a) for a in sys.argv[1:]] or (16, 32, 48, 63, 100, 128):
     for dt in (np.float32, np.int16):
         X = torch.from_numpy((rng.random((n, n, n)) * 200).astype(dt)).cuda()
         us = timed(lambda: dg._filter_axes(X, (0, 1, 2), 3, False, X.device))
