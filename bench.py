@@ -226,10 +226,13 @@ def main():
             _lib.deform_batch_strided(True, B, gxd, gxs, dd0, ds, None, gyd, gys, (0, 1, 2), 3, 3, 0.0, None,
                                       _lib.FLAG_AUTO, stream)
     else:
+        # as in the step: the forward call leaves its tiles' bounding boxes for the gradient call
+        # (EDHIP_FLAG_KEEP_BOXES / USE_BOXES; deform_grid / deform_grid_gradient set them for a
+        # displacement tensor that is handed to both unchanged)
         args_f = ([dgm._desc(Xf)], dgm._desc(df), None, [dgm._desc(out)], [(0, 1, 2)], [3], [3], [0.0],
-                  None, _lib.FLAG_AUTO, stream)
+                  None, _lib.FLAG_AUTO | _lib.FLAG_KEEP_BOXES, stream)
         args_g = ([dgm._desc(dxs)], dgm._desc(df), None, [dgm._desc(dY)], [(0, 1, 2)], [3], [3], [0.0],
-                  None, _lib.FLAG_AUTO, stream)
+                  None, _lib.FLAG_AUTO | _lib.FLAG_USE_BOXES, stream)
 
         def k1():
             _lib.deform(False, *args_f)

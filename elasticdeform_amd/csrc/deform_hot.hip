@@ -455,6 +455,9 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         int b0[3] = {red[0], red[1], red[2]};
         int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
         bool any = red[3] >= red[0];
+        if (hg.boxes && tid < 6)       // EDHIP_FLAG_KEEP_BOXES: the box goes to the gradient call too
+            hg.boxes[(size_t)(sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti) * 8 +
+                     tid] = red[tid];
         if (ABL & 8) {        // (only meaningful together with ABL & 4: identity coordinates)
             any = true;
             b0[0] = min(max(sp.tz * kT + hg.off[0] - 1, 0), hg.in_len[0] - 4);
@@ -679,6 +682,16 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
     const int oz0 = sp.tz * kT + zq;
     const bool vy = oy < hg.out_len[1];
 
+    // dY of a tile's first step is loaded one tile ahead: with the forward call's boxes there is no
+    // box pass left to hide its HBM round trip under
+    float gnext[NV];
+    {
+        const int ox = sp.tx0 * kT + xx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            gnext[i] = (vy && ox < hg.out_len[2] && oz0 + ZSTEP * i < hg.out_len[0])
+                           ? dy[(oz0 + ZSTEP * i) * hg.img_sz + oy * hg.img_sy + ox] : 0.f;
+    }
     for (int ti = 0; ti < ntile; ++ti) {
         int* red = sred + (ti % 3) * 8;
         const int ox = sp.tx0 * kT + ti * TX + xx;
@@ -686,11 +699,39 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
         const int ooff0 = oz0 * hg.img_sz + oy * hg.img_sy + ox;
         const int ostep = ZSTEP * hg.img_sz;
 
-        // dY of the first step: issued here so that its HBM round trip runs under the coordinates
         float gpre[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            gpre[i] = (vy && vx && oz0 + ZSTEP * i < hg.out_len[0]) ? dy[ooff0 + i * ostep] : 0.f;
+            gpre[i] = gnext[i];
+        if (ti + 1 < ntile) {
+            const bool nvx = ox + TX < hg.out_len[2];
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                gnext[i] = (vy && nvx && oz0 + ZSTEP * i < hg.out_len[0]) ? dy[ooff0 + TX + i * ostep] : 0.f;
+        }
+        // the forward call's boxes (EDHIP_FLAG_USE_BOXES): requested here, ahead of the barrier
+        const bool given = hg.use_boxes != 0;
+        int gb0[3] = {0, 0, 0}, gbhi[3] = {-1, -1, -1};
+        if (given) {
+            const int t0 = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 +
+                           ti * (TX / kT);
+            const int* bx = hg.boxes + (size_t)t0 * 8;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                gb0[h] = uni(bx[h]);
+                gbhi[h] = uni(bx[3 + h]);
+            }
+#pragma unroll
+            for (int k = 1; k < TX / kT; ++k) {
+                if (sp.tx0 + ti * (TX / kT) + k < hg.tiles[2]) {
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        gb0[h] = min(gb0[h], uni(bx[k * 8 + h]));
+                        gbhi[h] = max(gbhi[h], uni(bx[k * 8 + 3 + h]));
+                    }
+                }
+            }
+        }
 
         double tw[4];
         int tib[4];
@@ -725,17 +766,21 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
             const bool cst = hot_coords<ORDER, AFFINE>(hg, hp, qrow0 + i * qstep, tw, tib, b, P, start, frac);
             return vy && vx && oz < hg.out_len[0] && !cst;     // constant voxels contribute nothing (:928)
         };
+        // With the forward call's boxes (EDHIP_FLAG_USE_BOXES) the box pass is skipped: this tile's box
+        // is the union of the boxes of the 8-wide forward tiles it covers.
         int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
         int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+        if (!given) {
 ED_UNROLL(ED_K2_U1)
-        for (int i = 0; i < NV; ++i) {
-            int start[3];
-            float frac[3];
-            if (voxel(i, start, frac)) {
+            for (int i = 0; i < NV; ++i) {
+                int start[3];
+                float frac[3];
+                if (voxel(i, start, frac)) {
 #pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    lo[h] = min(lo[h], start[h]);
-                    hi[h] = max(hi[h], start[h] + ORDER);
+                    for (int h = 0; h < 3; ++h) {
+                        lo[h] = min(lo[h], start[h]);
+                        hi[h] = max(hi[h], start[h] + ORDER);
+                    }
                 }
             }
         }
@@ -754,14 +799,35 @@ ED_UNROLL(ED_K2_U1)
             if (lane == 0)
                 reinterpret_cast<float*>(smem + kOffSum)[(phase & 1) * 4 + wave] = gm;
         }
-        box_reduce_to_lds(red, lane, lo, hi);
+        if (!given)
+            box_reduce_to_lds(red, lane, lo, hi);
         lds_barrier();     // B1: box and sum known; the previous tile's flush is done (cells back at zero)
         // wave-uniform box: kept in SGPRs
-        const int b0[3] = {uni(red[0]), uni(red[1]), uni(red[2])};
-        const int bhi[3] = {uni(red[3]), uni(red[4]), uni(red[5])};
+        int b0[3], bhi[3];
+        if (given) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                b0[h] = gb0[h];
+                bhi[h] = gbhi[h];
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                b0[h] = uni(red[h]);
+                bhi[h] = uni(red[3 + h]);
+            }
+        }
+        bool any = bhi[0] >= b0[0] && bhi[1] >= b0[1] && bhi[2] >= b0[2];
+        if (given && !any) {
+            // an empty box may be a stale one: keep going with zero cells -- every live voxel then
+            // fails the window test below and is scattered directly
+            bhi[0] = b0[0] - 1;
+            bhi[1] = b0[1] - 1;
+            bhi[2] = b0[2] - 1;
+            any = true;
+        }
         const int ext[3] = {bhi[0] - b0[0] + 1, bhi[1] - b0[1] + 1, bhi[2] - b0[2] + 1};
-        const bool any = bhi[0] >= b0[0];
-        if (tid < 6)
+        if (tid < 6 && !given)
             sred[((ti + 2) % 3) * 8 + tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
         if (!any)
             continue;      // nothing to scatter (uniform)
@@ -769,6 +835,8 @@ ED_UNROLL(ED_K2_U1)
         int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
         if (hg.dbg & 1024)      // experiment: row offsets of 16 banks (mod 32): 34 % fewer conflict
             pitch = ext[2] <= 16 ? 16 : (ext[2] <= 48 ? 48 : 0);     // cycles, but the box doubles
+        if (given && ((unsigned)ext[0] > 4096u || (unsigned)ext[1] > 4096u))
+            pitch = 0;          // (a handed-over box is not trusted with the products below)
         const int by = ext[1];
         const int nrows = ext[0] * by;
         const int nbox = nrows * pitch;
@@ -828,9 +896,14 @@ ED_UNROLL(ED_K2_U2)
                 weights_from_frac<float, ORDER>(fr[0], w0);
                 weights_from_frac<float, ORDER>(fr[1], w1);
                 weights_from_frac<float, ORDER>(fr[2], w2);
-                if ((__float_as_int(gv) & 0x7f800000) == 0x7f800000) {
-                    // inf / NaN gradient: this voxel scatters its taps with float atomics straight
-                    // to global memory (rare, rolled loop)
+                const int rz = st[0] - b0[0], ry = st[1] - b0[1], rx = st[2] - b0[2];
+                // boxes handed over by the forward call are a hint: a window outside goes the direct way
+                const bool outside = given && (rz < 0 || rz + ORDER >= ext[0] || ry < 0 || ry + ORDER >= ext[1] ||
+                                               rx < 0 || rx + ORDER >= ext[2]);
+                if ((__float_as_int(gv) & 0x7f800000) == 0x7f800000 || outside) {
+                    // inf / NaN gradient (no fixed-point scale), or a window outside a stale box: this
+                    // voxel scatters its taps with float atomics straight to global memory (rare,
+                    // rolled loop)
 #pragma unroll 1
                     for (int t = 0; t < NT * NT * NT; ++t) {
                         const int l0 = t / (NT * NT), l1 = (t / NT) % NT, l2 = t % NT;
@@ -848,7 +921,6 @@ ED_UNROLL(ED_K2_U2)
                     }
                     continue;
                 }
-                const int rz = st[0] - b0[0], ry = st[1] - b0[1], rx = st[2] - b0[2];
                 int* bp = box + (rz * by + ry) * pitch + rx;
                 const float gs = gv * scale;
 #pragma unroll
@@ -891,7 +963,7 @@ ED_UNROLL(ED_K2_U2)
                         }
 #pragma unroll
                         for (int k = 0; k < FU; ++k) {
-                            if (acc[k] != 0) {
+                            if ((hg.dbg & 4096) ? acc[k] == 0x7ffffff1 : acc[k] != 0) {     // (4096: timing without the atomics)
                                 const int r = r0 + k * FR;
                                 const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                                 int rowoff;

@@ -1288,11 +1288,51 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     hg.affine[k] = tg.affine[k];
                 const size_t hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box);
                 hg.lds_grp = (int)((hlds + 15) & ~(size_t)15);
+                // EDHIP_FLAG_KEEP_BOXES / USE_BOXES: the forward kernel's tile boxes live in a buffer of
+                // their own (nothing else writes it) under a host-side key of everything they depend on
+                KeepKey* key = nullptr;
+                KeepKey cur;
+                memset(&cur, 0, sizeof(cur));
+                const int box_mode = batch ? batch->box_mode : 0;
+                if (hlds && box_mode && !getenv("EDHIP_NO_BOXES")) {
+                    hipError_t ke = hipSuccess;
+                    int* kb = (int*)keep_reserve(stream, (size_t)ntiles * nb * 8 * sizeof(int), &key, &ke);
+                    if (kb) {
+                        int n = 0;
+                        cur.w[n++] = 1;                                   // valid
+                        cur.w[n++] = (unsigned long long)(size_t)batch->disp_id;
+                        cur.w[n++] = (unsigned long long)g.disp_dtype | ((unsigned long long)batch->raw << 8) |
+                                     ((unsigned long long)ORDER << 16) | ((unsigned long long)tg.mode << 24) |
+                                     ((unsigned long long)g.has_affine << 32);
+                        cur.w[n++] = (unsigned long long)nb;
+                        cur.w[n++] = (unsigned long long)batch->disp_bstride;
+                        for (int k = 0; k < 3; ++k) {
+                            cur.w[n++] = (unsigned long long)g.in_len[k];
+                            cur.w[n++] = (unsigned long long)g.out_len[k];
+                            cur.w[n++] = (unsigned long long)g.off[k];
+                            cur.w[n++] = (unsigned long long)g.ncp[k];
+                        }
+                        for (int k = 0; k < 4; ++k)      // (RAW: the strides of the filtered copy -- a function of ncp)
+                            cur.w[n++] = (unsigned long long)g.disp_stride[k];
+                        if (g.has_affine)
+                            for (int k = 0; k < 12; ++k)
+                                memcpy(&cur.w[n++], &g.affine[k], sizeof(double));
+                        if (!GRAD && box_mode == 1) {
+                            hg.boxes = kb;
+                            *key = KeepKey();                  // not valid until this launch is in the stream
+                        } else if (GRAD && box_mode == 2 && memcmp(key, &cur, sizeof(cur)) == 0) {
+                            hg.boxes = kb;
+                            hg.use_boxes = 1;
+                        }
+                    }
+                }
                 if (hlds) {
                     const hipError_t he = launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
-                    if (he == hipSuccess)
+                    if (he == hipSuccess) {
                         hot_done = true;
-                    else if (he != hipErrorNotSupported)
+                        if (!GRAD && hg.boxes && key)
+                            *key = cur;
+                    } else if (he != hipErrorNotSupported)
                         e = he;
                 }
 

@@ -64,6 +64,9 @@ bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient);
 struct DeformBatch {
     int nbatch;
     int64_t in_bstride, out_bstride, disp_bstride;   // bytes
+    int box_mode = 0;               // 1: EDHIP_FLAG_KEEP_BOXES (forward), 2: EDHIP_FLAG_USE_BOXES (gradient)
+    const void* disp_id = nullptr;  // the caller's displacement pointer (identity of the control grid)
+    int raw = 0;                    // EDHIP_FLAG_RAW_DISPLACEMENT was set
 };
 hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream,
                               const DeformBatch* batch = nullptr);

@@ -363,6 +363,11 @@ struct HotGeom {
     int strips_x, strip_tiles, nstrips, total_strips, ntiles;
     int ncpx, box_cap, off_box, mode, has_affine;
     int lds_grp;          // bytes of LDS per wave group (K2, two groups per workgroup)
+    // tile bounding boxes handed from the forward to the gradient kernel: [tile][8] ints (lo x3,
+    // hi x3, -, -), tile = sample * ntiles + (tz * tiles_y + ty) * tiles_x + tx.  K1 writes them when
+    // the pointer is set; K2 reads them when `use_boxes` is set (see EDHIP_FLAG_USE_BOXES).
+    int* boxes;
+    int use_boxes;
     int dbg;                  // experiment switches (EDHIP_TILE_DBG), 0 in production
     float cval;
     int nstep;

@@ -20,6 +20,15 @@ namespace ed {
 // or nullptr with *err set.  The contents are unspecified.
 void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err);
 
+// A second, small cached buffer per (device, stream) that nothing but its owner writes: the tile
+// bounding boxes a forward deform leaves for the gradient call that follows it (deform_tile.hip).
+// `key` is a host-side blob describing what the buffer holds (all zero = nothing); it is reset when
+// the buffer moves.  Callers hold the stream's StreamGuard.
+struct KeepKey {
+    unsigned long long w[48];
+};
+void* keep_reserve(hipStream_t stream, size_t bytes, KeepKey** key, hipError_t* err);
+
 // Drains the devices that own scratch and frees every cached buffer.
 void workspace_release_all();
 

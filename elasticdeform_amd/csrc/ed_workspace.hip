@@ -19,6 +19,12 @@ struct Buffer {
 constexpr size_t kKeepBytes = (size_t)320 << 20;
 std::mutex g_mutex;
 std::map<std::pair<int, hipStream_t>, Buffer> g_buffers;
+struct KeepBuffer {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    KeepKey key;
+};
+std::map<std::pair<int, hipStream_t>, KeepBuffer> g_keep;
 // one host-side lock per (device, stream); entries are never erased, so the pointers stay valid
 std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::recursive_mutex>> g_stream_locks;
 }  // namespace
@@ -108,6 +114,44 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
     return b.ptr;
 }
 
+void* keep_reserve(hipStream_t stream, size_t bytes, KeepKey** key, hipError_t* err)
+{
+    *err = hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        *err = e;
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    KeepBuffer& b = g_keep[std::make_pair(dev, stream)];      // (std::map: the address is stable)
+    *key = &b.key;
+    if (b.ptr && b.cap >= bytes)
+        return b.ptr;
+    if (b.ptr) {
+        e = hipStreamSynchronize(stream);        // earlier kernels may still read the old buffer
+        if (e == hipSuccess)
+            e = hipFree(b.ptr);
+        b.ptr = nullptr;
+        b.cap = 0;
+        if (e != hipSuccess) {
+            *err = e;
+            return nullptr;
+        }
+    }
+    b.key = KeepKey();
+    size_t want = (bytes + bytes / 4 + 65535) & ~(size_t)65535;
+    e = hipMalloc(&b.ptr, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        b.ptr = nullptr;
+        *err = e;
+        return nullptr;
+    }
+    b.cap = want;
+    return b.ptr;
+}
+
 void workspace_trim(hipStream_t stream)
 {
     int dev = 0;
@@ -144,6 +188,15 @@ void workspace_release_all()
         kv.second.cap = 0;
     }
     g_buffers.clear();
+    for (auto& kv : g_keep) {
+        if (kv.second.ptr && hipSetDevice(kv.first.first) == hipSuccess) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(kv.second.ptr);
+        }
+        kv.second.ptr = nullptr;
+        kv.second.cap = 0;
+        kv.second.key = KeepKey();       // (entries stay: callers may hold the key's address)
+    }
     if (have_cur)
         (void)hipSetDevice(cur);
     (void)hipGetLastError();

@@ -301,8 +301,18 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
             e = launch_deform_label(g, v, stream);
         else if (!use_fast)
             e = launch_deform_exact(g, v, gradient != 0, stream);
-        else if (deform_tile_supported(g, v, gradient != 0))
-            e = launch_deform_tile(g, v, gradient != 0, stream);
+        else if (deform_tile_supported(g, v, gradient != 0)) {
+            DeformBatch one;
+            one.nbatch = 1;
+            one.in_bstride = one.out_bstride = one.disp_bstride = 0;
+            one.box_mode = (!gradient && (flags & EDHIP_FLAG_KEEP_BOXES)) ? 1
+                           : ((gradient && (flags & EDHIP_FLAG_USE_BOXES)) ? 2 : 0);
+            one.disp_id = displacement->data;
+            one.raw = (flags & EDHIP_FLAG_RAW_DISPLACEMENT) ? 1 : 0;
+            // (several inputs share the geometry: the boxes are those of the last forward launch,
+            // which is what a gradient call with the same inputs reads them for)
+            e = launch_deform_tile(g, v, gradient != 0, stream, &one);
+        }
         else
             e = launch_deform_fast(g, v, gradient != 0, stream);
         if (e != hipSuccess)
@@ -328,6 +338,9 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
         using namespace ed;
         DeformBatch db;
         db.nbatch = nbatch;
+        db.box_mode = (!gradient && (flags & EDHIP_FLAG_KEEP_BOXES)) ? 1
+                      : ((gradient && (flags & EDHIP_FLAG_USE_BOXES)) ? 2 : 0);
+        db.disp_id = displacements[0].data;
         const bool candidate = nbatch >= 2 && naxis == 3 && axis && !(flags & (EDHIP_FLAG_EXACT | EDHIP_FLAG_RAW_DISPLACEMENT)) &&
                                !getenv("EDHIP_BATCH_LOOP") &&
                                (inputs[0].dtype == EDHIP_F32 || inputs[0].dtype == EDHIP_F64) &&

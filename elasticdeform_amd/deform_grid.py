@@ -184,6 +184,37 @@ def _stream(device):
     return _torch().cuda.current_stream(device).cuda_stream
 
 
+# Forward -> gradient hand-over of the tile bounding boxes (EDHIP_FLAG_KEEP_BOXES / USE_BOXES): per
+# (device, stream), the storage address and version counter of the displacement tensor of the last
+# forward call.  The gradient call sets USE_BOXES when it is handed the same storage, unmodified
+# (autograd's backward, or deform_grid_gradient after deform_grid in a training step).  This is a
+# heuristic about CONTENTS only: the library checks every other argument itself and treats the boxes
+# as a hint, so a tensor changed behind PyTorch's back (`.data`), or a new tensor that landed on a
+# freed one's address, costs time and never correctness.
+_box_owner = {}
+
+
+def _box_id(displacement, df):
+    torch = _torch()
+    if torch.is_tensor(displacement) and displacement.is_cuda and df.data_ptr() == displacement.data_ptr():
+        return (displacement.data_ptr(), displacement._version)
+    return None
+
+
+def _box_flag_forward(displacement, df, device, stream):
+    """KEEP_BOXES for a forward call whose control grid is the caller's own device tensor."""
+    ident = _box_id(displacement, df)
+    _box_owner[(device.index, stream)] = ident
+    return _lib.FLAG_KEEP_BOXES if ident is not None else 0
+
+
+def _box_flag_gradient(displacement, df, device, stream):
+    ident = _box_id(displacement, df)
+    if ident is not None and _box_owner.get((device.index, stream)) == ident:
+        return _lib.FLAG_USE_BOXES
+    return 0
+
+
 def _filter_axes(x, axes, order, transpose, device, overwrite=False, stream=None):
     """Chain of 1-D spline filters over `axes` -- the reference's loop at deform_grid.py:157-162
     (forward) / :279-284 (transpose).  The reference filters x -> x_f and then x_f in place; so does
@@ -364,9 +395,10 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
         outs = [torch.empty(tuple(int(s) for s in shape), dtype=x.dtype, device=device)
                 for shape, x in zip(plan.output_shapes, Xd)]
 
+        bflag = _box_flag_forward(displacement, df, device, stream)
         _lib.deform(False, in_descs, _desc(df), plan.output_offset,
                     [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine, _flags | dflag, stream, prepared=_prepared(plan, len(Xd)))
+                    plan.inverse_affine, _flags | dflag | bflag, stream, prepared=_prepared(plan, len(Xd)))
         outs = [_narrow(o, xs) if w is not None else o for o, xs, w in zip(outs, Xs_dev, wide)]
         res = [_from_device(o, x) for o, x in zip(outs, Xs)]
     return res if isinstance(X, list) else res[0]
@@ -414,7 +446,8 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         stream = _stream(device)
         _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
                     [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine, _flags | dflag, stream, prepared=_prepared(plan, len(dXs)))
+                    plan.inverse_affine, _flags | dflag | _box_flag_gradient(displacement, df, device, stream),
+                    stream, prepared=_prepared(plan, len(dXs)))
 
         # gradient of the prefilter: its transpose along each deformed axis (deform_grid.py:276-286).
         # With a crop the scatter only touched a box of dX: the transposed filter runs on that box

@@ -114,7 +114,20 @@ enum edhip_flags {
      * SciPy before calling the C code), in one launch, with the same arithmetic and the same
      * per-axis rounding to the grid's dtype.  Grids of more than 4096 points are refused
      * (EDHIP_ERR_UNSUPPORTED): prefilter those with edhip_spline_filter1d. */
-    EDHIP_FLAG_RAW_DISPLACEMENT = 4
+    EDHIP_FLAG_RAW_DISPLACEMENT = 4,
+    /* edhip_deform / edhip_deform_batch*, forward (gradient = 0): also leave the bounding boxes of
+     * the tiles' tap windows -- a by-product of the forward kernel -- in a small per-stream buffer
+     * for the gradient call that follows (float32, 3 deformed axes: the tile kernels of
+     * deform_hot.hip; ignored elsewhere). */
+    EDHIP_FLAG_KEEP_BOXES = 8,
+    /* gradient = 1: the caller promises that the displacement's CONTENTS and the geometry are those of
+     * the last EDHIP_FLAG_KEEP_BOXES forward call on this stream (autograd: the backward of that
+     * forward).  The library compares the arguments it can see (pointer, shape, strides, extents,
+     * offsets, affine, order, mode); when they match the gradient kernel takes its tiles' boxes from
+     * the buffer instead of computing every window twice.  The boxes are a HINT: a voxel whose window
+     * does not lie in its tile's box is scattered straight to global memory, so a broken promise
+     * costs time, never correctness. */
+    EDHIP_FLAG_USE_BOXES = 16
 };
 
 /* strided N-d array in device memory: the POD stand-in for PyArrayObject* */

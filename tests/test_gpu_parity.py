@@ -880,3 +880,50 @@ def test_box_reduction_barrier_regression(order):
                                **F32_TOL)
     for _ in range(6):
         assert torch.equal(ed.deform_grid_batch(X, D, **kw), one)
+
+
+@pytest.mark.parametrize("order,mode,affine", [(3, "mirror", False), (1, "constant", False), (2, "wrap", True),
+                                               (5, "nearest", False)])
+def test_gradient_with_forward_boxes(order, mode, affine):
+    """EDHIP_FLAG_KEEP_BOXES / USE_BOXES: a gradient call that follows a forward call with the same
+    displacement tensor takes its tiles' bounding boxes from the forward kernel.  Same result as the
+    stand-alone gradient (the same contributions, added in the same fixed-point cells) and as the
+    oracle."""
+    rng = np.random.default_rng(order * 7 + len(mode))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    shape, pts = (44, 57, 70), (3, 4, 5)
+    X = torch.from_numpy(rng.random(shape).astype(np.float32)).to(dev)
+    D = torch.from_numpy(rng.standard_normal((3,) + pts) * 4.0).to(dev)
+    dY = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dev)
+    kw = dict(order=order, mode=mode, cval=0.25)
+    if affine:
+        kw["affine"] = np.eye(3, 4) + rng.standard_normal((3, 4)) * 0.03
+    alone = ed.deform_grid_gradient(dY, D.clone(), **kw)           # another tensor: no hand-over
+    ed.deform_grid(X, D, **kw)
+    handed = ed.deform_grid_gradient(dY, D, **kw)
+    want = orc.deform_grid_gradient(dY.cpu().numpy(), D.cpu().numpy(), **kw)
+    truth = orc.deform_grid_gradient(dY.cpu().numpy().astype(np.float64), D.cpu().numpy(), **kw)
+    _f32_grad_check(handed.cpu().numpy(), want, truth, flat=order < 5)      # (order 5: see _f32_grad_check)
+    scale = max(1.0, float(np.abs(truth).max()))
+    np.testing.assert_allclose(handed.cpu().numpy(), alone.cpu().numpy(), rtol=0, atol=2e-6 * scale)
+
+
+def test_gradient_with_stale_forward_boxes():
+    """The boxes are a hint: a displacement changed behind PyTorch's version counter (`.data`) between
+    the forward and the gradient call leaves stale boxes behind, and every window that falls outside
+    its tile's box is scattered directly -- the gradient is still the gradient of the NEW grid."""
+    rng = np.random.default_rng(99)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    shape, pts = (40, 48, 72), (3, 3, 4)
+    X = torch.from_numpy(rng.random(shape).astype(np.float32)).to(dev)
+    D = torch.from_numpy(rng.standard_normal((3,) + pts) * 1.0).to(dev)
+    dY = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dev)
+    kw = dict(order=3, mode="mirror")
+    ed.deform_grid(X, D, **kw)
+    version = D._version
+    D.data.copy_(torch.from_numpy(rng.standard_normal((3,) + pts) * 9.0))      # no version bump
+    assert D._version == version
+    got = ed.deform_grid_gradient(dY, D, **kw).cpu().numpy()
+    want = orc.deform_grid_gradient(dY.cpu().numpy(), D.cpu().numpy(), **kw)
+    truth = orc.deform_grid_gradient(dY.cpu().numpy().astype(np.float64), D.cpu().numpy(), **kw)
+    _f32_grad_check(got, want, truth)

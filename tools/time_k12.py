@@ -27,8 +27,11 @@ out = torch.empty_like(X)
 dxs = torch.zeros_like(X)
 stream = torch.cuda.current_stream(dev).cuda_stream
 mode = 3
-args_f = ([dgm._desc(Xf)], dgm._desc(df), None, [dgm._desc(out)], [(0, 1, 2)], [order], [mode], [0.0], None, _lib.FLAG_AUTO, stream)
-args_g = ([dgm._desc(dxs)], dgm._desc(df), None, [dgm._desc(dY)], [(0, 1, 2)], [order], [mode], [0.0], None, _lib.FLAG_AUTO, stream)
+boxes = os.environ.get("BOXES", "1") != "0"      # forward -> gradient hand-over of the tile boxes (the step's normal mode)
+args_f = ([dgm._desc(Xf)], dgm._desc(df), None, [dgm._desc(out)], [(0, 1, 2)], [order], [mode], [0.0], None,
+          _lib.FLAG_AUTO | (_lib.FLAG_KEEP_BOXES if boxes else 0), stream)
+args_g = ([dgm._desc(dxs)], dgm._desc(df), None, [dgm._desc(dY)], [(0, 1, 2)], [order], [mode], [0.0], None,
+          _lib.FLAG_AUTO | (_lib.FLAG_USE_BOXES if boxes else 0), stream)
 L = _lib.load()
 
 
