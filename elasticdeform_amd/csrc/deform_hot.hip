@@ -938,7 +938,11 @@ ED_UNROLL(ED_K2_U2)
             }
             lds_barrier();               // B3: all contributions are in
             // flush: half a wave per box row, lanes along x -- one float atomic per touched source
-            // element, runs of consecutive addresses (deform.c:791-813: mirror-mapped at the edges)
+            // element, runs of consecutive addresses (deform.c:791-813: mirror-mapped at the edges).
+            // (The cells in row-major order over all lanes -- every lane live, a third fewer LDS
+            // operations and instructions -- was measured: the part without the atomics drops from 25
+            // to 16 us, the atomics rise from 40 to 63 us: a wave-instruction then spans three to four
+            // row segments instead of two.)
             {
                 constexpr int FL = TX == 8 ? 16 : 32;          // lanes per box row
                 constexpr int FR = kBlock / FL;                // rows per pass
