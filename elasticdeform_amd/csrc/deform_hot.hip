@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         bool any = red[3] >= red[0];
         if (hg.boxes && tid < 6)       // EDHIP_FLAG_KEEP_BOXES: the box goes to the gradient call too
             hg.boxes[(size_t)(sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti) * 8 +
-                     tid] = red[tid];
+                     tid] = red[tid] - ((tid == 5 && any) ? kPadX : 0);      // (without the forward gather's padding tap)
         if (ABL & 8) {        // (only meaningful together with ABL & 4: identity coordinates)
             any = true;
             b0[0] = min(max(sp.tz * kT + hg.off[0] - 1, 0), hg.in_len[0] - 4);

@@ -1320,7 +1320,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         if (!GRAD && box_mode == 1) {
                             hg.boxes = kb;
                             *key = KeepKey();                  // not valid until this launch is in the stream
-                        } else if (GRAD && box_mode == 2 && memcmp(key, &cur, sizeof(cur)) == 0) {
+                        } else if (GRAD && box_mode == 2 && ORDER >= 3 && memcmp(key, &cur, sizeof(cur)) == 0) {
+                            // (orders 1 / 2: the box pass is a small part of a short tile, and the
+                            // hand-over's bookkeeping costs more than it saves: 190 -> 196, 242 -> 252 us)
                             hg.boxes = kb;
                             hg.use_boxes = 1;
                         }
