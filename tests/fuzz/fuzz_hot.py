@@ -52,13 +52,20 @@ for case in range(ncases):
             X = rng.random(full).astype(np.float32)
             disp = rng.standard_normal((3,) + pts) * sigma
             want = orc.deform_grid(X, disp, **kw)
-            got = ed.deform_grid(torch.from_numpy(X).to(dev), torch.from_numpy(disp).to(dev), **kw).cpu().numpy()
+            # one displacement tensor for both calls: the gradient takes the forward call's tile boxes
+            # (EDHIP_FLAG_USE_BOXES); every fourth case changes the grid behind PyTorch's version
+            # counter in between -- stale boxes, the gradient must still be that of the new grid
+            dd = torch.from_numpy(disp).to(dev)
+            got = ed.deform_grid(torch.from_numpy(X).to(dev), dd, **kw).cpu().numpy()
             err = float(np.abs(got - want).max()) if want.size else 0.0
             assert err <= 2e-5, "forward max abs err %.3e" % err
+            if rng.integers(0, 4) == 0:
+                disp = rng.standard_normal((3,) + pts) * float(rng.choice([0.5, 5.0, 20.0]))
+                dd.data.copy_(torch.from_numpy(disp))
+                desc += " [stale boxes]"
             dY = rng.random(want.shape).astype(np.float32)
             gw = orc.deform_grid_gradient(dY, disp, X_shape=full, **kw)
-            gg = ed.deform_grid_gradient(torch.from_numpy(dY).to(dev), torch.from_numpy(disp).to(dev),
-                                         X_shape=full, **kw).cpu().numpy()
+            gg = ed.deform_grid_gradient(torch.from_numpy(dY).to(dev), dd, X_shape=full, **kw).cpu().numpy()
             truth = orc.deform_grid_gradient(dY.astype(np.float64), disp, X_shape=full, **kw)
             gs = max(1.0, float(np.abs(truth).max()))
             eref = float(np.abs(gw.astype(np.float64) - truth).max())
