@@ -192,6 +192,7 @@ def _stream(device):
 # as a hint, so a tensor changed behind PyTorch's back (`.data`), or a new tensor that landed on a
 # freed one's address, costs time and never correctness.
 _box_owner = {}
+_batch_grids = {}      # (device, stream) -> (identity of the displacement tensor, its filtered grids) of the last batch forward
 
 
 def _box_id(displacement, df):
@@ -205,6 +206,7 @@ def _box_flag_forward(displacement, df, device, stream):
     """KEEP_BOXES for a forward call whose control grid is the caller's own device tensor."""
     ident = _box_id(displacement, df)
     _box_owner[(device.index, stream)] = ident
+    _batch_grids[(device.index, stream)] = None        # (the stream's box buffer changes hands)
     return _lib.FLAG_KEEP_BOXES if ident is not None else 0
 
 
@@ -518,9 +520,15 @@ def deform_grid_batch(X, displacements, order=3, mode='constant', cval=0.0, crop
         df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
         out = torch.empty((B,) + tuple(int(v) for v in plan.output_shapes[0]), dtype=Xd.dtype, device=device)
         (xd, xs), (dd0, ds), (od, os_) = _desc_sample0(Xf), _desc_sample0(df), _desc_sample0(out)
+        # the filtered grids are kept for the gradient call of the same (unmodified) displacement
+        # tensor: it skips their prefilter and takes this call's tile boxes (see _box_owner)
+        stream = _stream(device)
+        ident = _box_id(displacements, dd)
+        _batch_grids[(device.index, stream)] = (ident, df) if ident is not None else None
+        _box_owner[(device.index, stream)] = None
         _lib.deform_batch_strided(False, B, xd, xs, dd0, ds, plan.output_offset, od, os_, ax, o,
-                                  int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine, _flags,
-                                  _stream(device))
+                                  int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine,
+                                  _flags | (_lib.FLAG_KEEP_BOXES if ident is not None else 0), stream)
         return _from_device(out, X)
 
 
@@ -555,11 +563,19 @@ def deform_grid_gradient_batch(dY, displacements, order=3, mode='constant', cval
         dX = torch.zeros((B,) + tuple(int(v) for v in X_shape), dtype=dYd.dtype, device=device)
         ax = plan.axis[0]
         o = int(plan.order[0])
-        df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
+        stream = _stream(device)
+        kept = _batch_grids.get((device.index, stream))
+        ident = _box_id(displacements, dd)
+        bflag = 0
+        if kept is not None and ident is not None and kept[0] == ident:
+            df = kept[1]                      # the forward call's filtered grids (and its tile boxes)
+            bflag = _lib.FLAG_USE_BOXES
+        else:
+            df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
         (xd, xs), (dd0, ds), (yd, ys) = _desc_sample0(dX), _desc_sample0(df), _desc_sample0(dYd)
         _lib.deform_batch_strided(True, B, xd, xs, dd0, ds, plan.output_offset, yd, ys, ax, o,
-                                  int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine, _flags,
-                                  _stream(device))
+                                  int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine, _flags | bflag,
+                                  stream)
         if prefilter and o > 1:
             dX = _filter_axes(dX, [a + 1 for a in ax], o, True, device, overwrite=True)
         return _from_device(dX, dY)

@@ -927,3 +927,29 @@ def test_gradient_with_stale_forward_boxes():
     want = orc.deform_grid_gradient(dY.cpu().numpy(), D.cpu().numpy(), **kw)
     truth = orc.deform_grid_gradient(dY.cpu().numpy().astype(np.float64), D.cpu().numpy(), **kw)
     _f32_grad_check(got, want, truth)
+
+
+def test_batch_gradient_with_forward_boxes():
+    """deform_grid_gradient_batch after deform_grid_batch with the same displacement tensor: the
+    filtered grids and the forward call's tile boxes are reused; same gradient as without."""
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, shape, pts = 3, (40, 41, 66), (3, 4, 4)
+    X = torch.from_numpy(rng.random((B,) + shape).astype(np.float32)).to(dev)
+    D = torch.from_numpy(rng.standard_normal((B, 3) + pts) * 3.0).to(dev)
+    dY = torch.from_numpy(rng.standard_normal((B,) + shape).astype(np.float32)).to(dev)
+    kw = dict(order=3, mode="mirror")
+    alone = ed.deform_grid_gradient_batch(dY, D.clone(), **kw)
+    ed.deform_grid_batch(X, D, **kw)
+    handed = ed.deform_grid_gradient_batch(dY, D, **kw)
+    for b in range(B):
+        want = orc.deform_grid_gradient(dY[b].cpu().numpy(), D[b].cpu().numpy(), **kw)
+        truth = orc.deform_grid_gradient(dY[b].cpu().numpy().astype(np.float64), D[b].cpu().numpy(), **kw)
+        _f32_grad_check(handed[b].cpu().numpy(), want, truth)
+    scale = max(1.0, float(alone.abs().max()))
+    np.testing.assert_allclose(handed.cpu().numpy(), alone.cpu().numpy(), rtol=0, atol=2e-6 * scale)
+    D.mul_(1.5)                                  # version bump: the next gradient stands alone again
+    g2 = ed.deform_grid_gradient_batch(dY, D, **kw)
+    want = orc.deform_grid_gradient(dY[1].cpu().numpy(), D[1].cpu().numpy(), **kw)
+    truth = orc.deform_grid_gradient(dY[1].cpu().numpy().astype(np.float64), D[1].cpu().numpy(), **kw)
+    _f32_grad_check(g2[1].cpu().numpy(), want, truth)
