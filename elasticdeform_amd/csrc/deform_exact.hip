@@ -82,6 +82,39 @@ __global__ void source_box_init_kernel(int* box, int naxis)
         box[threadIdx.x] = (threadIdx.x & 1) ? (int)0x80000000 : 0x7fffffff;
 }
 
+// (order + 1)^3 taps of one voxel, lexicographic, summed exactly like the digit-counter loop of
+// deform_exact_kernel (value, then * w0, * w1, * w2, then added: deform.c:863-899), with the loads of
+// a row issued together.  S: a type whose conversion to double is the plain C one.
+template <typename S>
+__device__ __forceinline__ double exact_rows3(const char* base, const int64_t (&tap)[3][6], const double (&w)[3][6],
+                                              int order)
+{
+#pragma clang fp contract(off)
+    double t = 0.0;
+    for (int l0 = 0; l0 <= order; ++l0) {
+        for (int l1 = 0; l1 <= order; ++l1) {
+            const char* row = base + (tap[0][l0] + tap[1][l1]);
+            S vals[6];
+#pragma unroll
+            for (int l2 = 0; l2 < 6; ++l2)      // (taps past the order re-read tap 0: no branch around a load)
+                vals[l2] = *reinterpret_cast<const S*>(row + tap[2][l2 <= order ? l2 : 0]);
+#pragma unroll
+            for (int l2 = 0; l2 < 6; ++l2) {
+                if (l2 <= order) {
+                    double coeff = (double)vals[l2];
+                    if (order > 0) {
+                        coeff *= w[0][l0];
+                        coeff *= w[1][l1];
+                        coeff *= w[2][l2];
+                    }
+                    t += coeff;
+                }
+            }
+        }
+    }
+    return t;
+}
+
 // The control grid is first copied into LDS as doubles (component-major, C order): at 64 x naxis
 // dependent global loads per voxel the kernel was latency-bound (326 us for a 64^3 crop).
 template <int NAXIS>
@@ -217,7 +250,33 @@ __global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, con
     int cnt[NAXIS];
     if (!gradient) {
         double t = 0.0;
-        if (!constant) {                                   // deform.c:843-901
+        bool rows_done = false;
+        if (!constant && NAXIS == 3) {
+            // three deformed axes, element types with a plain C conversion: the same sum in the same
+            // order, but a row of taps (last axis) is loaded before it is accumulated -- the digit
+            // counter below issues one dependent global load per tap (64 round trips per voxel at
+            // order 3: the exact kernel's time)
+            if constexpr (NAXIS == 3) {
+                rows_done = true;
+                const char* base = v.in + in_off;
+                switch (v.in_dtype) {
+                case EDHIP_BOOL:
+                case EDHIP_U8: t = exact_rows3<uint8_t>(base, tap, w, order); break;
+                case EDHIP_I8: t = exact_rows3<int8_t>(base, tap, w, order); break;
+                case EDHIP_U16: t = exact_rows3<uint16_t>(base, tap, w, order); break;
+                case EDHIP_I16: t = exact_rows3<int16_t>(base, tap, w, order); break;
+                case EDHIP_U32: t = exact_rows3<uint32_t>(base, tap, w, order); break;
+                case EDHIP_I32: t = exact_rows3<int32_t>(base, tap, w, order); break;
+                case EDHIP_U64: t = exact_rows3<uint64_t>(base, tap, w, order); break;
+                case EDHIP_I64: t = exact_rows3<int64_t>(base, tap, w, order); break;
+                case EDHIP_F32: t = exact_rows3<float>(base, tap, w, order); break;
+                case EDHIP_F64: t = exact_rows3<double>(base, tap, w, order); break;
+                default: rows_done = false; break;       // 16-bit floats: below
+                }
+            }
+        }
+        if (rows_done) {
+        } else if (!constant) {                            // deform.c:843-901
 #pragma unroll
             for (int k = 0; k < NAXIS; ++k)
                 cnt[k] = 0;
