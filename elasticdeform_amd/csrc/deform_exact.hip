@@ -92,22 +92,40 @@ __device__ __forceinline__ double exact_rows3(const char* base, const int64_t (&
 #pragma clang fp contract(off)
     double t = 0.0;
     for (int l0 = 0; l0 <= order; ++l0) {
-        for (int l1 = 0; l1 <= order; ++l1) {
-            const char* row = base + (tap[0][l0] + tap[1][l1]);
-            S vals[6];
+        for (int l1 = 0; l1 <= order; l1 += 2) {      // two rows (up to 12 loads) in flight
+            const bool two = l1 + 1 <= order;
+            const char* row0 = base + (tap[0][l0] + tap[1][l1]);
+            const char* row1 = base + (tap[0][l0] + tap[1][two ? l1 + 1 : l1]);
+            S v0[6], v1[6];
 #pragma unroll
-            for (int l2 = 0; l2 < 6; ++l2)      // (taps past the order re-read tap 0: no branch around a load)
-                vals[l2] = *reinterpret_cast<const S*>(row + tap[2][l2 <= order ? l2 : 0]);
+            for (int l2 = 0; l2 < 6; ++l2) {    // (taps past the order re-read tap 0: no branch around a load)
+                v0[l2] = *reinterpret_cast<const S*>(row0 + tap[2][l2 <= order ? l2 : 0]);
+                v1[l2] = *reinterpret_cast<const S*>(row1 + tap[2][l2 <= order ? l2 : 0]);
+            }
 #pragma unroll
             for (int l2 = 0; l2 < 6; ++l2) {
                 if (l2 <= order) {
-                    double coeff = (double)vals[l2];
+                    double coeff = (double)v0[l2];
                     if (order > 0) {
                         coeff *= w[0][l0];
                         coeff *= w[1][l1];
                         coeff *= w[2][l2];
                     }
                     t += coeff;
+                }
+            }
+            if (two) {
+#pragma unroll
+                for (int l2 = 0; l2 < 6; ++l2) {
+                    if (l2 <= order) {
+                        double coeff = (double)v1[l2];
+                        if (order > 0) {
+                            coeff *= w[0][l0];
+                            coeff *= w[1][l1 + 1];
+                            coeff *= w[2][l2];
+                        }
+                        t += coeff;
+                    }
                 }
             }
         }
