@@ -35,6 +35,28 @@ def test_header_and_library_agree():
     assert lib.edhip_status_string(2) == b"data type not supported"
 
 
+def test_header_constants_match_the_python_binding():
+    """The flags, limits and dtype codes of include/edhip.h are the ones _lib.py passes."""
+    text = open(os.path.join(ROOT, "include", "edhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    enums = {k: int(v) for k, v in re.findall(r"\b(EDHIP_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    defs = {k: int(v) for k, v in re.findall(r"#define\s+(EDHIP_[A-Z0-9_]+)\s+(\d+)", text)}
+    assert enums["EDHIP_FLAG_AUTO"] == _lib.FLAG_AUTO and enums["EDHIP_FLAG_EXACT"] == _lib.FLAG_EXACT
+    assert enums["EDHIP_FLAG_FAST"] == _lib.FLAG_FAST
+    assert enums["EDHIP_FLAG_RAW_DISPLACEMENT"] == _lib.FLAG_RAW_DISPLACEMENT
+    assert enums["EDHIP_FLAG_KEEP_BOXES"] == _lib.FLAG_KEEP_BOXES
+    assert enums["EDHIP_FLAG_USE_BOXES"] == _lib.FLAG_USE_BOXES
+    flags = [v for k, v in enums.items() if k.startswith("EDHIP_FLAG_") and v]
+    assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)     # distinct bits
+    assert defs["EDHIP_MAX_DIMS"] == _lib.MAX_DIMS and defs["EDHIP_MAX_AXES"] == _lib.MAX_AXES
+    assert _lib.MAX_AXES == _lib.MAX_DIMS - 1          # the control grid has one dimension more
+    for name, code in _lib.DTYPE_CODES.items():
+        key = {"bool": "BOOL", "uint8": "U8", "int8": "I8", "uint16": "U16", "int16": "I16", "uint32": "U32",
+               "int32": "I32", "uint64": "U64", "int64": "I64", "float32": "F32", "float64": "F64",
+               "float16": "F16", "bfloat16": "BF16"}[name]
+        assert enums["EDHIP_" + key] == code, name
+
+
 def _desc(shape, dtype="float32", ptr=0x1000):
     a = np.empty(shape, dtype=dtype)
     return _lib.describe(ptr, a.dtype.name, a.shape, a.strides)
