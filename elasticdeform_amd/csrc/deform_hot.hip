@@ -996,7 +996,8 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
                 auto kern = hot_grad_kernel<ORDER, false, 4, 16, 2>;
                 static bool once = false;
                 if (!once) {
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     once = true;
                 }
                 const unsigned per = nblk / 8;
