@@ -1328,7 +1328,38 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         }
                     }
                 }
-                if (hlds) {
+                // one wavefront per tile (deform_wave.hip): strips of 4 tiles per 64-thread workgroup
+                static const int wave_mode = getenv("EDHIP_WAVE") ? atoi(getenv("EDHIP_WAVE")) : 3;
+                bool wave_done = false;
+                if (hlds && (wave_mode & (GRAD ? 2 : 1))) {
+                    HotGeom wg = hg;
+                    wg.strip_tiles = 4;
+                    if (const char* st = getenv("EDHIP_WAVE_STRIP"))
+                        wg.strip_tiles = atoi(st);
+                    while (wg.strip_tiles > 1 &&
+                           (int64_t)nb * tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + wg.strip_tiles - 1) / wg.strip_tiles) < 8192)
+                        wg.strip_tiles >>= 1;
+                    wg.strips_x = (tg.tiles[2] + wg.strip_tiles - 1) / wg.strip_tiles;
+                    const int64_t wstrips = (int64_t)tg.tiles[0] * tg.tiles[1] * wg.strips_x;
+                    if (wstrips * nb <= 0x3fffffffLL) {
+                        wg.nstrips = (int)wstrips;
+                        wg.total_strips = (int)(wstrips * nb);
+                        size_t wlds = wave_lds_bytes(GRAD, &wg.box_cap);
+                        if (const char* kb = getenv("EDHIP_WAVE_LDS")) {
+                            wlds = (size_t)atoi(kb);
+                            wg.box_cap = (int)(wlds / 4);
+                        }
+                        const unsigned wblk = (unsigned)(((wstrips * nb + 7) / 8) * 8);
+                        const hipError_t he = launch_wave_level1(wg, ORDER, GRAD, wblk, wlds, stream);
+                        if (he == hipSuccess) {
+                            hot_done = wave_done = true;
+                            if (!GRAD && hg.boxes && key)
+                                *key = cur;
+                        } else if (he != hipErrorNotSupported)
+                            e = he;
+                    }
+                }
+                if (hlds && !wave_done && e == hipSuccess) {
                     const hipError_t he = launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
                     if (he == hipSuccess) {
                         hot_done = true;

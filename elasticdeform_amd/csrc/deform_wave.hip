@@ -1,0 +1,914 @@
+// deform_wave.hip -- K1 (forward gather) and K2 (gradient scatter-add) for float32 volumes with 3
+// deformed axes and unit x-stride, spline orders 1-5: ONE WAVEFRONT PER OUTPUT TILE, no workgroup
+// barriers.  A workgroup is a single wave; it owns its 8 x 8 x 8 output tile, the tile's source box
+// in LDS and nothing else, so the only synchronisation left is s_waitcnt inside the wave, and the
+// 12 waves of a CU drift apart: while one gathers (LDS), others compute coordinates (fp64 VALU) or
+// wait for their staging copies.
+//
+// Per-voxel pipeline of DeformGrid's hot loop (deform.c:649-924 forward, :926-997 gradient):
+//
+//   lane map   lane = 8 y + z owns one (z, y) row of the tile and walks its 8 voxels along x.
+//              * the displacement spline's row of control columns Q[oz][oy][.] (tile_tables_kernel)
+//                is lane-constant: the 4 columns x 3 components a voxel needs stay in 24 VGPRs for
+//                the whole strip and are reloaded only when the walk crosses a control interval;
+//              * the x table entry (cubic weights, control indices: the reference's dsplvals,
+//                deform.c:639-647) is wave-uniform: scalar loads, SGPR operands of the 12 fp64 FMAs.
+//              Coordinates therefore cost no LDS access at all (the 4-wave kernels read 12 table
+//              taps per voxel from LDS).
+//   box        pass 1 walks the row once for the tile's bounding box of tap windows (DPP reduction,
+//              v_readlane -- no LDS atomics, no slots), pass 2 recomputes the coordinates (same
+//              instructions, same inputs: bit-identical) right before each voxel's taps: nothing is
+//              kept per voxel, so both passes are short rolled loops.
+//   K1 staging one copy of the box, row pitch 16 floats, plane stride 16 rows + 2 floats: with lanes on
+//              64 different (z, y) rows of the box the aligned 8-byte reads of a 32-lane group fall on
+//              32 different bank pairs when the deformation is rigid (tools/sim/conflicts_walk_x.py:
+//              176 LDS cycles per 64 voxels on the cfg2 field against 124 for two shifted copies,
+//              which need twice the LDS and twice the staging traffic).  A window of 4 taps at either
+//              parity is covered by three aligned ds_read_b64; the tap outside the window gets weight
+//              zero AND is replaced by zero (so an Inf / NaN next to the window cannot leak in).
+//              Interior boxes are staged with LDS-DMA (global_load_lds_dwordx4, one instruction per
+//              box plane); boxes that cross the x ends of the volume are mirror-mapped per element,
+//              as the reference does with the taps of a window that sticks out (deform.c:791-813).
+//   K1 gather  contracted over (z, y) first per box column, then over x: (NT + 1) NT (NT + 1) + NT + 1
+//              FMAs per voxel (105 for order 3).
+//   adaptive   a tile whose box exceeds the wave's LDS is processed as two 8 x 8 x 4 halves along x
+//              (same lanes, half the walk); what still does not fit goes to the spill list and the
+//              general kernels (deform_tile.hip).
+//
+// The sliding-register-window variant (keep a lane's 4 x 4 x 4 window in registers and fetch only
+// the column that enters when start_x advances) was evaluated on the cfg2 field before writing this
+// kernel (tools/sim/sliding_window_stats.py): 78 % of a lane's steps keep (start_z, start_y) and
+// advance start_x by one, but only 2 % of a WAVE's steps do so in all 64 lanes (0.3 % at sigma 10),
+// so a wave would execute the incremental path and the full reload on almost every step.
+#include <hip/hip_runtime.h>
+
+#include "ed_device.h"
+#include "ed_params.h"
+#include "ed_tile.h"
+
+namespace ed {
+namespace tile {
+
+namespace {
+
+typedef int int8v __attribute__((ext_vector_type(8)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// min of lo[3] / max of hi[3] over the wave, result wave-uniform (six interleaved DPP chains ending
+// in lane 63, see deform_hot.hip's box_reduce_to_lds for why this is hand-written)
+#define ED_RED6(CTRL)                                      \
+    "v_min_i32_dpp %0, %0, %0 " CTRL "\n\t"                \
+    "v_min_i32_dpp %1, %1, %1 " CTRL "\n\t"                \
+    "v_min_i32_dpp %2, %2, %2 " CTRL "\n\t"                \
+    "v_max_i32_dpp %3, %3, %3 " CTRL "\n\t"                \
+    "v_max_i32_dpp %4, %4, %4 " CTRL "\n\t"                \
+    "v_max_i32_dpp %5, %5, %5 " CTRL "\n\t"
+__device__ __forceinline__ void wave_box(int (&lo)[3], int (&hi)[3])
+{
+    asm volatile("s_nop 1\n\t"
+                 ED_RED6("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 ED_RED6("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 ED_RED6("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 ED_RED6("row_mirror row_mask:0xf bank_mask:0xf")
+                 ED_RED6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 ED_RED6("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        lo[h] = __builtin_amdgcn_readlane(lo[h], 63);
+        hi[h] = __builtin_amdgcn_readlane(hi[h], 63);
+    }
+}
+#undef ED_RED6
+
+__device__ __forceinline__ void glds16(const float* g, float* lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+struct WaveStrip {
+    int tz, ty, tx0, ntile, sample;
+};
+
+// strips are dealt to the 8 XCDs in contiguous chunks (block b runs on XCD b % 8): neighbouring
+// strips, whose source boxes overlap, share an L2
+__device__ __forceinline__ bool wave_strip(const HotGeom& hg, WaveStrip& sp, int b)
+{
+    const int per = (hg.total_strips + 7) >> 3;
+    int s = (b & 7) * per + (b >> 3);
+    if ((b >> 3) >= per || s >= hg.total_strips)
+        return false;
+    sp.sample = s / hg.nstrips;
+    s -= sp.sample * hg.nstrips;
+    const int sx = s % hg.strips_x;
+    s /= hg.strips_x;
+    sp.ty = s % hg.tiles[1];
+    sp.tz = s / hg.tiles[1];
+    sp.tx0 = sx * hg.strip_tiles;
+    sp.ntile = min(hg.strip_tiles, hg.tiles[2] - sp.tx0);
+    return true;
+}
+
+// The lane's control columns of its Q row: 4 columns x 3 components (fp64), reloaded when the
+// wave-uniform index tuple of the x table changes (once per control interval).
+struct QCols {
+    double v[4][3];
+    int idx[4];          // wave-uniform: the element offsets these columns were loaded from
+};
+
+__device__ __forceinline__ void qcols_load(QCols& qc, const double* __restrict__ qrow, const int (&idx)[4])
+{
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const double2 a = *reinterpret_cast<const double2*>(qrow + idx[l]);
+        qc.v[l][0] = a.x;
+        qc.v[l][1] = a.y;
+        qc.v[l][2] = qrow[idx[l] + 2];
+        qc.idx[l] = idx[l];
+    }
+}
+
+// Phase A for one voxel (deform.c:649-824): displacement from the lane's control columns with the
+// wave-uniform cubic weights `tw`, (affine), + offset, window start and fractional offsets.  Same
+// operations in the same order as hot_coords (deform_hot.hip) and voxel_coords (deform_tile.hip): a
+// voxel gets bit-identical (start, frac) whichever kernel serves its tile.  `b[h]` = output index +
+// crop offset along axis h (no affine) or 0 (affine: the real base is in `P`).  Returns true when the
+// voxel maps to the constant.
+template <int ORDER, bool AFFINE>
+__device__ __forceinline__ bool wave_coords(const HotGeom& hg, const HotParams* hp, const QCols& qc,
+                                            const double (&tw)[4], const int (&b)[3], const double (&P)[3],
+                                            int* start, float* frac)
+{
+    double d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        d[c] = tw[0] * qc.v[0][c];
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            d[c] = fma(tw[l], qc.v[l][c], d[c]);
+    int ci[3];
+    bool inr[3];
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+        inr[h] = coord_axis_fast<ORDER, float>(AFFINE ? P[h] + d[h] : d[h], AFFINE ? 0 : b[h], hg.in_len[h],
+                                               ci[h], frac[h]);
+    bool cst = false;
+    if (!(inr[0] && inr[1] && inr[2])) {
+        // one divergent region: the axes along which the source point left the array
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            if (!inr[h])
+                cst = coord_axis_mapped<ORDER, float>(AFFINE ? P[h] + d[h] : (double)b[h] + d[h], hg.in_len[h],
+                                                      hg.mode, hp->period[h], hp->inv_period[h], ci[h],
+                                                      frac[h]) || cst;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+        start[h] = cst ? 0 : ci[h] - ORDER / 2;
+    return cst;
+}
+
+__device__ __forceinline__ void wave_step_offsets(const HotParams* hp, long long ss, long long& vol_off,
+                                                  long long& img_off)
+{
+    vol_off = 0;
+    img_off = 0;
+    long long r = ss;
+    const int nstep = hp->nstep;
+    for (int l = 0; l < nstep; ++l) {
+        const long long len = hp->step_len[l];
+        const long long q = r / len;
+        const long long c = r - q * len;
+        vol_off += hp->in_step_stride[l] * c;
+        img_off += hp->out_step_stride[l] * c;
+        r = q;
+    }
+}
+
+// Rarely used wave-uniform values (boundary-map periods, the affine map, step-axis strides) are parked
+// in the head of the wave's LDS: as kernel arguments they are hoisted into scalar registers for the
+// whole kernel, and the spills (v_writelane / v_readlane) cost more than the occasional broadcast read.
+constexpr int kWaveHead = 416;
+static_assert(sizeof(HotParams) <= kWaveHead, "HotParams must fit the head of the wave's LDS");
+__device__ __forceinline__ void wave_prologue(const HotGeom& hg, char* smem, int lane)
+{
+    HotParams* hp = reinterpret_cast<HotParams*>(smem);
+    if (lane < 12) {
+        hp->affine[lane] = hg.affine[lane];
+        if (lane < 3) {
+            hp->offd[lane] = (double)hg.off[lane];
+            hp->last[lane] = (double)(hg.in_len[lane] - 1);
+            hp->period[lane] = hg.period[lane];
+            hp->inv_period[lane] = hg.inv_period[lane];
+        }
+        if (lane < 8) {
+            hp->step_len[lane] = hg.step_len[lane];
+            hp->in_step_stride[lane] = hg.vol_step[lane];
+            hp->out_step_stride[lane] = hg.img_step[lane];
+        }
+        if (lane == 0)
+            hp->nstep = hg.nstep;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): one wave, DS operations are ordered
+    asm volatile("" ::: "memory");
+}
+
+// Per-lane, per-strip constants of the row walk
+struct RowWalk {
+    int oz, oy;
+    bool vzy;                 // the lane's (z, y) row exists in the output
+    const double* qrow;       // the lane's row of control columns (clamped to the last row)
+    double Pzy[3];            // affine: A[h][0] oz + A[h][1] oy + A[h][3] + off_h
+};
+
+// x table entry of output column ox (wave-uniform): weights and control column offsets
+struct XEntry {
+    double w[4];
+    int idx[4];
+};
+__device__ __forceinline__ void xentry_load(const AxTab* __restrict__ xt, int ox, XEntry& e)
+{
+    const AxTab* t = xt + ox;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        e.w[l] = t->w[l];
+        e.idx[l] = t->idx[l];
+    }
+}
+
+// coordinates of the voxel at output column `ox` of the lane's row, given its x table entry
+template <int ORDER, bool AFFINE>
+__device__ __forceinline__ bool entry_voxel(const HotGeom& hg, const HotParams* hp, const RowWalk& rw, QCols& qc,
+                                            const XEntry& xe, int ox, int* start, float* frac)
+{
+    if (xe.idx[0] != qc.idx[0] || xe.idx[1] != qc.idx[1] || xe.idx[2] != qc.idx[2] || xe.idx[3] != qc.idx[3])
+        qcols_load(qc, rw.qrow, xe.idx);          // wave-uniform branch
+    const int b[3] = {rw.oz + hg.off[0], rw.oy + hg.off[1], ox + hg.off[2]};
+    double P[3] = {0.0, 0.0, 0.0};
+    if (AFFINE) {
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+            P[h] = fma(hp->affine[h * 4 + 2], (double)ox, rw.Pzy[h]);
+    }
+    return wave_coords<ORDER, AFFINE>(hg, hp, qc, xe.w, b, P, start, frac);
+}
+template <int ORDER, bool AFFINE>
+__device__ __forceinline__ bool row_voxel(const HotGeom& hg, const HotParams* hp, const RowWalk& rw, QCols& qc,
+                                          const AxTab* __restrict__ xt, int ox, int* start, float* frac)
+{
+    XEntry xe;
+    xentry_load(xt, min(ox, hg.out_len[2] - 1), xe);
+    return entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, xe, ox, start, frac);
+}
+
+// pass 1: bounding box of the tap windows of the lane's voxels [ox0, ox0 + nx), reduced over the wave.
+// Two voxels per iteration (independent fp64 chains); the table entries of the next pair are requested
+// (scalar loads) as soon as this pair's coordinates no longer need the registers.  nx is even.
+template <int ORDER, bool AFFINE>
+__device__ __forceinline__ void row_box(const HotGeom& hg, const HotParams* hp, const RowWalk& rw, QCols& qc,
+                                        const AxTab* __restrict__ xt, int ox0, int nx, int (&lo)[3], int (&hi)[3])
+{
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        lo[h] = 0x7fffffff;
+        hi[h] = (int)0x80000000;
+    }
+    const int last = hg.out_len[2] - 1;
+    XEntry ea, eb;
+    xentry_load(xt, min(ox0, last), ea);
+    xentry_load(xt, min(ox0 + 1, last), eb);
+#pragma unroll 1
+    for (int k = 0; k < nx; k += 2) {
+        const int ox = ox0 + k;
+        int sa[3], sb[3];
+        float fa[3], fb[3];
+        const bool ca = entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, ea, ox, sa, fa);
+        const bool cb = entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, eb, ox + 1, sb, fb);
+        xentry_load(xt, min(ox + 2, last), ea);
+        xentry_load(xt, min(ox + 3, last), eb);
+        if (rw.vzy && ox <= last && !ca) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                lo[h] = min(lo[h], sa[h]);
+                hi[h] = max(hi[h], sa[h] + ORDER);
+            }
+        }
+        if (rw.vzy && ox + 1 <= last && !cb) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                lo[h] = min(lo[h], sb[h]);
+                hi[h] = max(hi[h], sb[h] + ORDER);
+            }
+        }
+    }
+    wave_box(lo, hi);
+}
+
+// ================================================================================================
+// K1: forward
+// ================================================================================================
+// Box geometry of one (sub-)tile in LDS: element (rz, ry, rx) at rz * ps + ry * 16 + rx
+constexpr int kPitch = 16;
+// z-planes of taps in flight per voxel: two up to order 3 (152 VGPRs: three waves per SIMD, which is
+// what 12.5 KiB of LDS per wave allows anyway), one for the wider windows of orders 4 / 5
+#ifndef ED_GATHER_BUFS
+#define ED_GATHER_BUFS 2
+#endif
+template <int ORDER>
+constexpr int gather_bufs() { return ORDER <= 3 ? ED_GATHER_BUFS : 1; }
+struct BoxLayout {
+    int b0[3], ext[3];
+    int ps;
+    bool any, fits;
+};
+
+template <int ORDER>
+__device__ __forceinline__ void fwd_layout(const int (&lo)[3], const int (&hi)[3], int box_cap, BoxLayout& bl)
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int NP = (NT + 2) / 2;          // aligned pairs that cover a window at either parity
+    bl.any = hi[0] >= lo[0];
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        bl.b0[h] = lo[h];
+        bl.ext[h] = hi[h] - lo[h] + 1;
+    }
+    // columns the reads can touch: the last window starts at ext_x - NT, its first pair at that & ~1
+    const int need = ((bl.ext[2] - NT) & ~1) + 2 * NP;
+    bl.ps = bl.ext[1] * kPitch + 2;           // planes one bank pair apart (see the header)
+    bl.fits = bl.any && need <= kPitch && (unsigned)bl.ext[0] <= 4096u && (unsigned)bl.ext[1] <= 4096u &&
+              bl.ext[0] * bl.ps <= box_cap;
+}
+
+// stage the source box (one copy).  x-interior boxes: LDS-DMA, one instruction per 64 16-byte chunks
+// of a plane, the (z, y) mirror map applied to the lane's row; otherwise element by element.
+__device__ __forceinline__ void fwd_stage(const HotGeom& hg, const BoxLayout& bl, const float* __restrict__ src,
+                                          float* box, int lane)
+{
+    const bool x_inside = bl.b0[2] >= 0 && bl.b0[2] + kPitch <= hg.in_len[2];
+    const bool zy_inside = bl.b0[0] >= 0 && bl.b0[0] + bl.ext[0] <= hg.in_len[0] && bl.b0[1] >= 0 &&
+                           bl.b0[1] + bl.ext[1] <= hg.in_len[1];
+    if (x_inside) {
+        const int nchunk = bl.ext[1] * 4;              // 16-byte chunks per plane
+        for (int c0 = 0; c0 < nchunk; c0 += 64) {
+            const int c = c0 + lane;
+            const int row = c >> 2, ch = c & 3;
+            const bool live = c < nchunk;
+            const int ys = zy_inside ? bl.b0[1] + row : mirror_i32(bl.b0[1] + min(row, bl.ext[1] - 1), hg.in_len[1]);
+            const int rowoff = ys * hg.vol_sy + bl.b0[2] + 4 * ch;
+            for (int rz = 0; rz < bl.ext[0]; ++rz) {
+                const int zs = zy_inside ? bl.b0[0] + rz : mirror_i32(bl.b0[0] + rz, hg.in_len[0]);
+                if (live)
+                    glds16(src + (zs * hg.vol_sz + rowoff), box + rz * bl.ps + c0 * 4);
+            }
+        }
+    } else {
+        // every box index goes through the mirror map (deform.c:791-813); 16 lanes per row
+        const int sub = lane & 15;
+        const int nrows = bl.ext[0] * bl.ext[1];
+        const float inv_by = 1.0f / (float)bl.ext[1];
+        const int xs = mirror_i32(bl.b0[2] + sub, hg.in_len[2]);
+        for (int r = lane >> 4; r < nrows; r += 4) {
+            const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * bl.ext[1];
+            const int zs = mirror_i32(bl.b0[0] + zr, hg.in_len[0]);
+            const int ys = mirror_i32(bl.b0[1] + yr, hg.in_len[1]);
+            if (sub < bl.ext[2])
+                box[zr * bl.ps + yr * kPitch + sub] = src[zs * hg.vol_sz + ys * hg.vol_sy + xs];
+        }
+    }
+}
+
+// (ORDER + 1)^3 taps of one voxel from the staged box.  `bp` points at the aligned pair that holds
+// tap (0, 0, 0), `par` is the parity of the window's x start.  The work is cut into z-planes (NT rows
+// of 2 NP floats); the reads of the next NBUF - 1 planes are in flight while a plane is accumulated --
+// with one plane at a time the wave sat out the LDS latency once per plane, and 12 waves per CU do
+// not cover that.  The order is pinned by hand (empty asm statements): left alone, the compiler sinks
+// every FMA below the last read of the voxel and spills.
+template <int ORDER, int NBUF>
+__device__ __forceinline__ float wave_gather(const float* bp, int ps, bool par, const float (&w0)[ORDER + 1],
+                                             const float (&w1)[ORDER + 1], const float (&w2)[ORDER + 1])
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int NP = (NT + 2) / 2;
+    constexpr int NC = NT + 1;                 // box columns a window can touch (either parity)
+    float S[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+        S[j] = 0.f;
+    float v[NBUF][NT][2 * NP];
+    auto rd = [&](int l0) {
+        const float* pp = bp + l0 * ps;
+#pragma unroll
+        for (int l1 = 0; l1 < NT; ++l1) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float2 pr = *reinterpret_cast<const float2*>(pp + l1 * kPitch + 2 * p);
+                ED_NO_DS_MERGE();              // (ds_read2_b64 runs at half the rate of two ds_read_b64)
+                v[l0 % NBUF][l1][2 * p] = pr.x;
+                v[l0 % NBUF][l1][2 * p + 1] = pr.y;
+            }
+            if (2 * NP > NC)                   // keep the last pair an 8-byte read (64 banks; a 4-byte read has 32)
+                asm volatile("" ::"v"(v[l0 % NBUF][l1][2 * NP - 1]));
+        }
+    };
+    auto acc = [&](int l0) {
+        float c[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            c[j] = 0.f;
+#pragma unroll
+        for (int l1 = 0; l1 < NT; ++l1)
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                c[j] = fmaf(w1[l1], v[l0 % NBUF][l1][j], c[j]);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            S[j] = fmaf(w0[l0], c[j], S[j]);
+            asm volatile("" : "+v"(S[j]));
+        }
+    };
+#pragma unroll
+    for (int l0 = 0; l0 < NBUF - 1 && l0 < NT; ++l0)
+        rd(l0);
+#pragma unroll
+    for (int l0 = 0; l0 < NT; ++l0) {
+        if (l0 + NBUF - 1 < NT)
+            rd(l0 + NBUF - 1);
+        acc(l0);
+    }
+    // x contraction: even start -> columns 0 .. NT-1, odd start -> 1 .. NT; the column outside the
+    // window is dropped as a value (not only through a zero weight): an Inf / NaN there must not leak
+    S[0] = par ? 0.f : S[0];
+    S[NT] = par ? S[NT] : 0.f;
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const float wl = j > 0 ? w2[j - 1] : 0.f, wr = j < NT ? w2[j] : 0.f;
+        a = fmaf(par ? wl : wr, S[j], a);
+    }
+    return a;
+}
+
+template <int ORDER, bool AFFINE>
+__global__ __launch_bounds__(64, 3) void wave_fwd_kernel(const HotGeom hg, const AxTab* __restrict__ xt,
+                                                         const double* __restrict__ qtab,
+                                                         const float* __restrict__ vol0, float* __restrict__ img0)
+{
+    constexpr int NT = ORDER + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HotParams* hp = reinterpret_cast<const HotParams*>(smem);
+    float* box = reinterpret_cast<float*>(smem + kWaveHead);
+    WaveStrip sp;
+    if (!wave_strip(hg, sp, blockIdx.x))
+        return;
+    const int lane = threadIdx.x;
+    wave_prologue(hg, smem, lane);
+    const int yy = lane >> 3, zz = lane & 7;
+    const float* __restrict__ vol = vol0 + sp.sample * hg.vol_bstride;
+    float* __restrict__ img = img0 + sp.sample * hg.img_bstride;
+
+    RowWalk rw;
+    rw.oz = sp.tz * kT + zz;
+    rw.oy = sp.ty * kT + yy;
+    rw.vzy = rw.oz < hg.out_len[0] && rw.oy < hg.out_len[1];
+    rw.qrow = qtab + sp.sample * hg.q_bstride +
+              ((long long)min(rw.oz, hg.out_len[0] - 1) * hg.out_len[1] + min(rw.oy, hg.out_len[1] - 1)) * (4 * hg.ncpx);
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+        rw.Pzy[h] = AFFINE ? fma(hp->affine[h * 4 + 0], (double)rw.oz,
+                                 fma(hp->affine[h * 4 + 1], (double)rw.oy, hp->affine[h * 4 + 3] + hp->offd[h]))
+                           : 0.0;
+    const int obase = rw.oz * hg.img_sz + rw.oy * hg.img_sy;
+    QCols qc;
+    {
+        XEntry xe;
+        xentry_load(xt, min(sp.tx0 * kT, hg.out_len[2] - 1), xe);
+        qcols_load(qc, rw.qrow, xe.idx);
+    }
+
+    for (int ti = 0; ti < sp.ntile; ++ti) {
+        const int tile_id = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti;
+        const int ox_tile = (sp.tx0 + ti) * kT;
+        // whole tile first; if its box does not fit the wave's LDS, two halves along x
+        int nsub = 1, nx = kT;
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int ox0 = ox_tile + sub * nx;
+            int lo[3], hi[3];
+            row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox0, nx, lo, hi);
+            BoxLayout bl;
+            fwd_layout<ORDER>(lo, hi, hg.box_cap, bl);
+            if (nsub == 1 && hg.boxes && lane < 6) {      // EDHIP_FLAG_KEEP_BOXES: the box goes to the gradient call too
+                const int v = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2] : lane == 3 ? hi[0]
+                              : lane == 4 ? hi[1] : hi[2];
+                hg.boxes[(size_t)tile_id * 8 + lane] = v;
+            }
+            if (bl.any && !bl.fits) {
+                if (nsub == 1) {
+                    nsub = 2;
+                    nx = kT / 2;
+                    sub = -1;           // start over with the halves
+                    continue;
+                }
+                if (lane == 0) {        // hand the whole tile to the general kernels
+                    const int slot = atomicAdd(&hg.spill[0], 1);
+                    hg.spill[1 + slot] = tile_id;
+                }
+                break;
+            }
+            const int ps = bl.ps;
+            for (long long ss = 0; ss < hg.nsteps; ++ss) {
+                long long vol_off = 0, img_off = 0;
+                if (hg.nstep)
+                    wave_step_offsets(hp, ss, vol_off, img_off);
+#ifdef EDHIP_EXPERIMENTS
+                if (!(hg.dbg & 2))             // ablation: no staging
+#endif
+                if (bl.any) {
+                    // (the previous gather's reads have all returned: their values were stored)
+                    fwd_stage(hg, bl, vol + vol_off, box, lane);
+                    __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0) lgkmcnt(0): this wave's copies have landed
+                    asm volatile("" ::: "memory");
+                }
+                // ---- pass 2: coordinates again, weights, gather; two voxels at a time, one 16-byte
+                //      store per four ------------------------------------------------------------------
+                float o0 = 0.f, o1 = 0.f;
+                float* op = img + (img_off + obase + ox0);
+                const int last = hg.out_len[2] - 1;
+                XEntry ea, eb;
+                xentry_load(xt, min(ox0, last), ea);
+                xentry_load(xt, min(ox0 + 1, last), eb);
+#pragma unroll 1
+                for (int k = 0; k < nx; k += 2) {
+                    const int ox = ox0 + k;
+                    int st[2][3];
+                    float fr[2][3];
+                    bool live[2];
+                    live[0] = !entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, ea, ox, st[0], fr[0]) && rw.vzy && ox <= last;
+                    live[1] = !entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, eb, ox + 1, st[1], fr[1]) && rw.vzy && ox + 1 <= last;
+                    xentry_load(xt, min(ox + 2, last), ea);       // (arrive during the gather)
+                    xentry_load(xt, min(ox + 3, last), eb);
+                    float val[2] = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float w0[NT], w1[NT], w2[NT];
+                        weights_from_frac<float, ORDER>(fr[i][0], w0);
+                        weights_from_frac<float, ORDER>(fr[i][1], w1);
+                        weights_from_frac<float, ORDER>(fr[i][2], w2);
+                        // (a voxel that is not gathered reads the head of the box: no divergence)
+                        const int rz = live[i] ? st[i][0] - bl.b0[0] : 0, ry = live[i] ? st[i][1] - bl.b0[1] : 0,
+                                  rx = live[i] ? st[i][2] - bl.b0[2] : 0;
+                        const float* bp = box + (rz * ps + ry * kPitch + (rx & ~1));
+#ifdef EDHIP_EXPERIMENTS
+                        if (hg.dbg & 1)            // ablation: no gather
+                            val[i] = fr[i][0] + fr[i][1] + fr[i][2] + w0[1];
+                        else
+#endif
+                        if (bl.any)
+                            val[i] = wave_gather<ORDER, gather_bufs<ORDER>()>(bp, ps, rx & 1, w0, w1, w2);
+                    }
+                    val[0] = live[0] ? val[0] : hg.cval;
+                    val[1] = live[1] ? val[1] : hg.cval;
+                    if (!(k & 2)) {            // (k is wave-uniform)
+                        o0 = val[0];
+                        o1 = val[1];
+                    } else if (rw.vzy) {
+                        // streaming stores: the wave fills 16-byte pieces of 64 rows; the rest of each
+                        // 128-byte line follows from this same wave within the strip
+                        float* o = op + (k - 2);
+#ifdef EDHIP_EXPERIMENTS
+                        if ((hg.dbg & 8) && val[0] != -12345.678f)         // ablation: no stores
+                            continue;
+#endif
+                        if (ox + 1 <= last) {
+                            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                            f4u v4;
+                            v4.x = o0;
+                            v4.y = o1;
+                            v4.z = val[0];
+                            v4.w = val[1];
+                            __builtin_nontemporal_store(v4, reinterpret_cast<f4u*>(o));
+                        } else {
+                            if (ox - 2 <= last)
+                                __builtin_nontemporal_store(o0, &o[0]);
+                            if (ox - 1 <= last)
+                                __builtin_nontemporal_store(o1, &o[1]);
+                            if (ox <= last)
+                                __builtin_nontemporal_store(val[0], &o[2]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// K2: gradient.  Same walk; the box is an accumulator of fixed-point cells (ds_add_u32 sustains one
+// wave-instruction per ~4 cycles on MI355X, ds_add_f32 one per ~190: profiles/r02_ubench_lds.txt)
+// in a per-tile scale derived from the tile's sum of |dY|, flushed by its own wave with one float
+// atomic per touched source element (deform.c:926-997; see deform_tile.hip for the no-overflow bound).
+// ================================================================================================
+__device__ __forceinline__ int round_half_up_i32(float x)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));      // (int)floor(x + 0.5) in one instruction
+    return r;
+}
+
+struct CellLayout {
+    int b0[3], ext[3];
+    int ps;               // cells per plane (rows are ext[2] cells: tight)
+    bool any, fits;
+};
+__device__ __forceinline__ void grad_layout(const int (&lo)[3], const int (&hi)[3], int box_cap, CellLayout& cl)
+{
+    cl.any = hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2];
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        cl.b0[h] = lo[h];
+        cl.ext[h] = cl.any ? hi[h] - lo[h] + 1 : 0;
+    }
+    cl.ps = cl.ext[1] * cl.ext[2];
+    cl.fits = (unsigned)cl.ext[0] <= 1024u && (unsigned)cl.ext[1] <= 1024u && (unsigned)cl.ext[2] <= 1024u &&
+              cl.ext[0] * cl.ps <= box_cap;
+}
+
+template <int ORDER, bool AFFINE>
+__global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, const AxTab* __restrict__ xt,
+                                                          const double* __restrict__ qtab,
+                                                          const float* __restrict__ dy0, float* __restrict__ dx0)
+{
+    constexpr int NT = ORDER + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HotParams* hp = reinterpret_cast<const HotParams*>(smem);
+    int* cells = reinterpret_cast<int*>(smem + kWaveHead);
+    WaveStrip sp;
+    if (!wave_strip(hg, sp, blockIdx.x))
+        return;
+    const int lane = threadIdx.x;
+    // the accumulator cells start at zero and every flush leaves the cells it read at zero again
+    for (int e = lane * 4; e < hg.box_cap; e += 256)
+        *reinterpret_cast<int4*>(cells + e) = make_int4(0, 0, 0, 0);
+    wave_prologue(hg, smem, lane);
+    // lane -> (z, y): the 16 lanes that go through the LDS atomic unit together hold rows two apart
+    // along z and y.  Neighbouring voxels share a window start wherever the deformation compresses,
+    // and two lanes adding into one cell serialise the atomic (4.2 -> 6.0 cycles).
+    const int zz = 2 * (lane & 3) + ((lane >> 4) & 1);
+    const int yy = 2 * ((lane >> 2) & 3) + ((lane >> 5) & 1);
+    const float* __restrict__ dy = dy0 + sp.sample * hg.img_bstride;
+    float* __restrict__ dx = dx0 + sp.sample * hg.vol_bstride;
+
+    RowWalk rw;
+    rw.oz = sp.tz * kT + zz;
+    rw.oy = sp.ty * kT + yy;
+    rw.vzy = rw.oz < hg.out_len[0] && rw.oy < hg.out_len[1];
+    rw.qrow = qtab + sp.sample * hg.q_bstride +
+              ((long long)min(rw.oz, hg.out_len[0] - 1) * hg.out_len[1] + min(rw.oy, hg.out_len[1] - 1)) * (4 * hg.ncpx);
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+        rw.Pzy[h] = AFFINE ? fma(hp->affine[h * 4 + 0], (double)rw.oz,
+                                 fma(hp->affine[h * 4 + 1], (double)rw.oy, hp->affine[h * 4 + 3] + hp->offd[h]))
+                           : 0.0;
+    const int obase = rw.oz * hg.img_sz + rw.oy * hg.img_sy;
+    QCols qc;
+    {
+        XEntry xe;
+        xentry_load(xt, min(sp.tx0 * kT, hg.out_len[2] - 1), xe);
+        qcols_load(qc, rw.qrow, xe.idx);
+    }
+    // |sum in a cell| <= max tap weight * sum over the tile of |dY|: this scale cannot overflow
+    // (the 0.1 % margin covers the two roundings of the reciprocal and the product)
+    constexpr float kC = (float)((2147483648.0 - 1024.0) /
+                                 ((ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : ORDER == 3 ? 0.2963
+                                   : ORDER == 4 ? 0.2150 : 0.1664) * 1.001));
+
+    for (int ti = 0; ti < sp.ntile; ++ti) {
+        const int tile_id = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti;
+        const int ox_tile = (sp.tx0 + ti) * kT;
+        // the tile's box: handed over by the forward call (EDHIP_FLAG_USE_BOXES) or pass 1
+        bool given = hg.use_boxes != 0;
+        int lo[3], hi[3];
+        if (given) {
+            const int* bx = hg.boxes + (size_t)tile_id * 8;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                lo[h] = uni(bx[h]);
+                hi[h] = uni(bx[3 + h]);
+            }
+        } else
+            row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox_tile, kT, lo, hi);
+        CellLayout cl;
+        grad_layout(lo, hi, hg.box_cap, cl);
+        int nsub = 1, nx = kT;
+        CellLayout half0, half1;
+        half0 = half1 = cl;
+        if (!cl.fits) {
+            // two halves along x, each with a box of its own; nothing has been scattered yet, so a
+            // tile whose halves do not fit either can still go to the general kernels as a whole
+            given = false;
+            row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox_tile, kT / 2, lo, hi);
+            grad_layout(lo, hi, hg.box_cap, half0);
+            row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox_tile + kT / 2, kT / 2, lo, hi);
+            grad_layout(lo, hi, hg.box_cap, half1);
+            if (!(half0.fits && half1.fits)) {
+                if (lane == 0) {
+                    const int slot = atomicAdd(&hg.spill[0], 1);
+                    hg.spill[1 + slot] = tile_id;
+                }
+                continue;
+            }
+            nsub = 2;
+            nx = kT / 2;
+        }
+        for (int sub = 0; sub < nsub; ++sub) {
+            if (nsub == 2)
+                cl = sub ? half1 : half0;
+            if (!cl.any && !given)
+                continue;          // nothing to scatter (uniform): every voxel maps to the constant
+            const int ox0 = ox_tile + sub * nx;
+            const int px = cl.ext[2], ps = cl.ps;
+            const bool interior = cl.b0[0] >= 0 && cl.b0[0] + cl.ext[0] <= hg.in_len[0] && cl.b0[1] >= 0 &&
+                                  cl.b0[1] + cl.ext[1] <= hg.in_len[1] && cl.b0[2] >= 0 &&
+                                  cl.b0[2] + cl.ext[2] <= hg.in_len[2];
+            for (long long ss = 0; ss < hg.nsteps; ++ss) {
+                long long vol_off = 0, img_off = 0;
+                if (hg.nstep)
+                    wave_step_offsets(hp, ss, vol_off, img_off);
+                float* dst = dx + vol_off;
+                // dY of the lane's row
+                float g[kT];
+                {
+                    const float* gp = dy + (img_off + obase + ox0);
+                    float gm = 0.f;
+#pragma unroll
+                    for (int k = 0; k < kT; ++k) {
+                        g[k] = (k < nx && rw.vzy && ox0 + k < hg.out_len[2]) ? gp[k] : 0.f;
+                        // inf / NaN gradients have no fixed-point scale: left out of the sum, scattered
+                        // with float atomics below
+                        gm += (__float_as_int(g[k]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(g[k]);
+                    }
+                    gm = wave_sum(gm);
+                    const float scale = gm > 0.f ? fminf(kC * __frcp_rn(gm), 3.0e38f) : 0.f;
+                    const float inv_scale = gm > 0.f ? __frcp_rn(scale) : 0.f;
+
+                    // ---- pass 2: coordinates again, weights, scatter into the cells -------------------
+#pragma unroll 1
+                    for (int k = 0; k < nx; ++k) {
+                        float gv = g[0];
+#pragma unroll
+                        for (int j = 1; j < kT; ++j)
+                            gv = k == j ? g[j] : gv;       // (k is wave-uniform)
+                        const int ox = ox0 + k;
+                        int st[3];
+                        float fr[3];
+                        const bool cst = row_voxel<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox, st, fr);
+                        if (gv == 0.f || cst)
+                            continue;      // constant voxels contribute nothing (deform.c:928)
+                        float w0[NT], w1[NT], w2[NT];
+                        weights_from_frac<float, ORDER>(fr[0], w0);
+                        weights_from_frac<float, ORDER>(fr[1], w1);
+                        weights_from_frac<float, ORDER>(fr[2], w2);
+                        const int rz = st[0] - cl.b0[0], ry = st[1] - cl.b0[1], rx = st[2] - cl.b0[2];
+                        // boxes handed over by the forward call are a hint: a window outside goes the direct way
+                        const bool outside = given && (rz < 0 || rz + ORDER >= cl.ext[0] || ry < 0 ||
+                                                       ry + ORDER >= cl.ext[1] || rx < 0 || rx + ORDER >= cl.ext[2]);
+                        if ((__float_as_int(gv) & 0x7f800000) == 0x7f800000 || outside) {
+                            // inf / NaN gradient (no fixed-point scale), or a window outside a stale box:
+                            // this voxel scatters its taps with float atomics straight to global memory
+#pragma unroll 1
+                            for (int t = 0; t < NT * NT * NT; ++t) {
+                                const int l0 = t / (NT * NT), l1 = (t / NT) % NT, l2 = t % NT;
+                                const int zs = mirror_i32(st[0] + l0, hg.in_len[0]);
+                                const int ys = mirror_i32(st[1] + l1, hg.in_len[1]);
+                                const int xs = mirror_i32(st[2] + l2, hg.in_len[2]);
+                                float wp = w0[0], wq = w1[0], wr = w2[0];
+#pragma unroll
+                                for (int l = 1; l < NT; ++l) {
+                                    wp = l0 == l ? w0[l] : wp;
+                                    wq = l1 == l ? w1[l] : wq;
+                                    wr = l2 == l ? w2[l] : wr;
+                                }
+                                unsafeAtomicAdd(dst + (zs * hg.vol_sz + ys * hg.vol_sy + xs), gv * wp * wq * wr);
+                            }
+                            continue;
+                        }
+                        int* bp = cells + (rz * ps + ry * px + rx);
+                        const float gs = gv * scale;
+#pragma unroll
+                        for (int l0 = 0; l0 < NT; ++l0) {
+                            const float g0 = gs * w0[l0];
+#pragma unroll
+                            for (int l1 = 0; l1 < NT; ++l1) {
+                                const float g1 = g0 * w1[l1];
+                                int* rp = bp + (l0 * ps + l1 * px);
+#pragma unroll
+                                for (int l2 = 0; l2 < NT; ++l2)
+                                    atomicAdd(reinterpret_cast<unsigned*>(rp + l2),
+                                              (unsigned)round_half_up_i32(g1 * w2[l2]));
+                            }
+                        }
+                    }
+                    // ---- flush: one float atomic per touched source element (mirror-mapped at the edges,
+                    //      deform.c:791-813); the wave's own DS operations are ordered, no barrier ----------
+                    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0)
+                    asm volatile("" ::: "memory");
+                    {
+                        constexpr int FU = 4;                  // rows in flight per lane
+                        const int nrows = cl.ext[0] * cl.ext[1];
+                        const float inv_by = 1.f / (float)cl.ext[1];
+                        // 16 lanes per box row (4 rows per instruction) while the rows are that short
+                        const int fl = px <= 16 ? 16 : 64, fr_ = 64 / fl;
+                        const int subl = lane & (fl - 1), rslot = px <= 16 ? lane >> 4 : 0;
+                        for (int xo = 0; xo < px; xo += fl) {
+                            const int xi = xo + subl;
+                            const bool xin = xi < px;
+                            const int xs = interior ? cl.b0[2] + xi : mirror_i32(cl.b0[2] + min(xi, px - 1), hg.in_len[2]);
+                            for (int r0 = rslot; r0 < nrows; r0 += FU * fr_) {
+                                int acc[FU];
+#pragma unroll
+                                for (int u = 0; u < FU; ++u) {
+                                    const int r = r0 + u * fr_;
+                                    // read and reset in one LDS operation (ds_wrxchg_rtn_b32)
+                                    acc[u] = (xin && r < nrows)
+                                                 ? __hip_atomic_exchange(&cells[r * px + xi], 0, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_WORKGROUP)
+                                                 : 0;
+                                }
+#pragma unroll
+                                for (int u = 0; u < FU; ++u) {
+                                    if (acc[u] != 0) {
+                                        const int r = r0 + u * fr_;
+                                        const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * cl.ext[1];
+                                        int rowoff;
+                                        if (interior)
+                                            rowoff = (cl.b0[0] + zr) * hg.vol_sz + (cl.b0[1] + yr) * hg.vol_sy;
+                                        else
+                                            rowoff = mirror_i32(cl.b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
+                                                     mirror_i32(cl.b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+                                        unsafeAtomicAdd(dst + (rowoff + xs), (float)acc[u] * inv_scale);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// bytes of LDS per wave (one workgroup = one wave): 160 KiB / 12 in the hardware's allocation granule
+constexpr int kWaveLdsBytes = 12800;
+
+template <int ORDER>
+hipError_t launch_wave_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t lds, hipStream_t stream)
+{
+    if (gradient) {
+        if (hg.has_affine)
+            hipLaunchKernelGGL((wave_grad_kernel<ORDER, true>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+                               hg.img_r, hg.vol_w);
+        else
+            hipLaunchKernelGGL((wave_grad_kernel<ORDER, false>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+                               hg.img_r, hg.vol_w);
+        return hipGetLastError();
+    }
+    if (hg.has_affine)
+        hipLaunchKernelGGL((wave_fwd_kernel<ORDER, true>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+                           hg.vol_r, hg.img_w);
+    else
+        hipLaunchKernelGGL((wave_fwd_kernel<ORDER, false>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+                           hg.vol_r, hg.img_w);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// LDS per wave and the box capacity (floats / cells) that leaves
+size_t wave_lds_bytes(bool gradient, int* box_cap)
+{
+    (void)gradient;
+    *box_cap = (kWaveLdsBytes - kWaveHead) / 4;
+    return kWaveLdsBytes;
+}
+
+hipError_t launch_wave_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds,
+                              hipStream_t stream)
+{
+    switch (order) {
+    case 1: return launch_wave_order<1>(hg, gradient, nblk, lds, stream);
+    case 2: return launch_wave_order<2>(hg, gradient, nblk, lds, stream);
+    case 3: return launch_wave_order<3>(hg, gradient, nblk, lds, stream);
+    case 4: return launch_wave_order<4>(hg, gradient, nblk, lds, stream);
+    case 5: return launch_wave_order<5>(hg, gradient, nblk, lds, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
+}  // namespace tile
+}  // namespace ed

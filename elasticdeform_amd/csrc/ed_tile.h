@@ -381,5 +381,12 @@ hipError_t launch_hot_level1(const HotGeom& hg, int order, bool gradient, unsign
                              hipStream_t stream);
 size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box);
 
+// one-wavefront-per-tile kernels (deform_wave.hip): same argument block; `strip_tiles`, `strips_x`,
+// `nstrips`, `total_strips` describe the strips of the 64-thread workgroups, `box_cap` the floats /
+// cells of LDS one wave owns
+hipError_t launch_wave_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds,
+                              hipStream_t stream);
+size_t wave_lds_bytes(bool gradient, int* box_cap);
+
 }  // namespace tile
 }  // namespace ed
