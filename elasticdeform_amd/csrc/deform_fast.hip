@@ -662,7 +662,7 @@ hipError_t launch_typed(const GridGeom& g, const IOView& v, int gradient, hipStr
     if (nblk > 0x7fffffffLL || xblocks > 0x7fffffffLL)
         return hipErrorInvalidValue;
     if constexpr (NAXIS == 2 && ORDER >= 1) {
-        if (gradient && !getenv("EDHIP_2D_DIRECT_GRAD")) {
+        if (gradient && !ed_env("EDHIP_2D_DIRECT_GRAD")) {
             const int64_t rblocks2 = (nrows + kRows2 - 1) / kRows2;
             const int64_t nblk2 = xblocks * rblocks2;
             if (nblk2 > 0x7fffffffLL)

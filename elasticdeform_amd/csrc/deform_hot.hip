@@ -23,7 +23,6 @@
 // for the phase-by-phase mapping).
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 
 #include "ed_device.h"
 #include "ed_params.h"
@@ -990,7 +989,8 @@ template <int ORDER>
 hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t lds, hipStream_t stream)
 {
     if (gradient) {
-        static const int duo = getenv("EDHIP_GRAD_DUO") ? atoi(getenv("EDHIP_GRAD_DUO")) : 0;
+#ifdef EDHIP_EXPERIMENTS
+        const int duo = ed_env("EDHIP_GRAD_DUO") ? atoi(ed_env("EDHIP_GRAD_DUO")) : 0;
         if (duo && !hg.has_affine && ORDER == 3) {
             if constexpr (ORDER == 3) {
                 auto kern = hot_grad_kernel<ORDER, false, 4, 16, 2>;
@@ -1003,26 +1003,37 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
                 const unsigned per = nblk / 8;
                 hipLaunchKernelGGL(kern, dim3(8 * ((per + 1) / 2)), dim3(2 * kBlock), 2 * (size_t)hg.lds_grp, stream, hg);
             }
-        } else if (hg.has_affine)
+            return hipGetLastError();
+        }
+#endif
+        if (hg.has_affine)
             hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
         else
             hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
     } else {
-        if (hg.has_affine)
-            hipLaunchKernelGGL((hot_fwd_kernel<ORDER, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
-        else if (ORDER == 3 && getenv("EDHIP_HOT_ABL")) {
+#ifdef EDHIP_EXPERIMENTS
+        // profiling builds of the forward kernel (see hot_fwd_kernel's ABL switches)
+        if (!hg.has_affine && ORDER == 3 && ed_env("EDHIP_HOT_ABL")) {
             if constexpr (ORDER == 3) {
-                switch (atoi(getenv("EDHIP_HOT_ABL"))) {
+                switch (atoi(ed_env("EDHIP_HOT_ABL"))) {
 #define ED_ABL_CASE(A) case A: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, A>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
                 ED_ABL_CASE(32768) ED_ABL_CASE(8192) ED_ABL_CASE(16384) ED_ABL_CASE(16512) ED_ABL_CASE(128) ED_ABL_CASE(16) ED_ABL_CASE(1024) ED_ABL_CASE(4096) ED_ABL_CASE(5120) ED_ABL_CASE(7168) ED_ABL_CASE(3072) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
 #undef ED_ABL_CASE
                 default: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
                 }
             }
-        } else if (getenv("EDHIP_HOT_NTH512") && atoi(getenv("EDHIP_HOT_NTH512")) == 8)
-            hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, 0, 512, 8>), dim3(nblk), dim3(512), lds, stream, hg);
-        else if (getenv("EDHIP_HOT_NTH512"))
-            hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, 0, 512, 6>), dim3(nblk), dim3(512), lds, stream, hg);
+            return hipGetLastError();
+        }
+        if (!hg.has_affine && ed_env("EDHIP_HOT_NTH512")) {
+            if (atoi(ed_env("EDHIP_HOT_NTH512")) == 8)
+                hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, 0, 512, 8>), dim3(nblk), dim3(512), lds, stream, hg);
+            else
+                hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, 0, 512, 6>), dim3(nblk), dim3(512), lds, stream, hg);
+            return hipGetLastError();
+        }
+#endif
+        if (hg.has_affine)
+            hipLaunchKernelGGL((hot_fwd_kernel<ORDER, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
         else
             hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg);
     }
@@ -1040,7 +1051,7 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box)
     *off_box = (int)off;
     if (gradient) {
         size_t box = kGradBoxBytes;
-        if (const char* kb = getenv("EDHIP_GRAD_BOX_KB"))
+        if (const char* kb = ed_env("EDHIP_GRAD_BOX_KB"))
             box = (size_t)atoi(kb) * 1024;
         *box_cap = (int)(box / 4);
         const size_t total = off + box;
@@ -1049,9 +1060,9 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box)
     // forward: two shifted float copies; 4 workgroups per CU -> 40960 bytes each (wide control
     // grids: a 64 KiB block, fewer workgroups per CU)
     size_t budget = 40 * 1024;
-    if (const char* kb = getenv("EDHIP_HOT_FWD_KB"))      // experiment: fewer workgroups per CU
+    if (const char* kb = ed_env("EDHIP_HOT_FWD_KB"))      // experiment: fewer workgroups per CU
         budget = (size_t)atoi(kb) * 1024;
-    if (const char* abl = getenv("EDHIP_HOT_ABL")) {      // experiments (see hot_fwd_kernel)
+    if (const char* abl = ed_env("EDHIP_HOT_ABL")) {      // experiments (see hot_fwd_kernel)
         const int a = atoi(abl);
         if (a & 1024) {                                    // Q rows stay in global memory
             *off_box = kOffQ;

@@ -1177,10 +1177,10 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     size_t overlay = (box + 15) & ~(size_t)15;
     tg.off_ov = (int)(kOffQ + ((q_bytes(g) + 15) & ~(size_t)15));
     size_t lds = tg.off_ov + overlay;
-    if (const char* pad = getenv("EDHIP_LDS_PAD"))
+    if (const char* pad = ed_env("EDHIP_LDS_PAD"))
         lds += (size_t)atoi(pad);
     {
-        const char* dbg = getenv("EDHIP_TILE_DBG");
+        const char* dbg = ed_env("EDHIP_TILE_DBG");
         tg.dbg = dbg ? atoi(dbg) : 0;
     }
     // scratch: first-level spill list | second-level spill list | x table | Q
@@ -1240,10 +1240,10 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     profile_mark(false, stream);
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips * nb + 7) / 8) * 8);
-        constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
+        [[maybe_unused]] constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
         if constexpr (std::is_same<T, float>::value && ORDER >= 1) {
             // float32, unit stride along x on both sides: the benchmark kernels of deform_hot.hip
-            if (tg.in_stride[2] == 1 && tg.out_stride[2] == 1 && !(tg.dbg & 512) && !getenv("EDHIP_NO_HOT")) {
+            if (tg.in_stride[2] == 1 && tg.out_stride[2] == 1 && !(tg.dbg & 512) && !ed_env("EDHIP_NO_HOT")) {
                 memset(&hg, 0, sizeof(hg));
                 hg.vol_r = reinterpret_cast<const float*>(ve.in);
                 hg.vol_w = reinterpret_cast<float*>(const_cast<char*>(ve.in));
@@ -1294,7 +1294,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 KeepKey cur;
                 memset(&cur, 0, sizeof(cur));
                 const int box_mode = batch ? batch->box_mode : 0;
-                if (hlds && box_mode && !getenv("EDHIP_NO_BOXES")) {
+                if (hlds && box_mode && !ed_env("EDHIP_NO_BOXES")) {
                     hipError_t ke = hipSuccess;
                     int* kb = (int*)keep_reserve(stream, (size_t)ntiles * nb * 8 * sizeof(int), &key, &ke);
                     if (kb) {
@@ -1328,14 +1328,25 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         }
                     }
                 }
-                // one wavefront per tile (deform_wave.hip): strips of 4 tiles per 64-thread workgroup
-                static const int wave_mode = getenv("EDHIP_WAVE") ? atoi(getenv("EDHIP_WAVE")) : 3;
+                // Orders 4 / 5 run on the wave-per-tile kernels (deform_wave.hip: one wavefront per tile,
+                // one copy of the box, tiles that do not fit taken as two x-halves): the 4-wave kernels
+                // give up on a tile as soon as its 5- / 6-tap windows need the wide row pitch, and at
+                // these orders that is a large share of the tiles (256^3, sigma 5, whole call: order 4
+                // forward 419 -> 339 us, order 5 gradient 944 -> 886 us; profiles/r03_wave_vs_4wave.txt).
+                // Orders 1-3 stay on the 4-wave kernels, which are 10-30 % faster there.
                 bool wave_done = false;
+                int wave_mode = ORDER >= 4 ? 3 : 0;
+#ifdef EDHIP_EXPERIMENTS
+                if (const char* wm = ed_env("EDHIP_WAVE"))        // 1 forward, 2 gradient, 3 both, 0 neither
+                    wave_mode = atoi(wm);
+#endif
                 if (hlds && (wave_mode & (GRAD ? 2 : 1))) {
                     HotGeom wg = hg;
                     wg.strip_tiles = 4;
-                    if (const char* st = getenv("EDHIP_WAVE_STRIP"))
+#ifdef EDHIP_EXPERIMENTS
+                    if (const char* st = ed_env("EDHIP_WAVE_STRIP"))
                         wg.strip_tiles = atoi(st);
+#endif
                     while (wg.strip_tiles > 1 &&
                            (int64_t)nb * tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + wg.strip_tiles - 1) / wg.strip_tiles) < 8192)
                         wg.strip_tiles >>= 1;
@@ -1344,13 +1355,22 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     if (wstrips * nb <= 0x3fffffffLL) {
                         wg.nstrips = (int)wstrips;
                         wg.total_strips = (int)(wstrips * nb);
-                        size_t wlds = wave_lds_bytes(GRAD, &wg.box_cap);
-                        if (const char* kb = getenv("EDHIP_WAVE_LDS")) {
+                        int occ = 3;
+#ifdef EDHIP_EXPERIMENTS
+                        if (const char* oc = ed_env("EDHIP_WAVE_OCC"))
+                            occ = atoi(oc);
+#endif
+                        size_t wlds = wave_lds_bytes(GRAD, occ, &wg.box_cap);
+#ifdef EDHIP_EXPERIMENTS
+                        if (const char* kb = ed_env("EDHIP_WAVE_LDS")) {
                             wlds = (size_t)atoi(kb);
-                            wg.box_cap = (int)(wlds / 4);
+                            wg.box_cap = (int)((wlds - 416) / 4);
                         }
+                        if (const char* pp = ed_env("EDHIP_DEBUG_PTR"))
+                            wg.dbgbuf = (unsigned long long*)strtoull(pp, nullptr, 16);
+#endif
                         const unsigned wblk = (unsigned)(((wstrips * nb + 7) / 8) * 8);
-                        const hipError_t he = launch_wave_level1(wg, ORDER, GRAD, wblk, wlds, stream);
+                        const hipError_t he = launch_wave_level1(wg, ORDER, GRAD, wblk, wlds, occ, stream);
                         if (he == hipSuccess) {
                             hot_done = wave_done = true;
                             if (!GRAD && hg.boxes && key)
@@ -1376,6 +1396,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         else if (GRAD)
             hipLaunchKernelGGL((deform_tile3_grad_kernel<T, (ORDER < 1 ? 2 : ORDER), 16>), dim3(nblk),
                                dim3(kBlock), lds, stream, g, ve, tg);
+#ifdef EDHIP_EXPERIMENTS
         else if (kBenchKernel && tg.dbg) {
             if constexpr (kBenchKernel) {
             // profiling builds of the benchmark kernel (EDHIP_TILE_DBG), never used otherwise
@@ -1389,7 +1410,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
             default: hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR, 0>), dim3(nblk), dim3(kBlock), lds, stream, g, ve, tg); break;
             }
             }
-        } else
+        }
+#endif
+        else
             hipLaunchKernelGGL((deform_tile3_fwd_kernel<T, ORDER, PAIR>), dim3(nblk), dim3(kBlock),
                                lds, stream, g, ve, tg);
         e = hipGetLastError();
@@ -1406,7 +1429,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     t2.box_cap = (int)((box2 - (GRAD ? 64 : 0)) / sizeof(T));      // gradient: cells of sizeof(T) + wave sums
     const size_t lds2 = t2.off_ov + box2;
     const unsigned n2 = (unsigned)(ntiles * nb < 512 ? ntiles * nb : 512);
-    const bool skip_l2 = getenv("EDHIP_SKIP_L2") != nullptr;      // debugging aid
+    const bool skip_l2 = ed_env("EDHIP_SKIP_L2") != nullptr;      // debugging aid
     if (e == hipSuccess && !skip_l2) {
         if (GRAD)
             hipLaunchKernelGGL((deform_tile3_grad_kernel<T, (ORDER < 1 ? 2 : ORDER), 8>), dim3(n2),
@@ -1425,7 +1448,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                            0, stream, g, ve, t3);
         e = hipGetLastError();
     }
-    if (e == hipSuccess && getenv("EDHIP_PRINT_SPILL")) {      // debugging aid: tiles per level
+    if (e == hipSuccess && ed_env("EDHIP_PRINT_SPILL")) {      // debugging aid: tiles per level
         int c1 = 0, c2 = 0;
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(&c1, list_a, 4, hipMemcpyDeviceToHost);

@@ -95,12 +95,8 @@ struct WaveStrip {
 
 // strips are dealt to the 8 XCDs in contiguous chunks (block b runs on XCD b % 8): neighbouring
 // strips, whose source boxes overlap, share an L2
-__device__ __forceinline__ bool wave_strip(const HotGeom& hg, WaveStrip& sp, int b)
+__device__ __forceinline__ void strip_decode(const HotGeom& hg, WaveStrip& sp, int s)
 {
-    const int per = (hg.total_strips + 7) >> 3;
-    int s = (b & 7) * per + (b >> 3);
-    if ((b >> 3) >= per || s >= hg.total_strips)
-        return false;
     sp.sample = s / hg.nstrips;
     s -= sp.sample * hg.nstrips;
     const int sx = s % hg.strips_x;
@@ -109,9 +105,16 @@ __device__ __forceinline__ bool wave_strip(const HotGeom& hg, WaveStrip& sp, int
     sp.tz = s / hg.tiles[1];
     sp.tx0 = sx * hg.strip_tiles;
     sp.ntile = min(hg.strip_tiles, hg.tiles[2] - sp.tx0);
+}
+__device__ __forceinline__ bool wave_strip(const HotGeom& hg, WaveStrip& sp, int b)
+{
+    const int per = (hg.total_strips + 7) >> 3;
+    const int s = (b & 7) * per + (b >> 3);
+    if ((b >> 3) >= per || s >= hg.total_strips)
+        return false;
+    strip_decode(hg, sp, s);
     return true;
 }
-
 // The lane's control columns of its Q row: 4 columns x 3 components (fp64), reloaded when the
 // wave-uniform index tuple of the x table changes (once per control interval).
 struct QCols {
@@ -129,6 +132,10 @@ __device__ __forceinline__ void qcols_load(QCols& qc, const double* __restrict__
         qc.v[l][2] = qrow[idx[l] + 2];
         qc.idx[l] = idx[l];
     }
+    // Wait HERE, on the rare path.  Otherwise the compiler puts s_waitcnt vmcnt(0) at the join in front
+    // of every voxel's coordinates, and there it also waits for the output stores / flush atomics this
+    // wave has in flight (vmcnt counts those too): a memory round trip per voxel.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
 // Phase A for one voxel (deform.c:649-824): displacement from the lane's control columns with the
@@ -313,23 +320,23 @@ __device__ __forceinline__ void row_box(const HotGeom& hg, const HotParams* hp, 
 // ================================================================================================
 // K1: forward
 // ================================================================================================
-// Box geometry of one (sub-)tile in LDS: element (rz, ry, rx) at rz * ps + ry * 16 + rx
-constexpr int kPitch = 16;
-// z-planes of taps in flight per voxel: two up to order 3 (152 VGPRs: three waves per SIMD, which is
-// what 12.5 KiB of LDS per wave allows anyway), one for the wider windows of orders 4 / 5
-#ifndef ED_GATHER_BUFS
-#define ED_GATHER_BUFS 2
-#endif
-template <int ORDER>
-constexpr int gather_bufs() { return ORDER <= 3 ? ED_GATHER_BUFS : 1; }
+// Box geometry of one (sub-)tile in LDS: element (rz, ry, rx) at rz * ps + ry * pitch + rx; the pitch
+// is 16 floats for a whole tile and 12 where that is enough (the x-halves of a split tile): both are
+// whole 16-byte chunks, which LDS-DMA needs, and put the (z, y) rows of a 32-lane group on different
+// bank pairs together with the odd plane stride.
 struct BoxLayout {
     int b0[3], ext[3];
-    int ps;
+    int pitch, ps;
     bool any, fits;
 };
+// z-planes of taps in flight per voxel (one plane is requested ahead where the registers allow it:
+// three waves per SIMD, orders up to 3)
+template <int ORDER, int OCC>
+constexpr int gather_bufs() { return (ORDER <= 3 && OCC <= 3) ? 2 : 1; }
 
 template <int ORDER>
-__device__ __forceinline__ void fwd_layout(const int (&lo)[3], const int (&hi)[3], int box_cap, BoxLayout& bl)
+__device__ __forceinline__ void fwd_layout(const int (&lo)[3], const int (&hi)[3], int box_cap, bool half,
+                                           BoxLayout& bl)
 {
     constexpr int NT = ORDER + 1;
     constexpr int NP = (NT + 2) / 2;          // aligned pairs that cover a window at either parity
@@ -341,8 +348,9 @@ __device__ __forceinline__ void fwd_layout(const int (&lo)[3], const int (&hi)[3
     }
     // columns the reads can touch: the last window starts at ext_x - NT, its first pair at that & ~1
     const int need = ((bl.ext[2] - NT) & ~1) + 2 * NP;
-    bl.ps = bl.ext[1] * kPitch + 2;           // planes one bank pair apart (see the header)
-    bl.fits = bl.any && need <= kPitch && (unsigned)bl.ext[0] <= 4096u && (unsigned)bl.ext[1] <= 4096u &&
+    bl.pitch = (half && need <= 12) ? 12 : 16;
+    bl.ps = bl.ext[1] * bl.pitch + 2;         // planes one bank pair apart (see the header)
+    bl.fits = bl.any && need <= 16 && (unsigned)bl.ext[0] <= 4096u && (unsigned)bl.ext[1] <= 4096u &&
               bl.ext[0] * bl.ps <= box_cap;
 }
 
@@ -351,14 +359,16 @@ __device__ __forceinline__ void fwd_layout(const int (&lo)[3], const int (&hi)[3
 __device__ __forceinline__ void fwd_stage(const HotGeom& hg, const BoxLayout& bl, const float* __restrict__ src,
                                           float* box, int lane)
 {
-    const bool x_inside = bl.b0[2] >= 0 && bl.b0[2] + kPitch <= hg.in_len[2];
+    const bool x_inside = bl.b0[2] >= 0 && bl.b0[2] + bl.pitch <= hg.in_len[2];
     const bool zy_inside = bl.b0[0] >= 0 && bl.b0[0] + bl.ext[0] <= hg.in_len[0] && bl.b0[1] >= 0 &&
                            bl.b0[1] + bl.ext[1] <= hg.in_len[1];
     if (x_inside) {
-        const int nchunk = bl.ext[1] * 4;              // 16-byte chunks per plane
+        const int cpr = bl.pitch >> 2;                 // 16-byte chunks per row: 4 or 3
+        const int nchunk = bl.ext[1] * cpr;            // per plane
         for (int c0 = 0; c0 < nchunk; c0 += 64) {
             const int c = c0 + lane;
-            const int row = c >> 2, ch = c & 3;
+            const int row = cpr == 4 ? c >> 2 : (c * 21846) >> 16;      // c / 3 for c < 2^15
+            const int ch = c - row * cpr;
             const bool live = c < nchunk;
             const int ys = zy_inside ? bl.b0[1] + row : mirror_i32(bl.b0[1] + min(row, bl.ext[1] - 1), hg.in_len[1]);
             const int rowoff = ys * hg.vol_sy + bl.b0[2] + 4 * ch;
@@ -379,28 +389,34 @@ __device__ __forceinline__ void fwd_stage(const HotGeom& hg, const BoxLayout& bl
             const int zs = mirror_i32(bl.b0[0] + zr, hg.in_len[0]);
             const int ys = mirror_i32(bl.b0[1] + yr, hg.in_len[1]);
             if (sub < bl.ext[2])
-                box[zr * bl.ps + yr * kPitch + sub] = src[zs * hg.vol_sz + ys * hg.vol_sy + xs];
+                box[zr * bl.ps + yr * bl.pitch + sub] = src[zs * hg.vol_sz + ys * hg.vol_sy + xs];
         }
     }
 }
 
 // (ORDER + 1)^3 taps of one voxel from the staged box.  `bp` points at the aligned pair that holds
-// tap (0, 0, 0), `par` is the parity of the window's x start.  The work is cut into z-planes (NT rows
-// of 2 NP floats); the reads of the next NBUF - 1 planes are in flight while a plane is accumulated --
-// with one plane at a time the wave sat out the LDS latency once per plane, and 12 waves per CU do
-// not cover that.  The order is pinned by hand (empty asm statements): left alone, the compiler sinks
-// every FMA below the last read of the voxel and spills.
-template <int ORDER, int NBUF>
+// tap (0, 0, 0), `par` is the parity of the window's x start.  A window of NT taps at either parity
+// lies in NP aligned pairs; `wx` is the x weight vector shifted to the window's parity (zero outside)
+// and the value outside the window is replaced by zero as well (an Inf / NaN next to the window must
+// not leak in through 0 * Inf).  Accumulation order: x, then y, then z, each from zero -- the same
+// sums, bit for bit, as the 4-wave kernels (hot_gather, deform_hot.hip), so a voxel gets the same value
+// whichever level serves its tile (the crop identity full[crop] == cropped holds bit for bit).
+// The reads of the next NBUF - 1 z-planes are in flight while a plane is accumulated; the order is
+// pinned by hand (empty asm statements): left alone, the compiler sinks every FMA below the last read
+// of the voxel and spills.
+template <int ORDER, int NBUF, int PITCH>
 __device__ __forceinline__ float wave_gather(const float* bp, int ps, bool par, const float (&w0)[ORDER + 1],
                                              const float (&w1)[ORDER + 1], const float (&w2)[ORDER + 1])
 {
     constexpr int NT = ORDER + 1;
     constexpr int NP = (NT + 2) / 2;
     constexpr int NC = NT + 1;                 // box columns a window can touch (either parity)
-    float S[NC];
+    float wx[NC];
 #pragma unroll
-    for (int j = 0; j < NC; ++j)
-        S[j] = 0.f;
+    for (int j = 0; j < NC; ++j) {
+        const float wl = j > 0 ? w2[j - 1] : 0.f, wr = j < NT ? w2[j] : 0.f;
+        wx[j] = par ? wl : wr;
+    }
     float v[NBUF][NT][2 * NP];
     auto rd = [&](int l0) {
         const float* pp = bp + l0 * ps;
@@ -408,7 +424,7 @@ __device__ __forceinline__ float wave_gather(const float* bp, int ps, bool par, 
         for (int l1 = 0; l1 < NT; ++l1) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const float2 pr = *reinterpret_cast<const float2*>(pp + l1 * kPitch + 2 * p);
+                const float2 pr = *reinterpret_cast<const float2*>(pp + l1 * PITCH + 2 * p);
                 ED_NO_DS_MERGE();              // (ds_read2_b64 runs at half the rate of two ds_read_b64)
                 v[l0 % NBUF][l1][2 * p] = pr.x;
                 v[l0 % NBUF][l1][2 * p + 1] = pr.y;
@@ -417,21 +433,21 @@ __device__ __forceinline__ float wave_gather(const float* bp, int ps, bool par, 
                 asm volatile("" ::"v"(v[l0 % NBUF][l1][2 * NP - 1]));
         }
     };
+    float a0 = 0.f;
     auto acc = [&](int l0) {
-        float c[NC];
+        float a1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NC; ++j)
-            c[j] = 0.f;
-#pragma unroll
-        for (int l1 = 0; l1 < NT; ++l1)
+        for (int l1 = 0; l1 < NT; ++l1) {
+            const float first = par ? 0.f : v[l0 % NBUF][l1][0];
+            const float lastv = par ? v[l0 % NBUF][l1][NT] : 0.f;
+            float a2 = 0.f;
 #pragma unroll
             for (int j = 0; j < NC; ++j)
-                c[j] = fmaf(w1[l1], v[l0 % NBUF][l1][j], c[j]);
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            S[j] = fmaf(w0[l0], c[j], S[j]);
-            asm volatile("" : "+v"(S[j]));
+                a2 = fmaf(wx[j], j == 0 ? first : (j == NT ? lastv : v[l0 % NBUF][l1][j]), a2);
+            a1 = fmaf(w1[l1], a2, a1);
         }
+        a0 = fmaf(w0[l0], a1, a0);
+        asm volatile("" : "+v"(a0));
     };
 #pragma unroll
     for (int l0 = 0; l0 < NBUF - 1 && l0 < NT; ++l0)
@@ -442,21 +458,13 @@ __device__ __forceinline__ float wave_gather(const float* bp, int ps, bool par, 
             rd(l0 + NBUF - 1);
         acc(l0);
     }
-    // x contraction: even start -> columns 0 .. NT-1, odd start -> 1 .. NT; the column outside the
-    // window is dropped as a value (not only through a zero weight): an Inf / NaN there must not leak
-    S[0] = par ? 0.f : S[0];
-    S[NT] = par ? S[NT] : 0.f;
-    float a = 0.f;
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        const float wl = j > 0 ? w2[j - 1] : 0.f, wr = j < NT ? w2[j] : 0.f;
-        a = fmaf(par ? wl : wr, S[j], a);
-    }
-    return a;
+    return a0;
 }
 
-template <int ORDER, bool AFFINE>
-__global__ __launch_bounds__(64, 3) void wave_fwd_kernel(const HotGeom hg, const AxTab* __restrict__ xt,
+// OCC: waves per SIMD the kernel is compiled for (3: 168 VGPRs, 12.5 KiB of LDS per wave; 4: 128 VGPRs,
+// 10 KiB)
+template <int ORDER, bool AFFINE, int OCC>
+__global__ __launch_bounds__(64, OCC) void wave_fwd_kernel(const HotGeom hg, const AxTab* __restrict__ xt,
                                                          const double* __restrict__ qtab,
                                                          const float* __restrict__ vol0, float* __restrict__ img0)
 {
@@ -464,12 +472,16 @@ __global__ __launch_bounds__(64, 3) void wave_fwd_kernel(const HotGeom hg, const
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HotParams* hp = reinterpret_cast<const HotParams*>(smem);
     float* box = reinterpret_cast<float*>(smem + kWaveHead);
+    const int lane = threadIdx.x;
     WaveStrip sp;
+#ifdef EDHIP_EXPERIMENTS
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
     if (!wave_strip(hg, sp, blockIdx.x))
         return;
-    const int lane = threadIdx.x;
     wave_prologue(hg, smem, lane);
     const int yy = lane >> 3, zz = lane & 7;
+    {
     const float* __restrict__ vol = vol0 + sp.sample * hg.vol_bstride;
     float* __restrict__ img = img0 + sp.sample * hg.img_bstride;
 
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(64, 3) void wave_fwd_kernel(const HotGeom hg, const
             int lo[3], hi[3];
             row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox0, nx, lo, hi);
             BoxLayout bl;
-            fwd_layout<ORDER>(lo, hi, hg.box_cap, bl);
+            fwd_layout<ORDER>(lo, hi, hg.box_cap, nsub == 2, bl);
             if (nsub == 1 && hg.boxes && lane < 6) {      // EDHIP_FLAG_KEEP_BOXES: the box goes to the gradient call too
                 const int v = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2] : lane == 3 ? hi[0]
                               : lane == 4 ? hi[1] : hi[2];
@@ -521,7 +533,7 @@ __global__ __launch_bounds__(64, 3) void wave_fwd_kernel(const HotGeom hg, const
                 }
                 break;
             }
-            const int ps = bl.ps;
+            const int ps = bl.ps, pitch = bl.pitch;
             for (long long ss = 0; ss < hg.nsteps; ++ss) {
                 long long vol_off = 0, img_off = 0;
                 if (hg.nstep)
@@ -535,77 +547,88 @@ __global__ __launch_bounds__(64, 3) void wave_fwd_kernel(const HotGeom hg, const
                     __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0) lgkmcnt(0): this wave's copies have landed
                     asm volatile("" ::: "memory");
                 }
-                // ---- pass 2: coordinates again, weights, gather; two voxels at a time, one 16-byte
-                //      store per four ------------------------------------------------------------------
-                float o0 = 0.f, o1 = 0.f;
+                // ---- pass 2: coordinates again, weights, gather; one 16-byte store per four voxels ---
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f;
                 float* op = img + (img_off + obase + ox0);
                 const int last = hg.out_len[2] - 1;
-                XEntry ea, eb;
-                xentry_load(xt, min(ox0, last), ea);
-                xentry_load(xt, min(ox0 + 1, last), eb);
+                XEntry xe;
+                xentry_load(xt, min(ox0, last), xe);
 #pragma unroll 1
-                for (int k = 0; k < nx; k += 2) {
+                for (int k = 0; k < nx; ++k) {
                     const int ox = ox0 + k;
-                    int st[2][3];
-                    float fr[2][3];
-                    bool live[2];
-                    live[0] = !entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, ea, ox, st[0], fr[0]) && rw.vzy && ox <= last;
-                    live[1] = !entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, eb, ox + 1, st[1], fr[1]) && rw.vzy && ox + 1 <= last;
-                    xentry_load(xt, min(ox + 2, last), ea);       // (arrive during the gather)
-                    xentry_load(xt, min(ox + 3, last), eb);
-                    float val[2] = {0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        float w0[NT], w1[NT], w2[NT];
-                        weights_from_frac<float, ORDER>(fr[i][0], w0);
-                        weights_from_frac<float, ORDER>(fr[i][1], w1);
-                        weights_from_frac<float, ORDER>(fr[i][2], w2);
-                        // (a voxel that is not gathered reads the head of the box: no divergence)
-                        const int rz = live[i] ? st[i][0] - bl.b0[0] : 0, ry = live[i] ? st[i][1] - bl.b0[1] : 0,
-                                  rx = live[i] ? st[i][2] - bl.b0[2] : 0;
-                        const float* bp = box + (rz * ps + ry * kPitch + (rx & ~1));
+                    int st[3];
+                    float fr[3];
+                    XEntry xn;
+                    xentry_load(xt, min(ox + 1, last), xn);       // (requested a whole voxel ahead)
+                    const bool live = !entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, xe, ox, st, fr) && rw.vzy && ox <= last;
+                    float w0[NT], w1[NT], w2[NT];
+                    weights_from_frac<float, ORDER>(fr[0], w0);
+                    weights_from_frac<float, ORDER>(fr[1], w1);
+                    weights_from_frac<float, ORDER>(fr[2], w2);
+                    // (a voxel that is not gathered reads the head of the box: no divergence)
+                    const int rz = live ? st[0] - bl.b0[0] : 0, ry = live ? st[1] - bl.b0[1] : 0,
+                              rx = live ? st[2] - bl.b0[2] : 0;
+                    const float* bp = box + (rz * ps + ry * pitch + (rx & ~1));
+                    float val = 0.f;
 #ifdef EDHIP_EXPERIMENTS
-                        if (hg.dbg & 1)            // ablation: no gather
-                            val[i] = fr[i][0] + fr[i][1] + fr[i][2] + w0[1];
-                        else
+                    if (hg.dbg & 1)            // ablation: no gather
+                        val = fr[0] + fr[1] + fr[2] + w0[1];
+                    else
 #endif
-                        if (bl.any)
-                            val[i] = wave_gather<ORDER, gather_bufs<ORDER>()>(bp, ps, rx & 1, w0, w1, w2);
-                    }
-                    val[0] = live[0] ? val[0] : hg.cval;
-                    val[1] = live[1] ? val[1] : hg.cval;
-                    if (!(k & 2)) {            // (k is wave-uniform)
-                        o0 = val[0];
-                        o1 = val[1];
-                    } else if (rw.vzy) {
+                    if (bl.any)
+                        val = pitch == 16 ? wave_gather<ORDER, gather_bufs<ORDER, OCC>(), 16>(bp, ps, rx & 1, w0, w1, w2)
+                                          : wave_gather<ORDER, gather_bufs<ORDER, OCC>(), 12>(bp, ps, rx & 1, w0, w1, w2);
+                    val = live ? val : hg.cval;
+                    xe = xn;
+                    const int j = k & 3;       // (k is wave-uniform)
+                    if (j == 0)
+                        o0 = val;
+                    else if (j == 1)
+                        o1 = val;
+                    else if (j == 2)
+                        o2 = val;
+                    else if (rw.vzy) {
                         // streaming stores: the wave fills 16-byte pieces of 64 rows; the rest of each
                         // 128-byte line follows from this same wave within the strip
-                        float* o = op + (k - 2);
+                        float* o = op + (k - 3);
 #ifdef EDHIP_EXPERIMENTS
-                        if ((hg.dbg & 8) && val[0] != -12345.678f)         // ablation: no stores
+                        if ((hg.dbg & 8) && val != -12345.678f)         // ablation: no stores
                             continue;
 #endif
-                        if (ox + 1 <= last) {
+                        if (ox <= last) {
                             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
                             f4u v4;
                             v4.x = o0;
                             v4.y = o1;
-                            v4.z = val[0];
-                            v4.w = val[1];
+                            v4.z = o2;
+                            v4.w = val;
                             __builtin_nontemporal_store(v4, reinterpret_cast<f4u*>(o));
                         } else {
-                            if (ox - 2 <= last)
+                            if (ox - 3 <= last)
                                 __builtin_nontemporal_store(o0, &o[0]);
-                            if (ox - 1 <= last)
+                            if (ox - 2 <= last)
                                 __builtin_nontemporal_store(o1, &o[1]);
-                            if (ox <= last)
-                                __builtin_nontemporal_store(val[0], &o[2]);
+                            if (ox - 1 <= last)
+                                __builtin_nontemporal_store(o2, &o[2]);
                         }
                     }
                 }
             }
         }
     }
+    }
+#ifdef EDHIP_EXPERIMENTS
+    if (hg.dbgbuf && lane == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* d = hg.dbgbuf + (size_t)blockIdx.x * 4;
+        d[0] = t_begin;
+        d[1] = __builtin_readcyclecounter();
+        d[2] = hwid;
+        d[3] = xcc;
+    }
+#endif
 }
 
 // ================================================================================================
@@ -623,7 +646,7 @@ __device__ __forceinline__ int round_half_up_i32(float x)
 
 struct CellLayout {
     int b0[3], ext[3];
-    int ps;               // cells per plane (rows are ext[2] cells: tight)
+    int px, ps;           // cells per row / per plane
     bool any, fits;
 };
 __device__ __forceinline__ void grad_layout(const int (&lo)[3], const int (&hi)[3], int box_cap, CellLayout& cl)
@@ -634,13 +657,16 @@ __device__ __forceinline__ void grad_layout(const int (&lo)[3], const int (&hi)[
         cl.b0[h] = lo[h];
         cl.ext[h] = cl.any ? hi[h] - lo[h] + 1 : 0;
     }
-    cl.ps = cl.ext[1] * cl.ext[2];
+    // odd row pitch: the lanes of a wave sit on different (z, y) rows of the box at about the same x, and
+    // an even pitch folds them onto few banks (tools/sim/conflicts_k2.py: 2.7 -> 1.9 passes per 16 lanes)
+    cl.px = cl.ext[2] | 1;
+    cl.ps = cl.ext[1] * cl.px;
     cl.fits = (unsigned)cl.ext[0] <= 1024u && (unsigned)cl.ext[1] <= 1024u && (unsigned)cl.ext[2] <= 1024u &&
               cl.ext[0] * cl.ps <= box_cap;
 }
 
-template <int ORDER, bool AFFINE>
-__global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, const AxTab* __restrict__ xt,
+template <int ORDER, bool AFFINE, int OCC>
+__global__ __launch_bounds__(64, OCC) void wave_grad_kernel(const HotGeom hg, const AxTab* __restrict__ xt,
                                                           const double* __restrict__ qtab,
                                                           const float* __restrict__ dy0, float* __restrict__ dx0)
 {
@@ -648,10 +674,10 @@ __global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, cons
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HotParams* hp = reinterpret_cast<const HotParams*>(smem);
     int* cells = reinterpret_cast<int*>(smem + kWaveHead);
+    const int lane = threadIdx.x;
     WaveStrip sp;
     if (!wave_strip(hg, sp, blockIdx.x))
         return;
-    const int lane = threadIdx.x;
     // the accumulator cells start at zero and every flush leaves the cells it read at zero again
     for (int e = lane * 4; e < hg.box_cap; e += 256)
         *reinterpret_cast<int4*>(cells + e) = make_int4(0, 0, 0, 0);
@@ -659,8 +685,15 @@ __global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, cons
     // lane -> (z, y): the 16 lanes that go through the LDS atomic unit together hold rows two apart
     // along z and y.  Neighbouring voxels share a window start wherever the deformation compresses,
     // and two lanes adding into one cell serialise the atomic (4.2 -> 6.0 cycles).
-    const int zz = 2 * (lane & 3) + ((lane >> 4) & 1);
-    const int yy = 2 * ((lane >> 2) & 3) + ((lane >> 5) & 1);
+    int zz = 2 * (lane & 3) + ((lane >> 4) & 1);
+    int yy = 2 * ((lane >> 2) & 3) + ((lane >> 5) & 1);
+#ifdef EDHIP_EXPERIMENTS
+    if (hg.dbg & 16) {          // experiment: lane = 8 z + y
+        zz = lane >> 3;
+        yy = lane & 7;
+    }
+#endif
+    {
     const float* __restrict__ dy = dy0 + sp.sample * hg.img_bstride;
     float* __restrict__ dx = dx0 + sp.sample * hg.vol_bstride;
 
@@ -732,7 +765,7 @@ __global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, cons
             if (!cl.any && !given)
                 continue;          // nothing to scatter (uniform): every voxel maps to the constant
             const int ox0 = ox_tile + sub * nx;
-            const int px = cl.ext[2], ps = cl.ps;
+            const int px = cl.px, ps = cl.ps, ex = cl.ext[2];
             const bool interior = cl.b0[0] >= 0 && cl.b0[0] + cl.ext[0] <= hg.in_len[0] && cl.b0[1] >= 0 &&
                                   cl.b0[1] + cl.ext[1] <= hg.in_len[1] && cl.b0[2] >= 0 &&
                                   cl.b0[2] + cl.ext[2] <= hg.in_len[2];
@@ -758,6 +791,9 @@ __global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, cons
                     const float inv_scale = gm > 0.f ? __frcp_rn(scale) : 0.f;
 
                     // ---- pass 2: coordinates again, weights, scatter into the cells -------------------
+                    const int last = hg.out_len[2] - 1;
+                    XEntry xe;
+                    xentry_load(xt, min(ox0, last), xe);
 #pragma unroll 1
                     for (int k = 0; k < nx; ++k) {
                         float gv = g[0];
@@ -767,7 +803,10 @@ __global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, cons
                         const int ox = ox0 + k;
                         int st[3];
                         float fr[3];
-                        const bool cst = row_voxel<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox, st, fr);
+                        XEntry xn;
+                        xentry_load(xt, min(ox + 1, last), xn);       // (requested a whole voxel ahead)
+                        const bool cst = entry_voxel<ORDER, AFFINE>(hg, hp, rw, qc, xe, ox, st, fr);
+                        xe = xn;
                         if (gv == 0.f || cst)
                             continue;      // constant voxels contribute nothing (deform.c:928)
                         float w0[NT], w1[NT], w2[NT];
@@ -823,12 +862,12 @@ __global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, cons
                         const int nrows = cl.ext[0] * cl.ext[1];
                         const float inv_by = 1.f / (float)cl.ext[1];
                         // 16 lanes per box row (4 rows per instruction) while the rows are that short
-                        const int fl = px <= 16 ? 16 : 64, fr_ = 64 / fl;
-                        const int subl = lane & (fl - 1), rslot = px <= 16 ? lane >> 4 : 0;
-                        for (int xo = 0; xo < px; xo += fl) {
+                        const int fl = ex <= 16 ? 16 : 64, fr_ = 64 / fl;
+                        const int subl = lane & (fl - 1), rslot = ex <= 16 ? lane >> 4 : 0;
+                        for (int xo = 0; xo < ex; xo += fl) {
                             const int xi = xo + subl;
-                            const bool xin = xi < px;
-                            const int xs = interior ? cl.b0[2] + xi : mirror_i32(cl.b0[2] + min(xi, px - 1), hg.in_len[2]);
+                            const bool xin = xi < ex;
+                            const int xs = interior ? cl.b0[2] + xi : mirror_i32(cl.b0[2] + min(xi, ex - 1), hg.in_len[2]);
                             for (int r0 = rslot; r0 < nrows; r0 += FU * fr_) {
                                 int acc[FU];
 #pragma unroll
@@ -861,51 +900,65 @@ __global__ __launch_bounds__(64, 3) void wave_grad_kernel(const HotGeom hg, cons
             }
         }
     }
+    }
 }
 
-// bytes of LDS per wave (one workgroup = one wave): 160 KiB / 12 in the hardware's allocation granule
-constexpr int kWaveLdsBytes = 12800;
+// bytes of LDS per wave (one workgroup = one wave): 160 KiB / 12 resp. / 16 in the hardware's
+// allocation granule
+constexpr int kWaveLdsBytes3 = 12800, kWaveLdsBytes4 = 10240;
 
-template <int ORDER>
-hipError_t launch_wave_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t lds, hipStream_t stream)
+template <int ORDER, int OCC>
+hipError_t launch_wave_occ(const HotGeom& hg, bool gradient, unsigned nblk, size_t lds, hipStream_t stream)
 {
     if (gradient) {
         if (hg.has_affine)
-            hipLaunchKernelGGL((wave_grad_kernel<ORDER, true>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+            hipLaunchKernelGGL((wave_grad_kernel<ORDER, true, OCC>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
                                hg.img_r, hg.vol_w);
         else
-            hipLaunchKernelGGL((wave_grad_kernel<ORDER, false>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+            hipLaunchKernelGGL((wave_grad_kernel<ORDER, false, OCC>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
                                hg.img_r, hg.vol_w);
         return hipGetLastError();
     }
     if (hg.has_affine)
-        hipLaunchKernelGGL((wave_fwd_kernel<ORDER, true>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+        hipLaunchKernelGGL((wave_fwd_kernel<ORDER, true, OCC>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
                            hg.vol_r, hg.img_w);
     else
-        hipLaunchKernelGGL((wave_fwd_kernel<ORDER, false>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+        hipLaunchKernelGGL((wave_fwd_kernel<ORDER, false, OCC>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
                            hg.vol_r, hg.img_w);
     return hipGetLastError();
+}
+
+template <int ORDER>
+hipError_t launch_wave_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t lds, int occ, hipStream_t stream)
+{
+#ifdef EDHIP_EXPERIMENTS
+    if (occ == 4)
+        return launch_wave_occ<ORDER, 4>(hg, gradient, nblk, lds, stream);
+#endif
+    (void)occ;
+    return launch_wave_occ<ORDER, 3>(hg, gradient, nblk, lds, stream);
 }
 
 }  // namespace
 
 // LDS per wave and the box capacity (floats / cells) that leaves
-size_t wave_lds_bytes(bool gradient, int* box_cap)
+size_t wave_lds_bytes(bool gradient, int occ, int* box_cap)
 {
     (void)gradient;
-    *box_cap = (kWaveLdsBytes - kWaveHead) / 4;
-    return kWaveLdsBytes;
+    const int bytes = occ == 4 ? kWaveLdsBytes4 : kWaveLdsBytes3;
+    *box_cap = (bytes - kWaveHead) / 4;
+    return bytes;
 }
 
-hipError_t launch_wave_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds,
+hipError_t launch_wave_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds, int occ,
                               hipStream_t stream)
 {
     switch (order) {
-    case 1: return launch_wave_order<1>(hg, gradient, nblk, lds, stream);
-    case 2: return launch_wave_order<2>(hg, gradient, nblk, lds, stream);
-    case 3: return launch_wave_order<3>(hg, gradient, nblk, lds, stream);
-    case 4: return launch_wave_order<4>(hg, gradient, nblk, lds, stream);
-    case 5: return launch_wave_order<5>(hg, gradient, nblk, lds, stream);
+    case 1: return launch_wave_order<1>(hg, gradient, nblk, lds, occ, stream);
+    case 2: return launch_wave_order<2>(hg, gradient, nblk, lds, occ, stream);
+    case 3: return launch_wave_order<3>(hg, gradient, nblk, lds, occ, stream);
+    case 4: return launch_wave_order<4>(hg, gradient, nblk, lds, occ, stream);
+    case 5: return launch_wave_order<5>(hg, gradient, nblk, lds, occ, stream);
     default: return hipErrorNotSupported;
     }
 }

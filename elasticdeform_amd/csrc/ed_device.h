@@ -14,6 +14,16 @@
 
 #include "edhip.h"
 
+// Environment switches (kernel selection, ablations, debugging aids) exist only in EDHIP_EXPERIMENTS
+// builds (`make EXPERIMENTS=1`, used by tools/ on the GPU box).  The shipped library never calls
+// getenv: no environment variable can change what it launches or returns.
+#ifdef EDHIP_EXPERIMENTS
+#include <cstdlib>
+inline const char* ed_env(const char* name) { return getenv(name); }
+#else
+inline const char* ed_env(const char*) { return nullptr; }
+#endif
+
 namespace ed {
 
 // ---------------------------------------------------------------------------------------------

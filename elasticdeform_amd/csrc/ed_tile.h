@@ -368,6 +368,7 @@ struct HotGeom {
     // the pointer is set; K2 reads them when `use_boxes` is set (see EDHIP_FLAG_USE_BOXES).
     int* boxes;
     int use_boxes;
+    unsigned long long* dbgbuf;   // EDHIP_EXPERIMENTS builds: per-workgroup timestamps (else unused)
     int dbg;                  // experiment switches (EDHIP_TILE_DBG), 0 in production
     float cval;
     int nstep;
@@ -384,9 +385,9 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box);
 // one-wavefront-per-tile kernels (deform_wave.hip): same argument block; `strip_tiles`, `strips_x`,
 // `nstrips`, `total_strips` describe the strips of the 64-thread workgroups, `box_cap` the floats /
 // cells of LDS one wave owns
-hipError_t launch_wave_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds,
+hipError_t launch_wave_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds, int occ,
                               hipStream_t stream);
-size_t wave_lds_bytes(bool gradient, int* box_cap);
+size_t wave_lds_bytes(bool gradient, int occ, int* box_cap);
 
 }  // namespace tile
 }  // namespace ed

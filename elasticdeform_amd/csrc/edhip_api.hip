@@ -173,12 +173,22 @@ bool uniform_batch(const edhip_array* a, int n, int64_t* stride)
         if ((const char*)a[b].data != (const char*)a[0].data + (int64_t)b * *stride)
             return false;
     }
+    // the single-launch kernels address samples in elements: the distance must be a whole number of them
+    const int64_t es = (a[0].dtype == EDHIP_F64 || a[0].dtype == EDHIP_I64 || a[0].dtype == EDHIP_U64) ? 8
+                       : (a[0].dtype == EDHIP_F32 || a[0].dtype == EDHIP_I32 || a[0].dtype == EDHIP_U32) ? 4 : 1;
+    if (*stride % es != 0)
+        return false;
     return true;
 }
 
 }  // namespace
 
 extern "C" {
+
+#ifdef EDHIP_EXPERIMENTS
+// marks a profiling build (make EXPERIMENTS=1): environment switches are live in it
+const int edhip_experiments_build = 1;
+#endif
 
 int edhip_version(void) { return EDHIP_VERSION; }
 
@@ -331,6 +341,8 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
         err[0] = 0;
     if (nbatch < 0 || (nbatch > 0 && (!inputs || !displacements || !outputs)))
         return fail(err, errlen, EDHIP_ERR_INVALID, "invalid batch");
+    if (nbatch == 0)
+        return EDHIP_OK;          // nothing to do (and no descriptor to read)
     ed::StreamGuard guard((hipStream_t)hip_stream);
     // ---- one set of launches for the whole batch (the strip index of the tile kernels carries the
     //      sample): same-shaped float volumes at a constant distance, one prefiltered grid each ------
@@ -342,7 +354,6 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
                       : ((gradient && (flags & EDHIP_FLAG_USE_BOXES)) ? 2 : 0);
         db.disp_id = displacements[0].data;
         const bool candidate = nbatch >= 2 && naxis == 3 && axis && !(flags & (EDHIP_FLAG_EXACT | EDHIP_FLAG_RAW_DISPLACEMENT)) &&
-                               !getenv("EDHIP_BATCH_LOOP") &&
                                (inputs[0].dtype == EDHIP_F32 || inputs[0].dtype == EDHIP_F64) &&
                                outputs[0].dtype == inputs[0].dtype && inputs[0].ndim == outputs[0].ndim &&
                                inputs[0].ndim >= 3 && inputs[0].ndim <= EDHIP_MAX_DIMS &&

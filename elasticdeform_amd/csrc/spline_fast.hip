@@ -812,7 +812,7 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
         ncu = 256;
     int wgs_per_cu = sizeof(T) == 8 ? 1 : 2;
-    if (const char* w = getenv("EDHIP_TILE_WGS"))
+    if (const char* w = ed_env("EDHIP_TILE_WGS"))
         wgs_per_cu = atoi(w) > 0 ? atoi(w) : wgs_per_cu;
     const int64_t resident = (int64_t)ncu * wgs_per_cu;
     const bool aligned16 = ((uintptr_t)f.in % 16 == 0) && ((uintptr_t)f.out % 16 == 0);
@@ -848,7 +848,7 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
             const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, true>, kTileLdsBudget);
             if (attr != hipSuccess)
                 return hipErrorNotSupported;
-            if (getenv("EDHIP_FILTER_TRACE")) {
+            if (ed_env("EDHIP_FILTER_TRACE")) {
                 static unsigned long long* buf = nullptr;
                 if (!buf)
                     (void)hipMalloc((void**)&buf, 64 * 8);
@@ -1040,7 +1040,7 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
     p.seg_len = seg_blocks * kB;
     p.nseg = (int)((nblocks_line + seg_blocks - 1) / seg_blocks);
 
-    if (!getenv("EDHIP_NO_LINE_TILES")) {
+    if (!ed_env("EDHIP_NO_LINE_TILES")) {
         const hipError_t e = fp.in_dtype == EDHIP_F32 ? launch_line_tiles<float>(p, stream)
                                                       : launch_line_tiles<double>(p, stream);
         if (e != hipErrorNotSupported)

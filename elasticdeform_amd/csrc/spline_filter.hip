@@ -272,7 +272,7 @@ hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
         return hipSuccess;
     // lines of up to 128 samples: working copy in LDS (64 KiB: 256 threads x 32 samples ... 64 x 128),
     // all lines in one launch, the global scratch buffer is not touched
-    static const bool no_ldsws = getenv("EDHIP_FILTER_NO_LDSWS") != nullptr;      // A/B switch
+    static const bool no_ldsws = ed_env("EDHIP_FILTER_NO_LDSWS") != nullptr;      // A/B switch
     if (p.len <= 128 && !no_ldsws) {
         const int blk = p.len <= 32 ? 256 : (p.len <= 64 ? 128 : 64);
         const size_t lds = (size_t)p.len * blk * sizeof(double);

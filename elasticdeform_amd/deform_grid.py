@@ -153,11 +153,17 @@ def _narrow(t32, like):
     if name in _lib.REDUCED_DTYPES:
         return t32.to(like.dtype)
     lo, hi = _INT_RANGE[name]
-    r = torch.where(t32 > 0, t32 + 0.5, t32 - 0.5) if lo < 0 else torch.where(t32 > 0, t32 + 0.5, torch.zeros_like(t32))
-    # float32 cannot hold 2^31 - 1 / 2^32 - 1: clamp in float64 for the 32-bit types
-    if hi > 1e9:
-        r = r.double()
-    return r.clamp_(lo, hi).trunc_().to(like.dtype)
+    # in float64 like the reference (`t` is a double there): 0.49999997f + 0.5f rounds up to 1.0f in
+    # float32 and would store 1 where the double rule stores 0
+    t = t32.double()
+    nan = torch.isnan(t)
+    r = torch.where(t > 0, t + 0.5, t - 0.5) if lo < 0 else torch.where(t > 0, t + 0.5, torch.zeros_like(t))
+    r = r.clamp_(lo, hi).trunc_()
+    # NaN passes every comparison of the store rule and reaches the cast: x86-64's cvttsd2si gives the
+    # "integer indefinite" 0x80...0, of which the narrow and the unsigned types keep the low bits (0)
+    # -- what the exact kernels' store_forward produces
+    r = torch.where(nan, torch.full_like(r, float(lo) if name in ('int32', 'int64') else 0.0), r)
+    return r.to(like.dtype)
 
 
 def _desc(t):
@@ -520,8 +526,8 @@ def deform_grid_batch(X, displacements, order=3, mode='constant', cval=0.0, crop
         df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
         out = torch.empty((B,) + tuple(int(v) for v in plan.output_shapes[0]), dtype=Xd.dtype, device=device)
         (xd, xs), (dd0, ds), (od, os_) = _desc_sample0(Xf), _desc_sample0(df), _desc_sample0(out)
-        # the filtered grids are kept for the gradient call of the same (unmodified) displacement
-        # tensor: it skips their prefilter and takes this call's tile boxes (see _box_owner)
+        # the buffer of the filtered grids is kept for the gradient call of the same displacement
+        # tensor: it takes this call's tile boxes (see _box_owner and deform_grid_gradient_batch)
         stream = _stream(device)
         ident = _box_id(displacements, dd)
         _batch_grids[(device.index, stream)] = (ident, df) if ident is not None else None
@@ -567,11 +573,17 @@ def deform_grid_gradient_batch(dY, displacements, order=3, mode='constant', cval
         kept = _batch_grids.get((device.index, stream))
         ident = _box_id(displacements, dd)
         bflag = 0
-        if kept is not None and ident is not None and kept[0] == ident:
-            df = kept[1]                      # the forward call's filtered grids (and its tile boxes)
+        # The control grids are ALWAYS prefiltered again (three small launches): storage address +
+        # version counter say nothing certain about contents (a new tensor on a freed one's address, a
+        # `.data` write).  Only the forward call's tile boxes are handed over -- the kernel treats
+        # them as a hint it verifies per voxel -- and for that the fresh grids are written into the
+        # forward call's buffer, whose address is the library's key for the boxes.
+        df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
+        if kept is not None and ident is not None and kept[0] == ident and kept[1].shape == df.shape \
+                and kept[1].dtype == df.dtype:
+            kept[1].copy_(df)
+            df = kept[1]
             bflag = _lib.FLAG_USE_BOXES
-        else:
-            df = _filter_axes(dd, range(2, dd.ndim), 3, False, device)
         (xd, xs), (dd0, ds), (yd, ys) = _desc_sample0(dX), _desc_sample0(df), _desc_sample0(dYd)
         _lib.deform_batch_strided(True, B, xd, xs, dd0, ds, plan.output_offset, yd, ys, ax, o,
                                   int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine, _flags | bflag,

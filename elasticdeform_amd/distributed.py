@@ -67,23 +67,33 @@ def _host_staged(group):
     return _dist().get_backend(group) == 'gloo'
 
 
-def _p2p_exchange(sends, recvs, group):
+def _p2p_exchange(sends, recvs, group, device=None):
     """One ``batch_isend_irecv`` group: ``sends`` = [(tensor, peer)], ``recvs`` = [(tensor, peer)]
-    (group ranks).  All transfers of the group are in flight together."""
+    (group ranks).  All transfers of the group are in flight together.  Under RCCL ("nccl") every
+    tensor handed to the backend must live on the GPU: a host-resident source (the root's batch as it
+    came from a data loader) is moved to ``device`` slice by slice, a host-resident destination is
+    filled through a device buffer.  gloo (the CPU tests) goes the other way: through the host."""
     import torch
     dist = _dist()
     if not sends and not recvs:
         return
     staged = _host_staged(group)
+    if device is None and not staged:
+        device = torch.device('cuda', torch.cuda.current_device())
     ops, back = [], []
     for t, peer in sends:
         w = t.contiguous()
         if staged and w.is_cuda:
             w = w.cpu()
+        elif not staged and w.device.type != device.type:
+            w = w.to(device, non_blocking=True)
         ops.append(dist.P2POp(dist.isend, w, _global_rank(peer, group), group))
     for t, peer in recvs:
         if staged and t.is_cuda:
             w = torch.empty(t.shape, dtype=t.dtype)
+            back.append((t, w))
+        elif not staged and t.device.type != device.type:
+            w = torch.empty(t.shape, dtype=t.dtype, device=device)
             back.append((t, w))
         else:
             w = t
@@ -111,11 +121,11 @@ def scatter_batch(full, src, device, rank=None, world_size=None, group=None):
             plo, phi = shard_bounds(shape[0], peer, world)
             if peer != src and phi > plo:
                 sends.append((full[plo:phi], peer))
-        _p2p_exchange(sends, [], group)
+        _p2p_exchange(sends, [], group, device)
         return full[lo:hi].to(device)
     mine = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
     if hi > lo:
-        _p2p_exchange([], [(mine, src)], group)
+        _p2p_exchange([], [(mine, src)], group, device)
     return mine
 
 
@@ -124,9 +134,10 @@ def gather_batch(mine, n_items, dst, rank=None, world_size=None, group=None):
     ``dst`` (returned there; ``None`` elsewhere)."""
     import torch
     rank, world = _rank_world(rank, world_size, group)
+    dev = mine.device if mine.device.type != 'cpu' else None
     if rank != dst:
         if mine.shape[0] > 0:
-            _p2p_exchange([(mine, dst)], [], group)
+            _p2p_exchange([(mine, dst)], [], group, dev)
         return None
     full = torch.empty((n_items,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
     recvs = []
@@ -136,7 +147,7 @@ def gather_batch(mine, n_items, dst, rank=None, world_size=None, group=None):
             full[plo:phi].copy_(mine)
         elif phi > plo:
             recvs.append((full[plo:phi], peer))
-    _p2p_exchange([], recvs, group)
+    _p2p_exchange([], recvs, group, dev)
     return full
 
 
@@ -201,10 +212,13 @@ def deform_batch_sharded(X, displacements, gradient=False, scatter_from=None, ga
         if [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0]
                 for r in range(world)] != counts:
             raise ValueError('gather_to needs the contiguous balanced sharding of shard_bounds()')
-    if out.shape[0] == 0 and rank != gather_to:
-        return None
-    if rank == gather_to and out.shape[0] == 0:
+    # decided from values every rank holds, BEFORE any rank enters a send / recv: an exception on
+    # one rank only would leave the others waiting in the exchange
+    glo, ghi = shard_bounds(n_items, gather_to, world)
+    if ghi <= glo:
         raise ValueError('the gathering rank must own at least one volume')
+    if out.shape[0] == 0:
+        return None
     return gather_batch(out, n_items, gather_to, rank, world, group)
 
 
@@ -239,7 +253,7 @@ def deform_batch(volumes, displacements, rank=None, world_size=None, gather_to=N
     dist.all_gather_object(sigs, sig, group=group)
     flat = [s for part in sigs for s in part]
     if flat and all(s == flat[0] for s in flat):
-        if rank == gather_to and not outs:
+        if not sigs[gather_to]:      # (known to every rank: all of them raise, none enters the exchange)
             raise ValueError('the gathering rank must own at least one volume')
         as_numpy = bool(outs) and isinstance(outs[0], numpy.ndarray)
         if outs:

@@ -366,13 +366,8 @@ def test_fast_prefilter_kernels():
     shapes = ((64,), (70, 3, 97), (129, 200), (5, 64, 7), (3, 100, 65), (300, 70),
               # 16-byte-aligned extents (vector tiles), half-width tiles, lines too long for a tile
               (128, 64, 96), (96, 8, 256), (500, 4, 64), (2000, 8), (8, 2000), (40, 1100))
-    for shape, tiles in [(s, t) for s in shapes for t in (True, False)]:
-        # EDHIP_NO_LINE_TILES: the block-recompute kernels that serve lines too long for an LDS tile
-        os.environ.pop("EDHIP_NO_LINE_TILES", None)
-        if not tiles:
-            if len(shape) == 3 and shape[0] > 100:
-                continue
-            os.environ["EDHIP_NO_LINE_TILES"] = "1"
+    # (the last three shapes have lines too long for an LDS tile: they run on the block-recompute kernels)
+    for shape in shapes:
         for order in (2, 3, 4, 5):
             for dtype, flag, tol in ((np.float32, _lib.FLAG_AUTO, 2e-6 if order < 4 else 4e-6),
                                      (np.float64, _lib.FLAG_AUTO, 1e-13)):
@@ -404,7 +399,6 @@ def test_fast_prefilter_kernels():
                     want = scipy.ndimage.spline_filter1d(x.T.astype(np.float64), order=order, axis=1)
                     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0,
                                                atol=tol * np.abs(want).max())
-    os.environ.pop("EDHIP_NO_LINE_TILES", None)
 
 
 def test_raw_displacement_flag_equals_explicit_prefilter():
@@ -748,7 +742,7 @@ def test_label_values_beyond_2_53_round_trip_like_the_reference():
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_single_launch_batch_equals_item_by_item(dtype):
     """edhip_deform_batch_strided: the whole batch as ONE set of launches (strip index carries the
-    sample) against the item-by-item path of the same entry point (EDHIP_BATCH_LOOP), bit for bit in
+    sample) against one `deform_grid` call per sample, bit for bit in
     the forward direction -- strong deformation (tiles overflow into the spill levels across
     samples), a crop, a channel axis, an affine map, orders 1-5 -- and within the float rounding of
     the atomics for the gradient."""
@@ -771,11 +765,7 @@ def test_single_launch_batch_equals_item_by_item(dtype):
         D = torch.from_numpy(rng.standard_normal((B, 3) + c["pts"]) * c["sigma"]).to(dev)
         kw = c["kw"]
         one = ed.deform_grid_batch(X, D, **kw)
-        os.environ["EDHIP_BATCH_LOOP"] = "1"
-        try:
-            loop = ed.deform_grid_batch(X, D, **kw)
-        finally:
-            del os.environ["EDHIP_BATCH_LOOP"]
+        loop = torch.stack([ed.deform_grid(X[b], D[b], **kw) for b in range(B)])
         assert torch.equal(one, loop), (c["shape"], kw)
         # one sample against the oracle
         want = orc.deform_grid(X[B - 1].cpu().numpy(), D[B - 1].cpu().numpy(), **kw)
@@ -783,11 +773,7 @@ def test_single_launch_batch_equals_item_by_item(dtype):
         np.testing.assert_allclose(one[B - 1].cpu().numpy(), want, **tol)
         dY = torch.from_numpy(rng.random(tuple(one.shape)).astype(dtype)).to(dev)
         g1 = ed.deform_grid_gradient_batch(dY, D, X_shape=tuple(X.shape[1:]), **kw)
-        os.environ["EDHIP_BATCH_LOOP"] = "1"
-        try:
-            g2 = ed.deform_grid_gradient_batch(dY, D, X_shape=tuple(X.shape[1:]), **kw)
-        finally:
-            del os.environ["EDHIP_BATCH_LOOP"]
+        g2 = torch.stack([ed.deform_grid_gradient(dY[b], D[b], X_shape=tuple(X.shape[1:]), **kw) for b in range(B)])
         eps = 1e-5 if dtype == np.float32 else 1e-11
         assert float((g1 - g2).abs().max()) <= eps * max(1.0, float(g2.abs().max())), (c["shape"], kw)
 
@@ -953,3 +939,42 @@ def test_batch_gradient_with_forward_boxes():
     want = orc.deform_grid_gradient(dY[1].cpu().numpy(), D[1].cpu().numpy(), **kw)
     truth = orc.deform_grid_gradient(dY[1].cpu().numpy().astype(np.float64), D[1].cpu().numpy(), **kw)
     _f32_grad_check(g2[1].cpu().numpy(), want, truth)
+
+
+def test_batch_gradient_never_reuses_stale_grids():
+    """the batch gradient must not reuse the forward call's FILTERED grids on the
+    strength of (storage address, version counter).  (1) a `.data` write leaves both unchanged;
+    (2) a freed displacement tensor's address is handed to the next same-shaped grid by torch's
+    caching allocator, with the same version counter.  Both must give the gradient of the NEW grid."""
+    rng = np.random.default_rng(17)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, shape, pts = 2, (24, 40, 40), (3, 3, 4)
+    X = torch.from_numpy(rng.random((B,) + shape).astype(np.float32)).to(dev)
+    dY = torch.from_numpy(rng.standard_normal((B,) + shape).astype(np.float32)).to(dev)
+    kw = dict(order=3, mode="mirror")
+
+    def check(g, D):
+        for b in range(B):
+            want = orc.deform_grid_gradient(dY[b].cpu().numpy(), D[b].cpu().numpy(), **kw)
+            truth = orc.deform_grid_gradient(dY[b].cpu().numpy().astype(np.float64), D[b].cpu().numpy(), **kw)
+            _f32_grad_check(g[b].cpu().numpy(), want, truth)
+
+    # (1) .data write between forward and gradient
+    D = torch.from_numpy(rng.standard_normal((B, 3) + pts) * 1.0).to(dev)
+    ed.deform_grid_batch(X, D, **kw)
+    version = D._version
+    D.data.copy_(torch.from_numpy(rng.standard_normal((B, 3) + pts) * 6.0))
+    assert D._version == version
+    check(ed.deform_grid_gradient_batch(dY, D, **kw), D)
+
+    # (2) free / reallocate at the same address
+    def make(scale):
+        return torch.from_numpy(rng.standard_normal((B, 3) + pts) * scale).to(dev)
+    D1 = make(1.0)
+    ptr = D1.data_ptr()
+    ed.deform_grid_batch(X, D1, **kw)
+    del D1
+    D2 = make(7.0)
+    if D2.data_ptr() != ptr:
+        pytest.skip("the allocator did not reuse the address")
+    check(ed.deform_grid_gradient_batch(dY, D2, **kw), D2)

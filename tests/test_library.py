@@ -122,3 +122,31 @@ def test_empty_work_is_ok_without_a_gpu():
     # zero output voxels: validated, nothing launched, EDHIP_OK
     d2 = _desc((2, 3, 3), "float64")
     _call([_desc((8, 9))], d2, [_desc((0, 9))], [(0, 1)])
+
+
+def test_shipped_library_has_no_environment_switches():
+    """profiling / ablation switches must not ship.  The default build never calls
+    getenv (the symbol is not even imported), so no environment variable -- EDHIP_HOT_ABL used to select
+    kernels that skip the gather -- can change what the library launches or returns; the switches
+    exist only behind EDHIP_EXPERIMENTS (make EXPERIMENTS=1), through the one helper ed_env()."""
+    import glob
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "elasticdeform_amd", "csrc")
+    calls = 0
+    for path in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        text = open(path).read()
+        calls += len(re.findall(r"(?<![A-Za-z_])getenv\s*\(", text))
+    assert calls <= 1, calls          # the one call inside ed_env()'s EDHIP_EXPERIMENTS branch
+    text = open(os.path.join(csrc, "ed_device.h")).read()
+    i = text.index("#ifdef EDHIP_EXPERIMENTS")
+    assert "getenv" in text[i:text.index("#else", i)] and "getenv" not in text[text.index("#else", i):text.index("#endif", i)]
+    lib = os.path.join(root, "elasticdeform_amd", "libedhip.so")
+    syms = subprocess.run(["nm", "-D", lib], capture_output=True, text=True).stdout
+    if "edhip_experiments_build" in syms:
+        pytest.skip("the library in the tree is a profiling build (make EXPERIMENTS=1)")
+    assert "getenv" not in syms, "the shipped library imports getenv"
+    blob = open(lib, "rb").read()
+    for name in (b"EDHIP_HOT_ABL", b"EDHIP_TILE_DBG", b"EDHIP_GRAD_DUO", b"EDHIP_WAVE"):
+        assert name not in blob, name
