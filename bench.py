@@ -30,7 +30,12 @@ Extra objects on the JSON line:
                 SURVEY.md 8d) / average launch duration; peak 8 TB/s.  `traffic` = HBM bytes per
                 launch from the PMC passes recorded in profiles/hbm_traffic.json, reported only
                 when that file was measured for the kernel named here (stamped with its commit).
-  north_star_kernel   the same numbers for K1, the kernel BASELINE.json's 50 % target is quoted on.
+  north_star_kernel   the same numbers for K1, the kernel BASELINE.json's 50 % target is quoted on;
+                `frac_read_only` prices it on the READ bytes alone (4 B/voxel), the literal
+                "HBM-read roofline" of north_star.
+  stress        SURVEY.md 8(d) "report both": the same step at sigma = 10 (the README example's
+                aggressiveness: displacement gradient ~1.25, many tiles take the spill levels), a few
+                timed steps after the headline region; cfg2, rank 0, N = 1 only.
   step_roofline       the whole step against HBM: 64 B/voxel algorithmic (K3 24 + K1 8 + K2 8 +
                 K4 24) / ms_per_step.
   cpu_baseline  the REAL reference C path (oracle/_ref, compiled from /root/reference) when that
@@ -302,12 +307,20 @@ def main():
                 "avg_launch_us": round(us, 2), "median_launch_us": round(med, 2),
                 "whole_call_avg_us": round(call_ms * 1e3, 2)}
 
+    def commit_built():
+        try:
+            from elasticdeform_amd import _build_info
+            return _build_info.COMMIT
+        except Exception:
+            return None
+
     k1_obj = kernel_obj("K1", "K1 forward deform: hot_fwd_kernel<3,false> (deform_hot.hip; the strip launch of "
                         "one edhip_deform gradient=0 call on the prefiltered input; whole_call adds the "
                         "tables kernel and the two spill passes)", k1_us, k1_med, k1_ms)
     k2_obj = kernel_obj("K2", "K2 gradient scatter-add: hot_grad_kernel<3,false> (deform_hot.hip; the strip "
                         "launch of one edhip_deform gradient=1 call; whole_call adds the tables kernel and "
                         "the two spill passes)", k2_us, k2_med, k2_ms)
+    k1_obj["frac_read_only"] = round(4.0 * vox / (k1_us * 1e-6) / 1e9 / 8000.0, 4)
     dominant = k2_obj if k2_us >= k1_us else k1_obj
     dominant = dict(dominant)
     dominant["note"] = ("dominant = largest per-step GPU time among K1, K2 and the six prefilter passes "
@@ -320,6 +333,30 @@ def main():
                 "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 4),
                 "note": "64 B/voxel = prefilter 24 + forward 8 + gradient 8 + transposed prefilter 24"}
+
+    stress = None
+    if rank == 0 and world == 1 and not cfg5:
+        disp10 = torch.from_numpy(np.random.default_rng(22).standard_normal((3, 5, 5, 5)) * (10.0 * n / 256)).to(dev)
+
+        def step10():
+            fwd(X, disp10, **kw)
+            bwd(dY, disp10, **kw)
+        for _ in range(3):
+            step10()
+        torch.cuda.synchronize()
+        ns = max(5, args.steps // 2)
+        t0s = time.perf_counter()
+        for _ in range(ns):
+            step10()
+        torch.cuda.synchronize()
+        ms10 = (time.perf_counter() - t0s) / ns * 1e3
+        _, f10 = timed(lambda: fwd(X, disp10, **kw), 10)
+        _, g10 = timed(lambda: bwd(dY, disp10, **kw), 10)
+        stress = {"workload": "cfg2 at sigma 10 (stress): same volume, grid N(0,1)*10, order 3, mirror, prefilter on, "
+                              "deform_grid + deform_grid_gradient per step",
+                  "steps": ns, "ms_per_step": round(ms10, 4), "value": round(vox / (ms10 * 1e-3) / 1e6, 2),
+                  "unit": "Mvoxels/s", "vs_headline_ms": round(ms10 / (elapsed / args.steps * 1e3), 3),
+                  "deform_grid_ms": round(f10, 4), "deform_grid_gradient_ms": round(g10, 4)}
 
     if rank == 0:
         if cfg5:
@@ -348,7 +385,7 @@ def main():
             "roofline": dominant,
             "north_star_kernel": k1_obj,
             "step_roofline": step_obj,
-            "commit": commit_id(),
+            "commit": commit_id() or commit_built(),
             "phases_ms": {"deform_grid": round(fwd_ms, 4), "deform_grid_gradient": round(grad_ms, 4),
                           "K1_forward": round(k1_ms, 4), "K2_gradient": round(k2_ms, 4),
                           "K3_prefilter_3axes": round(k3_ms, 4),
@@ -356,6 +393,8 @@ def main():
             "fwd_only_mvox_s": round(vox / (fwd_ms * 1e-3) / 1e6, 1),
             "k1_only_mvox_s": round(vox / (k1_ms * 1e-3) / 1e6, 1),
         }
+        if stress is not None:
+            res["stress"] = stress
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

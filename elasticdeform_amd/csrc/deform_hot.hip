@@ -899,6 +899,11 @@ ED_UNROLL(ED_K2_U2)
                 // boxes handed over by the forward call are a hint: a window outside goes the direct way
                 const bool outside = given && (rz < 0 || rz + ORDER >= ext[0] || ry < 0 || ry + ORDER >= ext[1] ||
                                                rx < 0 || rx + ORDER >= ext[2]);
+                // (A contribution is resolved to wmax * sum|dY| / 2^31 of its TILE.  Sending voxels far
+                // below the tile's scale down the float path as well was measured and dropped: with a
+                // threshold of 2^-20 of the tile's sum 0.05 % of the voxels of a uniform-random dY take
+                // it, but 3 % of the WAVES then run the 64-iteration loop -- K2 310 -> 387 us.  The bound
+                // is documented in include/edhip.h and pinned by a test instead.)
                 if ((__float_as_int(gv) & 0x7f800000) == 0x7f800000 || outside) {
                     // inf / NaN gradient (no fixed-point scale), or a window outside a stale box: this
                     // voxel scatters its taps with float atomics straight to global memory (rare,

@@ -169,6 +169,17 @@ int edhip_device_count(void);
  *                        or NULL (deform.c:771-776; built by deform_grid.py:392-438).
  *   flags                enum edhip_flags.
  *   hip_stream           hipStream_t to enqueue on (NULL = the legacy default stream).
+ *
+ * Float gradients (fast arithmetic, 3 deformed axes): a tile of output voxels is accumulated in LDS
+ * in fixed point, in a scale taken from the tile's sum of |dY|; one contribution is resolved to
+ * wmax * sum|dY| / 2^31 of its tile (float32; 2^62 for float64) -- far below the float32 rounding of
+ * the reference's own `+=` (deform.c:309-312) for data of one magnitude.  The bound is ABSOLUTE per
+ * tile (8 x 8 x 16 output voxels): next to a dY value that is orders of magnitude above its
+ * neighbours, the neighbours' contributions are rounded to that resolution (1e6 among 1e-3: the small
+ * ones keep about 1e-4 absolute), where the reference's float `+=` keeps their relative precision in
+ * cells the large value does not reach; other tiles are unaffected.  Non-finite dY values are added
+ * with float atomics.  The order of the atomic additions is not reproducible from run to run
+ * (about 1e-7 of the gradient's scale).  Integer gradients are bit-exact.
  */
 int edhip_deform(int gradient, int ninputs,
                  const edhip_array* inputs,

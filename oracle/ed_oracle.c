@@ -4,7 +4,7 @@
  * Nothing in the product (elasticdeform_amd/) may import, link or call this file; only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_reference.py compares this restatement with the
+ * Parity status: PINNED.  tests/test_oracle.py compares this restatement with the
  * real reference (compiled from /root/reference into oracle/_ref by oracle/Makefile) and with the
  * golden vectors under tests/golden/ that tests/golden/gen_golden.py produced by importing the
  * reference; float64 / float32 / integer results are bit-identical (same IEEE double operations
@@ -572,7 +572,7 @@ done:
  * poles as correctly rounded decimal literals, which differ from the sqrt() expressions by an
  * ulp or so (up to 3e-13 relative for the second pole of orders 4/5, where the expression
  * cancels).  With the literals below the restatement is bit-identical to
- * scipy.ndimage.spline_filter1d (tests/test_oracle_vs_reference.py). */
+ * scipy.ndimage.spline_filter1d (tests/test_oracle.py). */
 static int spline_poles(int order, int transpose, double* pole, double* gain)
 {
     int n = 0, h;

@@ -278,10 +278,14 @@ def big_cases():
         cases.append(dict(name="cfg5_b%d" % b, make=make5, grad=True, big=True,
                           dY=lambda b=b: cfg5_sample(b)[3],
                           pick=lambda: ((slice(3, 128, 8), slice(5, 128, 8), slice(64, 128)),)))
-    cases.append(dict(name="cfg4_multi", make=cfg4_inputs, grad=False, big=True,
+    # gradient at size too: dX has the inputs' shapes (3 x 256^3 float32 accumulated
+    # through the transposed prefilter, 256^3 int32), stored on a sub-grid of the region the crop maps from
+    cases.append(dict(name="cfg4_multi", make=cfg4_inputs, grad=True, big=True,
                       pick=lambda: ((slice(None), slice(None, None, 4), slice(None, None, 4),
                                      slice(None, None, 2)),
-                                    (slice(None, None, 2), slice(None, None, 2), slice(None)))))
+                                    (slice(None, None, 2), slice(None, None, 2), slice(None))),
+                      gpick=lambda: ((slice(None), slice(72, 184, 4), slice(72, 184, 4), slice(72, 184, 2)),
+                                     (slice(72, 184, 2), slice(72, 184, 2), slice(72, 184)))))
     return cases
 
 

@@ -40,10 +40,14 @@ def main():
 
     # GOLDEN_ONLY=small: regenerate small.npz only (the BASELINE-sized cases take minutes of CPU)
     only_small = os.environ.get("GOLDEN_ONLY") == "small"
+    # GOLDEN_CASE=name: recompute that one case and merge it into the existing archive
+    one_case = os.environ.get("GOLDEN_CASE")
     stores = {"small": {}, "big": {}}
     t0 = time.time()
     for case in C.all_cases():
         if only_small and case["big"]:
+            continue
+        if one_case and case["name"] != one_case:
             continue
         X, disp, kw = case["make"]()
         store = stores["big" if case["big"] else "small"]
@@ -56,9 +60,10 @@ def main():
             dY = C.seeded_dY(case, out)
             g = ref.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
             gs = g if isinstance(g, list) else [g]
+            gpicks = case["gpick"]() if case.get("gpick") else picks
             for i, gi in enumerate(gs):
                 store["%s/grad%d" % (case["name"], i)] = \
-                    gi if picks[i] is None else gi[picks[i]].copy()
+                    gi if gpicks[i] is None else gi[gpicks[i]].copy()
         print("%-40s %6.2fs" % (case["name"], time.time() - t0), flush=True)
 
     # spline prefilter (SciPy, third-party arithmetic on the path) and its transpose (reference C)
@@ -86,6 +91,20 @@ def main():
         ext.spline_filter1d_grad(a, g, 1, 3)
         filt["tr_o3_%s" % dt] = g
 
+    if one_case:
+        for which in ("small", "big"):
+            if stores[which]:
+                path = os.path.join(HERE, which + ".npz")
+                merged = dict(np.load(path))
+                merged.update(stores[which])
+                np.savez_compressed(path, **merged)
+                with open(os.path.join(HERE, "meta.json")) as f:
+                    meta = json.load(f)
+                meta["n_" + which] = len(merged)
+                with open(os.path.join(HERE, "meta.json"), "w") as f:
+                    json.dump(meta, f, indent=1)
+                print(which + ".npz", os.path.getsize(path) // 1024, "KiB,", len(merged), "arrays")
+        return 0
     np.savez_compressed(os.path.join(HERE, "small.npz"), **stores["small"])
     if only_small:
         with open(os.path.join(HERE, "meta.json")) as f:

@@ -17,10 +17,11 @@ def _aslist(v):
     return v if isinstance(v, list) else [v]
 
 
-def _apply_pick(case, arrs):
-    if not case["pick"]:
+def _apply_pick(case, arrs, grad=False):
+    pick = case.get("gpick") if grad and case.get("gpick") else case["pick"]
+    if not pick:
         return arrs
-    return [a[p] for a, p in zip(arrs, case["pick"]())]
+    return [a[p] for a, p in zip(arrs, pick())]
 
 
 SMALL = [c for c in C.all_cases() if not c["big"]]
@@ -41,7 +42,7 @@ def test_oracle_matches_golden_small(case, golden):
         dY = C.seeded_dY(case, out)
         grad = orc.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
         want = golden.outputs(case, "grad")
-        got = _apply_pick(case, _aslist(grad))
+        got = _apply_pick(case, _aslist(grad), grad=True)
         assert len(want) == len(got)
         for w, g in zip(want, got):
             assert g.dtype == w.dtype
@@ -59,7 +60,7 @@ def test_oracle_matches_golden_baseline_configs(case, golden):
     if case["grad"]:
         dY = C.seeded_dY(case, out)
         grad = orc.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
-        for w, g in zip(golden.outputs(case, "grad"), _apply_pick(case, _aslist(grad))):
+        for w, g in zip(golden.outputs(case, "grad"), _apply_pick(case, _aslist(grad), grad=True)):
             np.testing.assert_array_equal(g, w)
 
 
