@@ -40,6 +40,18 @@ __device__ __forceinline__ uint16_t float_to_bf16(float f)
     return (uint16_t)(u >> 16);
 }
 
+// bytes per element of an edhip_dtype (0 for an unknown code)
+__host__ __device__ __forceinline__ int dtype_size(int dt)
+{
+    switch (dt) {
+    case EDHIP_BOOL: case EDHIP_U8: case EDHIP_I8: return 1;
+    case EDHIP_U16: case EDHIP_I16: case EDHIP_F16: case EDHIP_BF16: return 2;
+    case EDHIP_U32: case EDHIP_I32: case EDHIP_F32: return 4;
+    case EDHIP_U64: case EDHIP_I64: case EDHIP_F64: return 8;
+    default: return 0;
+    }
+}
+
 __device__ __forceinline__ double load_as_double(const char* p, int dt)
 {
     switch (dt) {

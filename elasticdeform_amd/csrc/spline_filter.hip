@@ -13,7 +13,9 @@
 // is across lines).  The fp64 working copy of the lines lives in a line-interleaved scratch
 // buffer ws[i * nlines + line], so that the 64 lanes of a wave, which hold 64 different lines,
 // always touch 64 consecutive doubles -- coalesced whatever the filtered axis is.
+#include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include "ed_device.h"
 #include "ed_params.h"
 
@@ -39,32 +41,10 @@ __device__ __forceinline__ LineAddr line_address(const FilterParams& p, int64_t 
     return {p.in + in_off, p.out + out_off};
 }
 
-// forward prefilter of one line (SciPy: gain, then per pole causal init / causal recursion /
-// anti-causal init / anti-causal recursion)
-// LDSWS: the fp64 working copy of the block's lines sits in LDS ([len][blockDim] doubles, the same
-// line-interleaved layout) instead of the global scratch buffer: short lines (small volumes, integer
-// volumes of any rank) otherwise pay a dependent global round trip per sample -- 28 us per pass for a
-// 32^3 volume, more than the deformation itself.  Same operations in the same order: same bits.
-template <bool LDSWS>
-__global__ __launch_bounds__(256) void prefilter_kernel(const FilterParams p, const int64_t line0,
-                                                        const int64_t nl)
+// forward prefilter of one line in place (SciPy: [gain applied by the caller], then per pole causal
+// init / causal recursion / anti-causal init / anti-causal recursion); element i at ws[i * wst]
+__device__ __forceinline__ void forward_line(double* ws, const int64_t wst, const int64_t n, const FilterParams& p)
 {
-    extern __shared__ double lws[];
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nl)
-        return;
-    const LineAddr a = line_address(p, line0 + j);
-    const int64_t n = p.len;
-    const int64_t wst = LDSWS ? (int64_t)blockDim.x : nl;
-    double* ws = LDSWS ? lws + threadIdx.x : p.ws + j;      // element i at ws[i * wst]
-    if (n < 2 || p.npoles == 0) {
-        for (int64_t i = 0; i < n; ++i)
-            store_cast(a.out + i * p.out_axis_stride, p.out_dtype,
-                       load_as_double(a.in + i * p.in_axis_stride, p.in_dtype));
-        return;
-    }
-    for (int64_t i = 0; i < n; ++i)
-        ws[i * wst] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype) * p.gain;
     for (int h = 0; h < p.npoles; ++h) {
         const double z = p.pole[h];
         const double zn1 = p.pole_pow[h];
@@ -87,47 +67,22 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const FilterParams p, co
         }
         // anti-causal initialisation and recursion c[i] = z (c[i+1] - c[i])
         double next = (z * prev2 + prev) * z / (z * z - 1);
-        const bool last = h == p.npoles - 1;
-        if (last)
-            store_cast(a.out + (n - 1) * p.out_axis_stride, p.out_dtype, next);
-        else
-            ws[(n - 1) * wst] = next;
+        ws[(n - 1) * wst] = next;
         for (int64_t i = n - 2; i >= 0; --i) {
             const double c = z * (next - ws[i * wst]);
-            if (last)
-                store_cast(a.out + i * p.out_axis_stride, p.out_dtype, c);
-            else
-                ws[i * wst] = c;
+            ws[i * wst] = c;
             next = c;
         }
     }
 }
 
-// transpose of the prefilter on one line -- deform.c:1116-1156
-template <bool LDSWS>
-__global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterParams p,
-                                                                  const int64_t line0,
-                                                                  const int64_t nl)
+// transpose of the prefilter on one line in place, gain included -- deform.c:1116-1156
+__device__ __forceinline__ void transpose_line(double* ws, const int64_t wst, const int64_t len, const FilterParams& p)
 {
-    extern __shared__ double lws[];
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nl)
-        return;
-    const LineAddr a = line_address(p, line0 + j);
-    const int64_t len = p.len;
-    const int64_t wst = LDSWS ? (int64_t)blockDim.x : nl;
-    double* ws = LDSWS ? lws + threadIdx.x : p.ws + j;
-    if (len <= 1 || p.npoles == 0) {
-        for (int64_t i = 0; i < len; ++i)
-            store_cast(a.out + i * p.out_axis_stride, p.out_dtype,
-                       load_as_double(a.in + i * p.in_axis_stride, p.in_dtype));
-        return;
-    }
-    for (int64_t i = 0; i < len; ++i)
-        ws[i * wst] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype);
     for (int h = 0; h < p.npoles; ++h) {
         const double q = p.pole[h];
         const bool last = h == p.npoles - 1;
+        const double gl = last ? p.gain : 1.0;      // (x * 1.0 is exact: the intermediate poles are unchanged)
         // adjoint of the anti-causal recursion, running sum for the adjoint of its initialisation
         double x0 = ws[0];
         double sum = q * x0;
@@ -153,14 +108,10 @@ __global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterPa
         if (p.trunc_branch[h]) {
             const double l0 = next;
             double zn = q;
-            if (last)
-                store_cast(a.out, p.out_dtype, l0 * p.gain);
+            ws[0] = last ? l0 * p.gain : l0;
             for (int64_t ll = 1; ll < len; ++ll) {
                 const double c = ws[ll * wst] + zn * l0;
-                if (last)
-                    store_cast(a.out + ll * p.out_axis_stride, p.out_dtype, c * p.gain);
-                else
-                    ws[ll * wst] = c;
+                ws[ll * wst] = last ? c * p.gain : c;
                 zn *= q;
             }
         } else {
@@ -170,24 +121,224 @@ __global__ __launch_bounds__(256) void prefilter_transpose_kernel(const FilterPa
             const double l0 = next / (1.0 - z2n * z2n);
             const double tail = ws[(len - 1) * wst] + z2n * l0;
             z2n *= z2n * iz;
-            if (last) {
-                store_cast(a.out, p.out_dtype, l0 * p.gain);
-                store_cast(a.out + (len - 1) * p.out_axis_stride, p.out_dtype, tail * p.gain);
-            } else {
-                ws[0] = l0;
-                ws[(len - 1) * wst] = tail;
-            }
+            ws[0] = last ? l0 * p.gain : l0;
+            ws[(len - 1) * wst] = last ? tail * p.gain : tail;
             for (int64_t ll = 1; ll <= len - 2; ++ll) {
                 const double c = ws[ll * wst] + (zn + z2n) * l0;
-                if (last)
-                    store_cast(a.out + ll * p.out_axis_stride, p.out_dtype, c * p.gain);
-                else
-                    ws[ll * wst] = c;
+                ws[ll * wst] = last ? c * p.gain : c;
                 zn *= q;
                 z2n *= iz;
             }
         }
+        (void)gl;
     }
+}
+
+// The same two recursions for a line in an LDS tile (element i at ws[i * kTilePitch]), blocked by 8: the
+// 8 LDS reads of a block are issued together and the dependent fp64 chain runs on registers.  With one
+// wave per CU nothing else hides the LDS latency, and the compiler does not pipeline the rolled loops
+// above.  Same operations on the same operands in the same order: same bits.
+constexpr int kTileLines = 64, kTilePitch = 65, kBlk = 8;
+__device__ __forceinline__ void forward_line_tile(double* ws, const int n, const FilterParams& p)
+{
+    constexpr int W = kTilePitch;
+    for (int h = 0; h < p.npoles; ++h) {
+        const double z = p.pole[h];
+        const double zn1 = p.pole_pow[h];
+        double c0 = ws[0] + zn1 * ws[(n - 1) * W];
+        double zi = z;
+        int i = 1;
+        for (; i + kBlk <= n - 1; i += kBlk) {
+            double a[kBlk], b[kBlk];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k) {
+                a[k] = ws[(i + k) * W];
+                b[k] = ws[(n - 1 - i - k) * W];
+            }
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k) {
+                c0 += zi * (a[k] + zn1 * b[k]);
+                zi *= z;
+            }
+        }
+        for (; i < n - 1; ++i) {
+            c0 += zi * (ws[i * W] + zn1 * ws[(n - 1 - i) * W]);
+            zi *= z;
+        }
+        c0 /= 1 - zn1 * zn1;
+        ws[0] = c0;
+        double prev = c0, prev2 = c0;
+        i = 1;
+        for (; i + kBlk <= n; i += kBlk) {
+            double a[kBlk];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k)
+                a[k] = ws[(i + k) * W];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k) {
+                const double c = a[k] + z * prev;
+                a[k] = c;
+                prev2 = prev;
+                prev = c;
+            }
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k)
+                ws[(i + k) * W] = a[k];
+        }
+        for (; i < n; ++i) {
+            const double c = ws[i * W] + z * prev;
+            ws[i * W] = c;
+            prev2 = prev;
+            prev = c;
+        }
+        double next = (z * prev2 + prev) * z / (z * z - 1);
+        ws[(n - 1) * W] = next;
+        i = n - 2;
+        for (; i - kBlk + 1 >= 0; i -= kBlk) {
+            double a[kBlk];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k)
+                a[k] = ws[(i - k) * W];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k) {
+                const double c = z * (next - a[k]);
+                a[k] = c;
+                next = c;
+            }
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k)
+                ws[(i - k) * W] = a[k];
+        }
+        for (; i >= 0; --i) {
+            const double c = z * (next - ws[i * W]);
+            ws[i * W] = c;
+            next = c;
+        }
+    }
+}
+
+// One thread per line; LDSWS: the fp64 working copy of the block's lines sits in LDS ([len][blockDim]
+// doubles, line-interleaved) instead of the global scratch buffer: short lines (small volumes)
+// otherwise pay a dependent global round trip per sample -- 28 us per pass for a 32^3 volume, more
+// than the deformation itself.  Same operations in the same order: same bits.
+template <bool LDSWS, bool TRANSPOSE>
+__global__ __launch_bounds__(256) void prefilter_kernel(const FilterParams p, const int64_t line0,
+                                                        const int64_t nl)
+{
+    extern __shared__ double lws[];
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nl)
+        return;
+    const LineAddr a = line_address(p, line0 + j);
+    const int64_t n = p.len;
+    const int64_t wst = LDSWS ? (int64_t)blockDim.x : nl;
+    double* ws = LDSWS ? lws + threadIdx.x : p.ws + j;      // element i at ws[i * wst]
+    if (n < 2 || p.npoles == 0) {
+        for (int64_t i = 0; i < n; ++i)
+            store_cast(a.out + i * p.out_axis_stride, p.out_dtype,
+                       load_as_double(a.in + i * p.in_axis_stride, p.in_dtype));
+        return;
+    }
+    if (TRANSPOSE) {
+        for (int64_t i = 0; i < n; ++i)
+            ws[i * wst] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype);
+        transpose_line(ws, wst, n, p);
+    } else {
+        for (int64_t i = 0; i < n; ++i)
+            ws[i * wst] = load_as_double(a.in + i * p.in_axis_stride, p.in_dtype) * p.gain;
+        forward_line(ws, wst, n, p);
+    }
+    for (int64_t i = 0; i < n; ++i)
+        store_cast(a.out + i * p.out_axis_stride, p.out_dtype, ws[i * wst]);
+}
+
+// Lines of 129 .. 313 samples (256^3 volumes): a tile of 64 lines in LDS (fp64, [len][65]: one wave per
+// CU owns the 160 KiB).  All 256 threads move the tile -- along the filtered axis when that is the
+// contiguous one, across the 64 lines otherwise, so that a wave instruction touches consecutive
+// addresses either way -- and one wave runs the 64 recursions.  The per-thread kernel above walks its
+// line sample by sample through global memory: a dependent round trip per sample and, for the
+// contiguous axis, 64 cache lines per wave instruction (256^3 int16: 340 us per axis pass).
+// calls f(std::integral_constant<int, DT>) for the runtime dtype code: the per-element switch of
+// load_as_double / store_cast folds away inside f, and its loads can be issued back to back
+template <typename F>
+__device__ __forceinline__ void with_dtype(int dt, F&& f)
+{
+#define ED_DT_CASE(D) case D: f(std::integral_constant<int, D>()); break;
+    switch (dt) {
+    ED_DT_CASE(EDHIP_BOOL) ED_DT_CASE(EDHIP_U8) ED_DT_CASE(EDHIP_I8) ED_DT_CASE(EDHIP_U16) ED_DT_CASE(EDHIP_I16)
+    ED_DT_CASE(EDHIP_U32) ED_DT_CASE(EDHIP_I32) ED_DT_CASE(EDHIP_U64) ED_DT_CASE(EDHIP_I64) ED_DT_CASE(EDHIP_F16)
+    ED_DT_CASE(EDHIP_BF16) ED_DT_CASE(EDHIP_F32)
+    default: f(std::integral_constant<int, EDHIP_F64>()); break;
+    }
+#undef ED_DT_CASE
+}
+
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void prefilter_line_tile_kernel(const FilterParams p)
+{
+    extern __shared__ double lws[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t line0 = (int64_t)blockIdx.x * kTileLines;
+    const int nl = (int)(p.nlines - line0 < kTileLines ? p.nlines - line0 : kTileLines);
+    const int n = (int)p.len;
+    // (no static LDS: the dynamic allocation may then take all 160 KiB)
+    int64_t* s_in = reinterpret_cast<int64_t*>(lws + (size_t)n * kTilePitch);
+    int64_t* s_out = s_in + kTileLines;
+    if (tid < kTileLines) {
+        const LineAddr a = line_address(p, line0 + (tid < nl ? tid : nl - 1));
+        s_in[tid] = a.in - p.in;
+        s_out[tid] = a.out - p.out;
+    }
+    __syncthreads();
+    const bool along_in = p.in_axis_stride == dtype_size(p.in_dtype);
+    const bool along_out = p.out_axis_stride == dtype_size(p.out_dtype);
+    const double g = TRANSPOSE ? 1.0 : p.gain;
+    // ---- tile -> LDS: a wave instruction touches consecutive addresses either along the filtered axis
+    //      (lanes <-> samples, waves <-> lines) or across the lines (lanes <-> lines, waves <-> samples)
+    with_dtype(p.in_dtype, [&](auto dt) {
+        constexpr int DT = decltype(dt)::value;
+        if (along_in) {
+            for (int l = wave; l < nl; l += 4) {
+                const char* base = p.in + s_in[l];
+#pragma unroll 4
+                for (int i = lane; i < n; i += 64) {
+                    const double v = load_as_double(base + (int64_t)i * p.in_axis_stride, DT);
+                    lws[i * kTilePitch + l] = TRANSPOSE ? v : v * g;
+                }
+            }
+        } else if (lane < nl) {
+            const char* base = p.in + s_in[lane];
+#pragma unroll 8
+            for (int i = wave; i < n; i += 4) {
+                const double v = load_as_double(base + (int64_t)i * p.in_axis_stride, DT);
+                lws[i * kTilePitch + lane] = TRANSPOSE ? v : v * g;
+            }
+        }
+    });
+    __syncthreads();
+    if (tid < nl) {
+        if (TRANSPOSE)
+            transpose_line(lws + tid, kTilePitch, n, p);
+        else
+            forward_line_tile(lws + tid, n, p);
+    }
+    __syncthreads();
+    with_dtype(p.out_dtype, [&](auto dt) {
+        constexpr int DT = decltype(dt)::value;
+        if (along_out) {
+            for (int l = wave; l < nl; l += 4) {
+                char* base = p.out + s_out[l];
+#pragma unroll 4
+                for (int i = lane; i < n; i += 64)
+                    store_cast(base + (int64_t)i * p.out_axis_stride, DT, lws[i * kTilePitch + l]);
+            }
+        } else if (lane < nl) {
+            char* base = p.out + s_out[lane];
+#pragma unroll 8
+            for (int i = wave; i < n; i += 4)
+                store_cast(base + (int64_t)i * p.out_axis_stride, DT, lws[i * kTilePitch + lane]);
+        }
+    });
 }
 
 // Whole-grid order-3 prefilter of a small control grid (<= 4096 points) in ONE launch: the grid
@@ -280,11 +431,42 @@ hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
         if (nblk <= 0x7fffffffLL) {
             const dim3 grid((unsigned)nblk);
             if (p.transpose)
-                hipLaunchKernelGGL(prefilter_transpose_kernel<true>, grid, dim3(blk), lds, stream, p,
+                hipLaunchKernelGGL((prefilter_kernel<true, true>), grid, dim3(blk), lds, stream, p,
                                    (int64_t)0, p.nlines);
             else
-                hipLaunchKernelGGL(prefilter_kernel<true>, grid, dim3(blk), lds, stream, p, (int64_t)0,
+                hipLaunchKernelGGL((prefilter_kernel<true, false>), grid, dim3(blk), lds, stream, p, (int64_t)0,
                                    p.nlines);
+            return hipGetLastError();
+        }
+    }
+    // 129 .. 313 samples (the lines of a 256^3 volume): tiles of 64 lines in LDS
+    if (p.len <= 313 && p.len >= 2 && p.npoles > 0 && !no_ldsws && dtype_size(p.in_dtype) > 0 &&
+        dtype_size(p.out_dtype) > 0) {
+        const size_t lds = (size_t)p.len * kTilePitch * sizeof(double) + 2 * kTileLines * sizeof(int64_t);
+        const int64_t nblk = (p.nlines + kTileLines - 1) / kTileLines;
+        bool ok = nblk <= 0x7fffffffLL;
+        if (ok && lds > 64 * 1024) {
+            // (per device: a process may drive several GPUs)
+            static std::atomic<unsigned long long> allowed{0};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const unsigned long long bit = 1ull << (dev & 63);
+            if (!(allowed.load(std::memory_order_acquire) & bit)) {
+                ok = hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_line_tile_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_line_tile_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                if (ok)
+                    allowed.fetch_or(bit, std::memory_order_release);
+                else
+                    (void)hipGetLastError();
+            }
+        }
+        if (ok) {
+            if (p.transpose)
+                hipLaunchKernelGGL(prefilter_line_tile_kernel<true>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
+            else
+                hipLaunchKernelGGL(prefilter_line_tile_kernel<false>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
             return hipGetLastError();
         }
     }
@@ -296,9 +478,9 @@ hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
         const int64_t nl = p.nlines - line0 < chunk ? p.nlines - line0 : chunk;
         const dim3 grid((unsigned)((nl + block - 1) / block));
         if (p.transpose)
-            hipLaunchKernelGGL(prefilter_transpose_kernel<false>, grid, dim3(block), 0, stream, p, line0, nl);
+            hipLaunchKernelGGL((prefilter_kernel<false, true>), grid, dim3(block), 0, stream, p, line0, nl);
         else
-            hipLaunchKernelGGL(prefilter_kernel<false>, grid, dim3(block), 0, stream, p, line0, nl);
+            hipLaunchKernelGGL((prefilter_kernel<false, false>), grid, dim3(block), 0, stream, p, line0, nl);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
