@@ -185,28 +185,11 @@ __global__ __launch_bounds__(256) void source_box_kernel(const GridGeom g, int* 
     }
 }
 
+// one (output voxel kk, step ss) pair in the reference's evaluation order
 template <int NAXIS, bool LDSGRID>
-__global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, const IOView v,
-                                                           const int gradient)
+__device__ __forceinline__ void exact_item(const GridGeom& g, const IOView& v, const int gradient,
+                                           const double* sgrid, const int per, const int64_t kk, const int64_t ss)
 {
-    extern __shared__ double sgrid[];       // LDSGRID: the control grid as doubles
-    int per = 0;
-    if (LDSGRID) {
-        per = stage_grid_lds<NAXIS>(g, sgrid);
-        __syncthreads();
-    }
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = g.nvox * v.nsteps;
-    if (tid >= total)
-        return;
-    int64_t kk, ss;
-    if (v.steps_fastest) {
-        kk = tid / v.nsteps;
-        ss = tid - kk * v.nsteps;
-    } else {
-        ss = tid / g.nvox;
-        kk = tid - ss * g.nvox;
-    }
 
     // output voxel index, last deformed axis fastest (from_scipy.h:67-79)
     int64_t o[NAXIS];
@@ -356,7 +339,75 @@ __global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, con
     }
 }
 
+template <int NAXIS, bool LDSGRID>
+__global__ __launch_bounds__(256) void deform_exact_kernel(const GridGeom g, const IOView v,
+                                                           const int gradient)
+{
+    extern __shared__ double sgrid[];       // LDSGRID: the control grid as doubles
+    int per = 0;
+    if (LDSGRID) {
+        per = stage_grid_lds<NAXIS>(g, sgrid);
+        __syncthreads();
+    }
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = g.nvox * v.nsteps;
+    if (tid >= total)
+        return;
+    int64_t kk, ss;
+    if (v.steps_fastest) {
+        kk = tid / v.nsteps;
+        ss = tid - kk * v.nsteps;
+    } else {
+        ss = tid / g.nvox;
+        kk = tid - ss * g.nvox;
+    }
+    exact_item<NAXIS, LDSGRID>(g, v, gradient, sgrid, per, kk, ss);
+}
+
+// The voxels of a list (the near-tie voxels of the integer fast path, deform_wave.hip), forward, every
+// step of each: [0] = count, [1 .. cap] = linear output voxel ids.  A list that overflowed its capacity
+// (adversarial inputs) means every voxel -- correct, at the exact kernel's speed.
+template <bool LDSGRID>
+__global__ __launch_bounds__(256) void deform_exact_list_kernel(const GridGeom g, const IOView v,
+                                                                const int* list, const int cap)
+{
+    extern __shared__ double sgrid[];
+    int per = 0;
+    const int count = list[0];
+    if (count == 0)
+        return;
+    if (LDSGRID) {
+        per = stage_grid_lds<3>(g, sgrid);
+        __syncthreads();
+    }
+    const bool all = count > cap;
+    const int64_t nv = all ? g.nvox : (int64_t)count;
+    const int64_t n = nv * v.nsteps;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iv = e / v.nsteps, ss = e - iv * v.nsteps;
+        const int64_t kk = all ? iv : (int64_t)list[1 + iv];
+        exact_item<3, LDSGRID>(g, v, 0, sgrid, per, kk, ss);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_deform_exact_list(const GridGeom& g, const IOView& v, const int* list, int cap,
+                                    hipStream_t stream)
+{
+    if (g.naxis != 3 || g.nvox <= 0)
+        return hipErrorInvalidValue;
+    int64_t points = 3;
+    for (int k = 0; k < 3; ++k)
+        points *= g.ncp[k];
+    const bool lds_grid = points <= 7680;
+    const size_t lds = lds_grid ? (size_t)points * sizeof(double) : 0;
+    if (lds_grid)
+        hipLaunchKernelGGL((deform_exact_list_kernel<true>), dim3(1024), dim3(256), lds, stream, g, v, list, cap);
+    else
+        hipLaunchKernelGGL((deform_exact_list_kernel<false>), dim3(1024), dim3(256), 0, stream, g, v, list, cap);
+    return hipGetLastError();
+}
 
 hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
 {

@@ -1216,6 +1216,60 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     if constexpr (std::is_integral<T>::value) {
         if (nb != 1)
             return hipErrorNotSupported;      // the label kernels take one volume per call
+        if (e == hipSuccess && v.order >= 1) {
+            // 8- / 16-bit integer volumes, orders 1-5: the wave-per-tile kernel with fp64 taps; the voxels it
+            // lists (value near a rounding tie, coordinate on a boundary) are redone by the exact kernel
+            HotGeom hg;
+            memset(&hg, 0, sizeof(hg));
+            hg.q = tg.q_global;
+            hg.xt = tg.xt_global;
+            hg.spill = tg.spill;
+            hg.q_bstride = tg.q_bstride;
+            for (int k = 0; k < 3; ++k) {
+                hg.in_len[k] = tg.in_len[k];
+                hg.out_len[k] = tg.out_len[k];
+                hg.off[k] = tg.off[k];
+                hg.tiles[k] = tg.tiles[k];
+                hg.period[k] = tg.period[k];
+                hg.inv_period[k] = tg.inv_period[k];
+            }
+            hg.vol_sz = tg.in_stride[0];
+            hg.vol_sy = tg.in_stride[1];
+            hg.img_sz = tg.out_stride[0];
+            hg.img_sy = tg.out_stride[1];
+            hg.ntiles = tg.ntiles;
+            hg.ncpx = tg.ncpx;
+            hg.mode = tg.mode;
+            hg.has_affine = tg.has_affine;
+            hg.cval = (float)ve.cval;
+            hg.cvald = ve.cval;
+            hg.nstep = ve.nstep;
+            hg.nsteps = ve.nsteps;
+            for (int l = 0; l < ve.nstep; ++l) {
+                hg.step_len[l] = ve.step_len[l];
+                hg.vol_step[l] = ve.in_step_stride[l];
+                hg.img_step[l] = ve.out_step_stride[l];
+            }
+            for (int k = 0; k < 12; ++k)
+                hg.affine[k] = tg.affine[k];
+            hg.tie_list = tg.label_list;
+            hg.tie_cap = tg.label_cap;
+            hg.strip_tiles = 4;
+            while (hg.strip_tiles > 1 &&
+                   (int64_t)tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + hg.strip_tiles - 1) / hg.strip_tiles) < 8192)
+                hg.strip_tiles >>= 1;
+            hg.strips_x = (tg.tiles[2] + hg.strip_tiles - 1) / hg.strip_tiles;
+            const int64_t wstrips = (int64_t)tg.tiles[0] * tg.tiles[1] * hg.strips_x;
+            if (wstrips > 0x3fffffffLL)
+                return hipErrorNotSupported;
+            hg.nstrips = hg.total_strips = (int)wstrips;
+            const size_t wlds = wave_lds_bytes(false, 3, &hg.box_cap);
+            const unsigned wblk = (unsigned)(((wstrips + 7) / 8) * 8);
+            e = launch_wave_int(hg, v.order, v.in_dtype, ve.in, ve.out, wblk, wlds, stream);
+            if (e == hipSuccess)
+                e = launch_deform_exact_list(g, v, tg.label_list, tg.label_cap, stream);
+            return e;
+        }
         if (e == hipSuccess) {
             const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
             hipLaunchKernelGGL(deform_tile3_label_kernel<T>, dim3(nblk), dim3(kBlock), 0, stream, g, ve, tg);
@@ -1552,6 +1606,34 @@ bool deform_label_supported(const GridGeom& g, const IOView& v, int gradient)
     if (q_global_bytes(g) > ((size_t)512 << 20) || 24 * (size_t)g.ncp[1] * (size_t)g.ncp[2] > 48 * 1024)
         return false;
     return true;
+}
+
+// integer fast path: 8- / 16-bit volumes, orders 1-5, forward, unit stride along the last deformed axis
+bool deform_int_supported(const GridGeom& g, const IOView& v, int gradient)
+{
+    if (g.naxis != 3 || gradient || v.order < 1 || v.order > 5 || v.in_dtype != v.out_dtype)
+        return false;
+    if (v.in_dtype != EDHIP_U8 && v.in_dtype != EDHIP_I8 && v.in_dtype != EDHIP_U16 && v.in_dtype != EDHIP_I16)
+        return false;
+    IOView v0 = v;
+    v0.order = 0;
+    if (!deform_label_supported(g, v0, 0))
+        return false;
+    const int64_t esz = label_elem_size(v.in_dtype);
+    if (v.in_stride[2] != esz || v.out_stride[2] != esz)
+        return false;
+    for (int k = 0; k < 3; ++k)
+        if (g.in_len[k] < 2)
+            return false;
+    return true;
+}
+
+hipError_t launch_deform_int(const GridGeom& g, const IOView& v, hipStream_t stream)
+{
+    if (!deform_int_supported(g, v, 0))
+        return hipErrorNotSupported;
+    return label_elem_size(v.in_dtype) == 1 ? launch_tile<uint8_t, 0, false, false>(g, v, stream, nullptr)
+                                            : launch_tile<uint16_t, 0, false, false>(g, v, stream, nullptr);
 }
 
 hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream)

@@ -42,6 +42,8 @@
 // so a wave would execute the incremental path and the full reload on almost every step.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ed_device.h"
 #include "ed_params.h"
 #include "ed_tile.h"
@@ -903,6 +905,371 @@ __global__ __launch_bounds__(64, OCC) void wave_grad_kernel(const HotGeom hg, co
     }
 }
 
+// ================================================================================================
+// Integer volumes (8- and 16-bit), spline orders 1-5, forward.  The reference runs every dtype through
+// one double-precision loop (deform.c:863-887) and rounds half away from zero into the type
+// (:292-306,906-919); integer results therefore have to be BIT-equal, and until now only the exact
+// kernel (one thread per voxel, the reference's evaluation order: 3.1 ms for 256^3 int16, order 3)
+// served them.  Here: the same walk as the float kernel, the box staged as float32 (exact for these
+// types), coordinates from the per-call tables, weights and taps in fp64.  That value is within
+// ~2e-5 of the reference's (the fast coordinate is within ~1e-11 of the reference's, |v| < 2^16), so
+// every voxel rounds identically EXCEPT where the value lies within 1e-4 of a rounding tie (x.5), or
+// where the coordinate sits on a decision boundary of the boundary map (an integer once it is at or
+// beyond the array's ends: the constant test, the fold points).  Those voxels -- a few per ten
+// thousand -- are listed and re-evaluated by the exact kernel (launch_deform_exact_list), exactly like
+// the near-tie voxels of the order-0 label kernel (deform_tile.hip).
+// ================================================================================================
+constexpr double kIntTieBand = 1e-4;
+constexpr double kCoordEps = 1e-6;
+
+// coordinates with the fraction in fp64; `near` is set when the voxel has to be re-evaluated exactly
+template <int ORDER, bool AFFINE>
+__device__ __forceinline__ bool int_coords(const HotGeom& hg, const HotParams* hp, const QCols& qc,
+                                           const double (&tw)[4], const int (&b)[3], const double (&P)[3],
+                                           int* start, double* frac, bool& near)
+{
+    double d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        d[c] = tw[0] * qc.v[0][c];
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            d[c] = fma(tw[l], qc.v[l][c], d[c]);
+    int ci[3];
+    bool inr[3];
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        inr[h] = coord_axis_fast<ORDER, double>(AFFINE ? P[h] + d[h] : d[h], AFFINE ? 0 : b[h], hg.in_len[h],
+                                                ci[h], frac[h]);
+        // the outermost cells take the slow region too: the array's ends are decision boundaries
+        constexpr int lo = (ORDER & 1) ? 0 : 1;
+        const int hi = (ORDER & 1) ? hg.in_len[h] - 2 : hg.in_len[h] - 2;
+        inr[h] = inr[h] && ci[h] > lo && ci[h] < hi;
+    }
+    bool cst = false;
+    near = false;
+    if (!(inr[0] && inr[1] && inr[2])) {
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            if (!inr[h]) {
+                const double c = AFFINE ? P[h] + d[h] : (double)b[h] + d[h];
+                const double fr = c - floor(c);
+                const bool outside = !(c >= kCoordEps && c <= (double)(hg.in_len[h] - 1) - kCoordEps);
+                near = near || (outside && (fr < kCoordEps || fr > 1.0 - kCoordEps)) || !(c == c);
+                cst = coord_axis_mapped<ORDER, double>(c, hg.in_len[h], hg.mode, hp->period[h], hp->inv_period[h],
+                                                       ci[h], frac[h]) || cst;
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+        start[h] = cst ? 0 : ci[h] - ORDER / 2;
+    return cst;
+}
+
+// (ORDER + 1)^3 taps in fp64 from the float32 box (column-first contraction, see wave_gather for the
+// pair / parity scheme)
+template <int ORDER, int PITCH>
+__device__ __forceinline__ double int_gather(const float* bp, int ps, bool par, const double (&w0)[ORDER + 1],
+                                             const double (&w1)[ORDER + 1], const double (&w2)[ORDER + 1])
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int NP = (NT + 2) / 2;
+    constexpr int NC = NT + 1;
+    double S[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+        S[j] = 0.0;
+#pragma unroll
+    for (int l0 = 0; l0 < NT; ++l0) {
+        const float* pp = bp + l0 * ps;
+        float v[NT][2 * NP];
+#pragma unroll
+        for (int l1 = 0; l1 < NT; ++l1) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float2 pr = *reinterpret_cast<const float2*>(pp + l1 * PITCH + 2 * p);
+                ED_NO_DS_MERGE();
+                v[l1][2 * p] = pr.x;
+                v[l1][2 * p + 1] = pr.y;
+            }
+            if (2 * NP > NC)
+                asm volatile("" ::"v"(v[l1][2 * NP - 1]));
+        }
+        double c[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            c[j] = 0.0;
+#pragma unroll
+        for (int l1 = 0; l1 < NT; ++l1)
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                c[j] = fma(w1[l1], (double)v[l1][j], c[j]);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            S[j] = fma(w0[l0], c[j], S[j]);
+            asm volatile("" : "+v"(S[j]));
+        }
+    }
+    S[0] = par ? 0.0 : S[0];
+    S[NT] = par ? S[NT] : 0.0;
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const double wl = j > 0 ? w2[j - 1] : 0.0, wr = j < NT ? w2[j] : 0.0;
+        a = fma(par ? wl : wr, S[j], a);
+    }
+    return a;
+}
+
+// the reference's store rule (deform.c:292-306): round half away from zero, clamp, C cast
+template <typename TIN>
+__device__ __forceinline__ TIN int_store_value(double t)
+{
+    constexpr bool is_signed = (TIN)(-1) < (TIN)0;
+    constexpr double lo = is_signed ? -(double)(1u << (8 * sizeof(TIN) - 1)) : 0.0;
+    constexpr double hi = is_signed ? (double)((1u << (8 * sizeof(TIN) - 1)) - 1) : (double)((1u << (8 * sizeof(TIN))) - 1);
+    t = t > 0 ? t + 0.5 : (is_signed ? t - 0.5 : 0.0);
+    t = t > hi ? hi : t;
+    t = t < lo ? lo : t;
+    return (TIN)(int)t;          // (NaN: the tie test below sends the voxel to the exact kernel)
+}
+
+template <int ORDER, bool AFFINE, typename TIN>
+__global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, const AxTab* __restrict__ xt,
+                                                             const double* __restrict__ qtab,
+                                                             const TIN* __restrict__ vol0, TIN* __restrict__ img0)
+{
+    constexpr int NT = ORDER + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HotParams* hp = reinterpret_cast<const HotParams*>(smem);
+    float* box = reinterpret_cast<float*>(smem + kWaveHead);
+    const int lane = threadIdx.x;
+    WaveStrip sp;
+    if (!wave_strip(hg, sp, blockIdx.x))
+        return;
+    wave_prologue(hg, smem, lane);
+    const int yy = lane >> 3, zz = lane & 7;
+    const TIN* __restrict__ vol = vol0;
+    TIN* __restrict__ img = img0;
+
+    RowWalk rw;
+    rw.oz = sp.tz * kT + zz;
+    rw.oy = sp.ty * kT + yy;
+    rw.vzy = rw.oz < hg.out_len[0] && rw.oy < hg.out_len[1];
+    rw.qrow = qtab + ((long long)min(rw.oz, hg.out_len[0] - 1) * hg.out_len[1] + min(rw.oy, hg.out_len[1] - 1)) * (4 * hg.ncpx);
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+        rw.Pzy[h] = AFFINE ? fma(hp->affine[h * 4 + 0], (double)rw.oz,
+                                 fma(hp->affine[h * 4 + 1], (double)rw.oy, hp->affine[h * 4 + 3] + hp->offd[h]))
+                           : 0.0;
+    const int obase = rw.oz * hg.img_sz + rw.oy * hg.img_sy;
+    const int vox_row = (rw.oz * hg.out_len[1] + rw.oy) * hg.out_len[2];
+    QCols qc;
+    {
+        XEntry xe;
+        xentry_load(xt, min(sp.tx0 * kT, hg.out_len[2] - 1), xe);
+        qcols_load(qc, rw.qrow, xe.idx);
+    }
+    const int last = hg.out_len[2] - 1;
+    const TIN cst_value = int_store_value<TIN>(hg.cvald);
+
+    for (int ti = 0; ti < sp.ntile; ++ti) {
+        const int ox_tile = (sp.tx0 + ti) * kT;
+        // whole tile; two halves along x if its box does not fit; taps straight from global memory if
+        // the halves do not fit either (mode 2)
+        int nsub = 1, nx = kT;
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int ox0 = ox_tile + sub * nx;
+            int lo[3], hi[3];
+            row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox0, nx, lo, hi);
+            BoxLayout bl;
+            fwd_layout<ORDER>(lo, hi, hg.box_cap, nsub == 2, bl);
+            bool direct = false;
+            if (bl.any && !bl.fits) {
+                if (nsub == 1) {
+                    nsub = 2;
+                    nx = kT / 2;
+                    sub = -1;
+                    continue;
+                }
+                direct = true;
+            }
+            const int ps = bl.ps, pitch = bl.pitch;
+            for (long long ss = 0; ss < hg.nsteps; ++ss) {
+                long long vol_off = 0, img_off = 0;
+                if (hg.nstep)
+                    wave_step_offsets(hp, ss, vol_off, img_off);
+                const TIN* __restrict__ src = vol + vol_off;
+                if (bl.any && !direct) {
+                    // stage the box as float32, every index through the mirror map (deform.c:791-813)
+                    const int sx = lane & 15;
+                    const int nrows = bl.ext[0] * bl.ext[1];
+                    const float inv_by = 1.0f / (float)bl.ext[1];
+                    const bool interior = bl.b0[0] >= 0 && bl.b0[0] + bl.ext[0] <= hg.in_len[0] && bl.b0[1] >= 0 &&
+                                          bl.b0[1] + bl.ext[1] <= hg.in_len[1] && bl.b0[2] >= 0 &&
+                                          bl.b0[2] + bl.ext[2] <= hg.in_len[2];
+                    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): the previous gather's reads
+                    if (interior) {
+                        // four rows per wave instruction, 16 lanes along x; all loads of the box in flight
+                        const TIN* p0 = src + ((bl.b0[0] * hg.vol_sz + bl.b0[1] * hg.vol_sy) + bl.b0[2] + sx);
+#pragma unroll 4
+                        for (int r = lane >> 4; r < nrows; r += 4) {
+                            const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * bl.ext[1];
+                            if (sx < bl.ext[2])
+                                box[zr * ps + yr * pitch + sx] = (float)p0[zr * hg.vol_sz + yr * hg.vol_sy];
+                        }
+                    } else {
+                        const int xs = mirror_i32(bl.b0[2] + min(sx, bl.ext[2] - 1), hg.in_len[2]);
+                        for (int r = lane >> 4; r < nrows; r += 4) {
+                            const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * bl.ext[1];
+                            const int zs = mirror_i32(bl.b0[0] + zr, hg.in_len[0]);
+                            const int ys = mirror_i32(bl.b0[1] + yr, hg.in_len[1]);
+                            if (sx < bl.ext[2])
+                                box[zr * ps + yr * pitch + sx] = (float)src[zs * hg.vol_sz + ys * hg.vol_sy + xs];
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    asm volatile("" ::: "memory");
+                }
+                TIN* op = img + (img_off + obase);
+                // the lane's voxels of this (sub-)tile are packed and stored together: 8 or 16 contiguous
+                // bytes per lane instead of one 1- / 2-byte store per voxel
+                unsigned long long pk0 = 0, pk1 = 0;
+                constexpr int kBits = 8 * (int)sizeof(TIN);
+                constexpr int kPer64 = 64 / kBits;             // voxels per 64-bit word: 8 or 4
+                XEntry xe;
+                xentry_load(xt, min(ox0, last), xe);
+#pragma unroll 1
+                for (int k = 0; k < nx; ++k) {
+                    const int ox = ox0 + k;
+                    int st[3];
+                    double fr[3];
+                    bool near;
+                    XEntry xn;
+                    xentry_load(xt, min(ox + 1, last), xn);
+                    const int b[3] = {rw.oz + hg.off[0], rw.oy + hg.off[1], ox + hg.off[2]};
+                    double P[3] = {0.0, 0.0, 0.0};
+                    if (xe.idx[0] != qc.idx[0] || xe.idx[1] != qc.idx[1] || xe.idx[2] != qc.idx[2] ||
+                        xe.idx[3] != qc.idx[3])
+                        qcols_load(qc, rw.qrow, xe.idx);
+                    if (AFFINE) {
+#pragma unroll
+                        for (int h = 0; h < 3; ++h)
+                            P[h] = fma(hp->affine[h * 4 + 2], (double)ox, rw.Pzy[h]);
+                    }
+                    const bool cst = int_coords<ORDER, AFFINE>(hg, hp, qc, xe.w, b, P, st, fr, near);
+                    xe = xn;
+                    const bool inside = rw.vzy && ox <= last;
+                    const bool live = inside && !cst;
+                    double w0[NT], w1[NT], w2[NT];
+                    weights_from_frac<double, ORDER>(fr[0], w0);
+                    weights_from_frac<double, ORDER>(fr[1], w1);
+                    weights_from_frac<double, ORDER>(fr[2], w2);
+                    double t = 0.0;
+                    if (direct) {
+                        if (live) {
+                            // taps straight from global memory, mirror-mapped (rolled: rare)
+#pragma unroll 1
+                            for (int l0 = 0; l0 < NT; ++l0) {
+                                const int zs = mirror_i32(st[0] + l0, hg.in_len[0]);
+                                double a1 = 0.0;
+#pragma unroll 1
+                                for (int l1 = 0; l1 < NT; ++l1) {
+                                    const int ys = mirror_i32(st[1] + l1, hg.in_len[1]);
+                                    double a2 = 0.0;
+#pragma unroll
+                                    for (int l2 = 0; l2 < NT; ++l2)
+                                        a2 = fma(w2[l2], (double)src[zs * hg.vol_sz + ys * hg.vol_sy +
+                                                                     mirror_i32(st[2] + l2, hg.in_len[2])], a2);
+                                    double wy = w1[0];
+#pragma unroll
+                                    for (int l = 1; l < NT; ++l)
+                                        wy = l1 == l ? w1[l] : wy;
+                                    a1 = fma(wy, a2, a1);
+                                }
+                                double wz = w0[0];
+#pragma unroll
+                                for (int l = 1; l < NT; ++l)
+                                    wz = l0 == l ? w0[l] : wz;
+                                t = fma(wz, a1, t);
+                            }
+                        }
+                    } else if (bl.any) {
+                        const int rz = live ? st[0] - bl.b0[0] : 0, ry = live ? st[1] - bl.b0[1] : 0,
+                                  rx = live ? st[2] - bl.b0[2] : 0;
+                        const float* bp = box + (rz * ps + ry * pitch + (rx & ~1));
+                        t = pitch == 16 ? int_gather<ORDER, 16>(bp, ps, rx & 1, w0, w1, w2)
+                                        : int_gather<ORDER, 12>(bp, ps, rx & 1, w0, w1, w2);
+                    }
+                    // value within the band of a rounding tie (x.5), or not a number: exact kernel
+                    const double at = fabs(t);
+                    const double ft = at - floor(at);
+                    const bool tie = live && (!(fabs(ft - 0.5) >= kIntTieBand) || !(t == t));
+                    if (inside) {
+                        if ((near || tie) && hg.tie_list) {
+                            const int slot = atomicAdd(&hg.tie_list[0], 1);
+                            if (slot < hg.tie_cap)
+                                hg.tie_list[1 + slot] = vox_row + ox;
+                        }
+                    }
+                    {
+                        typedef typename std::make_unsigned<TIN>::type UT;
+                        const unsigned long long bits = (unsigned long long)(UT)(live ? int_store_value<TIN>(t) : cst_value);
+                        if (k < kPer64)        // (k is wave-uniform)
+                            pk0 |= bits << (kBits * k);
+                        else
+                            pk1 |= bits << (kBits * (k - kPer64));
+                    }
+                }
+                if (rw.vzy) {
+                    TIN* o = op + ox0;
+                    const int nbytes = nx * (int)sizeof(TIN);          // 4, 8 or 16
+                    const bool whole = ox0 + nx - 1 <= last && (((size_t)o) & (nbytes >= 8 ? 7 : 3)) == 0;
+                    if (whole) {
+                        if (nbytes == 4)
+                            __builtin_nontemporal_store((unsigned)pk0, reinterpret_cast<unsigned*>(o));
+                        else
+                            __builtin_nontemporal_store(pk0, reinterpret_cast<unsigned long long*>(o));
+                        if (nbytes == 16)
+                            __builtin_nontemporal_store(pk1, reinterpret_cast<unsigned long long*>(o) + 1);
+                    } else {
+                        for (int k = 0; k < nx; ++k)
+                            if (ox0 + k <= last)
+                                o[k] = (TIN)((k < kPer64 ? pk0 >> (kBits * k) : pk1 >> (kBits * (k - kPer64))));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int ORDER, typename TIN>
+hipError_t launch_wave_int_t(const HotGeom& hg, const void* vol, void* img, unsigned nblk, size_t lds, hipStream_t stream)
+{
+    if (hg.has_affine)
+        hipLaunchKernelGGL((wave_int_fwd_kernel<ORDER, true, TIN>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+                           (const TIN*)vol, (TIN*)img);
+    else
+        hipLaunchKernelGGL((wave_int_fwd_kernel<ORDER, false, TIN>), dim3(nblk), dim3(64), lds, stream, hg, hg.xt, hg.q,
+                           (const TIN*)vol, (TIN*)img);
+    return hipGetLastError();
+}
+template <int ORDER>
+hipError_t launch_wave_int_o(const HotGeom& hg, int dtype, const void* vol, void* img, unsigned nblk, size_t lds,
+                             hipStream_t stream)
+{
+    switch (dtype) {
+    case EDHIP_U8: return launch_wave_int_t<ORDER, uint8_t>(hg, vol, img, nblk, lds, stream);
+    case EDHIP_I8: return launch_wave_int_t<ORDER, int8_t>(hg, vol, img, nblk, lds, stream);
+    case EDHIP_U16: return launch_wave_int_t<ORDER, uint16_t>(hg, vol, img, nblk, lds, stream);
+    case EDHIP_I16: return launch_wave_int_t<ORDER, int16_t>(hg, vol, img, nblk, lds, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
 // bytes of LDS per wave (one workgroup = one wave): 160 KiB / 12 resp. / 16 in the hardware's
 // allocation granule
 constexpr int kWaveLdsBytes3 = 12800, kWaveLdsBytes4 = 10240;
@@ -948,6 +1315,19 @@ size_t wave_lds_bytes(bool gradient, int occ, int* box_cap)
     const int bytes = occ == 4 ? kWaveLdsBytes4 : kWaveLdsBytes3;
     *box_cap = (bytes - kWaveHead) / 4;
     return bytes;
+}
+
+hipError_t launch_wave_int(const HotGeom& hg, int order, int dtype, const void* vol, void* img, unsigned nblk,
+                           size_t lds, hipStream_t stream)
+{
+    switch (order) {
+    case 1: return launch_wave_int_o<1>(hg, dtype, vol, img, nblk, lds, stream);
+    case 2: return launch_wave_int_o<2>(hg, dtype, vol, img, nblk, lds, stream);
+    case 3: return launch_wave_int_o<3>(hg, dtype, vol, img, nblk, lds, stream);
+    case 4: return launch_wave_int_o<4>(hg, dtype, vol, img, nblk, lds, stream);
+    case 5: return launch_wave_int_o<5>(hg, dtype, vol, img, nblk, lds, stream);
+    default: return hipErrorNotSupported;
+    }
 }
 
 hipError_t launch_wave_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds, int occ,

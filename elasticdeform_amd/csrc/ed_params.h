@@ -47,6 +47,10 @@ struct IOView {
 // launchers (defined in the .hip files, called from edhip_api.cpp); all enqueue on `stream` and
 // return the hipError_t of the launch.
 hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream);
+// forward, 3 deformed axes, only the output voxels of a device-side list ([0] = count, [1 .. cap] =
+// linear voxel ids; count > cap: every voxel): the near-tie voxels of the integer fast path
+hipError_t launch_deform_exact_list(const GridGeom& g, const IOView& v, const int* list, int cap,
+                                    hipStream_t stream);
 
 // edhip_source_box: box[2h] = floor(min), box[2h+1] = ceil(max) of the raw (unmapped) source
 // coordinate along axis h over every output voxel; `box` = 2 * naxis device ints
@@ -77,6 +81,10 @@ size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch = 1);   // scra
 // kernel (fast coordinates, exact re-evaluation of near-tie voxels), see deform_tile.hip
 hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream);
 bool deform_label_supported(const GridGeom& g, const IOView& v, int gradient);
+// 8- / 16-bit integer volumes with spline orders 1-5 (forward): bit-equal to the exact kernel (fast
+// coordinates and fp64 taps; voxels near a rounding tie or a coordinate boundary re-evaluated exactly)
+hipError_t launch_deform_int(const GridGeom& g, const IOView& v, hipStream_t stream);
+bool deform_int_supported(const GridGeom& g, const IOView& v, int gradient);
 void tile_profile_enable(int enable);                    // edhip_profile_dominant
 double tile_profile_last_us();                           // edhip_profile_last_us
 

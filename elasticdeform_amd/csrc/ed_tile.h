@@ -369,6 +369,11 @@ struct HotGeom {
     int* boxes;
     int use_boxes;
     unsigned long long* dbgbuf;   // EDHIP_EXPERIMENTS builds: per-workgroup timestamps (else unused)
+    // integer fast path (wave_int_fwd_kernel): near-tie voxels for the exact re-evaluation,
+    // [0] = count, [1 .. tie_cap] = linear output voxel ids; the constant of 'constant' mode in fp64
+    int* tie_list;
+    int tie_cap;
+    double cvald;
     int dbg;                  // experiment switches (EDHIP_TILE_DBG), 0 in production
     float cval;
     int nstep;
@@ -388,6 +393,10 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box);
 hipError_t launch_wave_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds, int occ,
                               hipStream_t stream);
 size_t wave_lds_bytes(bool gradient, int occ, int* box_cap);
+// integer volumes (8- / 16-bit), orders 1-5, forward: fast coordinates, fp64 taps, near-tie voxels listed
+// for the exact kernel; `dtype` is the edhip_dtype of input and output
+hipError_t launch_wave_int(const HotGeom& hg, int order, int dtype, const void* vol, void* img, unsigned nblk,
+                           size_t lds, hipStream_t stream);
 
 }  // namespace tile
 }  // namespace ed

@@ -306,9 +306,13 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         // order-0 label maps of any dtype: bit-equal to the exact kernels, so AUTO takes it too
         const bool use_label = !(flags & EDHIP_FLAG_EXACT) && !use_fast && in.dtype != EDHIP_F32 &&
                                in.dtype != EDHIP_F64 && deform_label_supported(g, v, gradient);
+        // 8- / 16-bit integer volumes, orders 1-5: bit-equal as well (near-tie voxels redone exactly)
+        const bool use_int = !(flags & EDHIP_FLAG_EXACT) && !use_fast && !use_label && deform_int_supported(g, v, gradient);
         hipError_t e;
         if (use_label)
             e = launch_deform_label(g, v, stream);
+        else if (use_int)
+            e = launch_deform_int(g, v, stream);
         else if (!use_fast)
             e = launch_deform_exact(g, v, gradient != 0, stream);
         else if (deform_tile_supported(g, v, gradient != 0)) {

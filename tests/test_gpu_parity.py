@@ -1043,3 +1043,49 @@ def test_gradient_with_a_wide_dynamic_range_inside_a_tile():
     unit = 0.2963 * 1.001 * float(np.abs(dY[16:24, 16:24, 16:32]).sum()) / 2147482624.0
     near = ~far & (np.abs(truth) < 1.0)
     assert float(np.abs(got[near] - truth[near]).max()) <= 128 * 0.5 * unit + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.uint16, np.int16])
+def test_integer_fast_path_is_bit_equal(dtype):
+    """8- / 16-bit integer volumes, spline orders 1-5: fast coordinates + fp64 taps on
+    the wave-per-tile kernel, voxels near a rounding tie or a coordinate boundary redone by the exact
+    kernel -- bit-equal to the reference's arithmetic (the oracle) in every mode, with a crop, an
+    affine map, a channel axis, strong deformations (tiles split in halves / taken from global memory)
+    and a non-integer cval."""
+    rng = np.random.default_rng(abs(hash(np.dtype(dtype).name)) % 2**32)
+    info = np.iinfo(dtype)
+    cases = [
+        dict(shape=(40, 44, 70), pts=(3, 3, 3), sigma=2.0, kw=dict(mode="mirror")),
+        dict(shape=(33, 41, 37), pts=(3, 4, 3), sigma=3.0, kw=dict(mode="constant", cval=3.7)),
+        dict(shape=(48, 40, 72), pts=(2, 3, 3), sigma=14.0, kw=dict(mode="wrap")),
+        dict(shape=(36, 40, 50), pts=(3, 3, 3), sigma=30.0, kw=dict(mode="nearest")),
+        dict(shape=(2, 36, 40, 50), pts=(3, 3, 3), sigma=3.0,
+             kw=dict(mode="reflect", axis=(1, 2, 3), crop=(slice(3, 30), slice(0, 33), slice(7, 47)))),
+        dict(shape=(33, 35, 37), pts=(3, 4, 3), sigma=3.0,
+             kw=dict(mode="constant", cval=-1.5, affine=np.eye(3, 4) + 0.03 * rng.standard_normal((3, 4)))),
+    ]
+    for c in cases:
+        lo, hi = max(info.min, -30000), min(info.max, 30000)
+        X = rng.integers(lo, hi, c["shape"], endpoint=True).astype(dtype)
+        disp = rng.standard_normal((3,) + c["pts"]) * c["sigma"]
+        for order in (1, 2, 3, 4, 5):
+            kw = dict(c["kw"], order=order)
+            want = orc.deform_grid(X, disp, **kw)
+            got = ed.deform_grid(torch.from_numpy(X).cuda(), torch.from_numpy(disp).cuda(), **kw).cpu().numpy()
+            assert got.dtype == want.dtype
+            np.testing.assert_array_equal(got, want, err_msg=str((c["shape"], kw)))
+
+
+def test_integer_fast_path_with_every_voxel_on_a_rounding_tie():
+    """Adversarial input for the tie list: a ramp sampled exactly half-way between voxels gives x.5 at
+    every voxel (order 1), so every voxel is listed, the list overflows and every voxel is redone by
+    the exact kernel -- still bit-equal."""
+    n = 72
+    X = (np.arange(n, dtype=np.int16)[None, None, :] * np.ones((72, 72, 1), np.int16)).copy()
+    disp = np.zeros((3, 2, 2, 2))
+    disp[2] = 0.5                                   # a shift of exactly half a voxel along x
+    for mode in ("nearest", "mirror", "constant"):
+        kw = dict(order=1, mode=mode, prefilter=False)
+        want = orc.deform_grid(X, disp, **kw)
+        got = ed.deform_grid(torch.from_numpy(X).cuda(), torch.from_numpy(disp).cuda(), **kw).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
