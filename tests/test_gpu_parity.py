@@ -1080,8 +1080,8 @@ def test_integer_fast_path_with_every_voxel_on_a_rounding_tie():
     """Adversarial input for the tie list: a ramp sampled exactly half-way between voxels gives x.5 at
     every voxel (order 1), so every voxel is listed, the list overflows and every voxel is redone by
     the exact kernel -- still bit-equal."""
-    n = 72
-    X = (np.arange(n, dtype=np.int16)[None, None, :] * np.ones((72, 72, 1), np.int16)).copy()
+    n = 128          # 2 M voxels: more than the list holds (1 M), so the overflow path runs
+    X = (np.arange(n, dtype=np.int16)[None, None, :] * np.ones((n, n, 1), np.int16)).copy()
     disp = np.zeros((3, 2, 2, 2))
     disp[2] = 0.5                                   # a shift of exactly half a voxel along x
     for mode in ("nearest", "mirror", "constant"):
