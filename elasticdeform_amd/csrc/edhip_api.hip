@@ -187,7 +187,7 @@ extern "C" {
 
 #ifdef EDHIP_EXPERIMENTS
 // marks a profiling build (make EXPERIMENTS=1): environment switches are live in it
-const int edhip_experiments_build = 1;
+int edhip_experiments_build = 1;
 #endif
 
 int edhip_version(void) { return EDHIP_VERSION; }
