@@ -1477,12 +1477,21 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     TileGeom t2 = tg;
     t2.worklist = list_a;
     t2.spill = list_b;
-    size_t box2 = 48 * 1024;
+    // (float32 up to order 3: 32 KiB boxes hold nearly every tile level 1 gives up on, and three
+    // workgroups per CU instead of two serve them a third faster -- 256^3 sigma 10: forward call
+    // 404 -> 368 us, gradient call 532 -> 502 us; smaller boxes send tiles to the direct level, which is
+    // far slower for gradients: profiles/r03_bench_misc.txt)
+    size_t box2 = (sizeof(T) == 4 && ORDER <= 3) ? 32 * 1024 : 48 * 1024;
+    unsigned wgs2 = (sizeof(T) == 4 && ORDER <= 3) ? 768 : 512;
+    if (const char* kb = ed_env("EDHIP_L2_BOX_KB"))        // experiment: smaller boxes, more workgroups per CU
+        box2 = (size_t)atoi(kb) * 1024;
+    if (const char* w = ed_env("EDHIP_L2_WGS"))
+        wgs2 = (unsigned)atoi(w);
     if (t2.off_ov + box2 > 64 * 1024)
         box2 = (64 * 1024 - t2.off_ov) & ~(size_t)63;
     t2.box_cap = (int)((box2 - (GRAD ? 64 : 0)) / sizeof(T));      // gradient: cells of sizeof(T) + wave sums
     const size_t lds2 = t2.off_ov + box2;
-    const unsigned n2 = (unsigned)(ntiles * nb < 512 ? ntiles * nb : 512);
+    const unsigned n2 = (unsigned)(ntiles * nb < wgs2 ? ntiles * nb : wgs2);
     const bool skip_l2 = ed_env("EDHIP_SKIP_L2") != nullptr;      // debugging aid
     if (e == hipSuccess && !skip_l2) {
         if (GRAD)
