@@ -1143,9 +1143,11 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         ve.out_step_stride[l] = v.out_step_stride[l] / (int64_t)sizeof(T);
     }
     // strips of 8 tiles amortise the prologue; small outputs (crops) take shorter strips so that the
-    // launch still has a few workgroups per CU (even lengths: the gradient kernel walks 16-wide tiles)
+    // launch still has a few workgroups per CU (even lengths for the gradient: its kernel walks 16-wide
+    // tiles; the forward kernels go down to one tile per workgroup -- a tile is a serial chain of
+    // coordinates, box reduction, staging and gather, ~8 us, and a 32^3 volume has 64 of them)
     tg.strip_tiles = kStrip;
-    while (tg.strip_tiles > 2 &&
+    while (tg.strip_tiles > (GRAD ? 2 : 1) &&
            (int64_t)nb * tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles) < 1024)
         tg.strip_tiles >>= 1;
     tg.strips_x = (tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles;

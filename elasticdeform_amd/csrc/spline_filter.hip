@@ -217,6 +217,128 @@ __device__ __forceinline__ void forward_line_tile(double* ws, const int n, const
     }
 }
 
+// transpose_line for a line in an LDS tile, blocked like forward_line_tile (same operations, same order)
+__device__ __forceinline__ void transpose_line_tile(double* ws, const int len, const FilterParams& p)
+{
+    constexpr int W = kTilePitch;
+    for (int h = 0; h < p.npoles; ++h) {
+        const double q = p.pole[h];
+        const bool last = h == p.npoles - 1;
+        const double x0 = ws[0];
+        double sum = q * x0;
+        double prev = -q * x0;
+        ws[0] = prev;
+        int ll = 1;
+        for (; ll + kBlk <= len - 1; ll += kBlk) {
+            double a[kBlk];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k)
+                a[k] = ws[(ll + k) * W];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k) {
+                const double x = a[k];
+                sum = q * (sum + x);
+                prev = q * (prev - x);
+                a[k] = prev;
+            }
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k)
+                ws[(ll + k) * W] = a[k];
+        }
+        for (; ll < len - 1; ++ll) {
+            const double x = ws[ll * W];
+            sum = q * (sum + x);
+            prev = q * (prev - x);
+            ws[ll * W] = prev;
+        }
+        sum = (q / (q * q - 1.0)) * (sum + ws[(len - 1) * W]);
+        const double up = ws[(len - 2) * W] + q * sum;
+        ws[(len - 1) * W] = sum;
+        double next = up + q * sum;
+        ws[(len - 2) * W] = next;
+        ll = len - 3;
+        for (; ll - kBlk + 1 >= 0; ll -= kBlk) {
+            double a[kBlk];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k)
+                a[k] = ws[(ll - k) * W];
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k) {
+                const double cur = a[k] + q * next;
+                a[k] = cur;
+                next = cur;
+            }
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k)
+                ws[(ll - k) * W] = a[k];
+        }
+        for (; ll >= 0; --ll) {
+            const double cur = ws[ll * W] + q * next;
+            ws[ll * W] = cur;
+            next = cur;
+        }
+        const double g = p.gain;
+        if (p.trunc_branch[h]) {
+            const double l0 = next;
+            double zn = q;
+            ws[0] = last ? l0 * g : l0;
+            ll = 1;
+            for (; ll + kBlk <= len; ll += kBlk) {
+                double a[kBlk];
+#pragma unroll
+                for (int k = 0; k < kBlk; ++k)
+                    a[k] = ws[(ll + k) * W];
+#pragma unroll
+                for (int k = 0; k < kBlk; ++k) {
+                    const double c = a[k] + zn * l0;
+                    a[k] = last ? c * g : c;
+                    zn *= q;
+                }
+#pragma unroll
+                for (int k = 0; k < kBlk; ++k)
+                    ws[(ll + k) * W] = a[k];
+            }
+            for (; ll < len; ++ll) {
+                const double c = ws[ll * W] + zn * l0;
+                ws[ll * W] = last ? c * g : c;
+                zn *= q;
+            }
+        } else {
+            double zn = q;
+            const double iz = 1.0 / q;
+            double z2n = p.pole_pow[h];
+            const double l0 = next / (1.0 - z2n * z2n);
+            const double tail = ws[(len - 1) * W] + z2n * l0;
+            z2n *= z2n * iz;
+            ws[0] = last ? l0 * g : l0;
+            ws[(len - 1) * W] = last ? tail * g : tail;
+            ll = 1;
+            for (; ll + kBlk <= len - 1; ll += kBlk) {
+                double a[kBlk];
+#pragma unroll
+                for (int k = 0; k < kBlk; ++k)
+                    a[k] = ws[(ll + k) * W];
+#pragma unroll
+                for (int k = 0; k < kBlk; ++k) {
+                    const double c = a[k] + (zn + z2n) * l0;
+                    a[k] = last ? c * g : c;
+                    zn *= q;
+                    z2n *= iz;
+                }
+#pragma unroll
+                for (int k = 0; k < kBlk; ++k)
+                    ws[(ll + k) * W] = a[k];
+            }
+            for (; ll <= len - 2; ++ll) {
+                const double c = ws[ll * W] + (zn + z2n) * l0;
+                ws[ll * W] = last ? c * g : c;
+                zn *= q;
+                z2n *= iz;
+            }
+        }
+    }
+}
+
 // One thread per line; LDSWS: the fp64 working copy of the block's lines sits in LDS ([len][blockDim]
 // doubles, line-interleaved) instead of the global scratch buffer: short lines (small volumes)
 // otherwise pay a dependent global round trip per sample -- 28 us per pass for a 32^3 volume, more
@@ -318,7 +440,7 @@ __global__ __launch_bounds__(256) void prefilter_line_tile_kernel(const FilterPa
     __syncthreads();
     if (tid < nl) {
         if (TRANSPOSE)
-            transpose_line(lws + tid, kTilePitch, n, p);
+            transpose_line_tile(lws + tid, n, p);
         else
             forward_line_tile(lws + tid, n, p);
     }
@@ -421,26 +543,12 @@ hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
 {
     if (p.nlines <= 0 || p.len <= 0)
         return hipSuccess;
-    // lines of up to 128 samples: working copy in LDS (64 KiB: 256 threads x 32 samples ... 64 x 128),
-    // all lines in one launch, the global scratch buffer is not touched
     static const bool no_ldsws = ed_env("EDHIP_FILTER_NO_LDSWS") != nullptr;      // A/B switch
-    if (p.len <= 128 && !no_ldsws) {
-        const int blk = p.len <= 32 ? 256 : (p.len <= 64 ? 128 : 64);
-        const size_t lds = (size_t)p.len * blk * sizeof(double);
-        const int64_t nblk = (p.nlines + blk - 1) / blk;
-        if (nblk <= 0x7fffffffLL) {
-            const dim3 grid((unsigned)nblk);
-            if (p.transpose)
-                hipLaunchKernelGGL((prefilter_kernel<true, true>), grid, dim3(blk), lds, stream, p,
-                                   (int64_t)0, p.nlines);
-            else
-                hipLaunchKernelGGL((prefilter_kernel<true, false>), grid, dim3(blk), lds, stream, p, (int64_t)0,
-                                   p.nlines);
-            return hipGetLastError();
-        }
-    }
-    // 129 .. 313 samples (the lines of a 256^3 volume): tiles of 64 lines in LDS
-    if (p.len <= 313 && p.len >= 2 && p.npoles > 0 && !no_ldsws && dtype_size(p.in_dtype) > 0 &&
+    static const bool no_short_tile = ed_env("EDHIP_FILTER_NO_SHORT_TILE") != nullptr;
+    // 2 .. 313 samples (up to the lines of a 256^3 volume): tiles of 64 lines in LDS, moved by the whole
+    // workgroup.  (Short lines used to go to the one-thread-per-line kernel below: 21 us per pass for a
+    // 32^3 volume, its 32 dependent global loads per thread; the tile kernel takes 5.)
+    if (p.len <= 313 && p.len >= 2 && p.npoles > 0 && !no_ldsws && (p.len > 128 || !no_short_tile) && dtype_size(p.in_dtype) > 0 &&
         dtype_size(p.out_dtype) > 0) {
         const size_t lds = (size_t)p.len * kTilePitch * sizeof(double) + 2 * kTileLines * sizeof(int64_t);
         const int64_t nblk = (p.nlines + kTileLines - 1) / kTileLines;
@@ -467,6 +575,23 @@ hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
                 hipLaunchKernelGGL(prefilter_line_tile_kernel<true>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
             else
                 hipLaunchKernelGGL(prefilter_line_tile_kernel<false>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
+            return hipGetLastError();
+        }
+    }
+    // what is left with lines of up to 128 samples: one thread per line, working copy in LDS (64 KiB:
+    // 256 threads x 32 samples ... 64 x 128), the global scratch buffer is not touched
+    if (p.len <= 128 && !no_ldsws) {
+        const int blk = p.len <= 32 ? 256 : (p.len <= 64 ? 128 : 64);
+        const size_t lds = (size_t)p.len * blk * sizeof(double);
+        const int64_t nblk = (p.nlines + blk - 1) / blk;
+        if (nblk <= 0x7fffffffLL) {
+            const dim3 grid((unsigned)nblk);
+            if (p.transpose)
+                hipLaunchKernelGGL((prefilter_kernel<true, true>), grid, dim3(blk), lds, stream, p,
+                                   (int64_t)0, p.nlines);
+            else
+                hipLaunchKernelGGL((prefilter_kernel<true, false>), grid, dim3(blk), lds, stream, p, (int64_t)0,
+                                   p.nlines);
             return hipGetLastError();
         }
     }

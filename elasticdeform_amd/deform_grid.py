@@ -22,11 +22,15 @@ deform.c:643, and yields inf / NaN coordinates that map to cval).
 There is no CPU fallback: without a GPU or without the built library the call raises.
 """
 import os
+import sys
 
 import numpy
 
+from . import _fastlane
 from . import _host
 from . import _lib
+
+_this = sys.modules[__name__]
 
 _ARITHMETIC = {'auto': _lib.FLAG_AUTO, 'exact': _lib.FLAG_EXACT, 'fast': _lib.FLAG_FAST}
 _flags = _ARITHMETIC.get(os.environ.get('EDHIP_ARITHMETIC', 'auto').lower(), _lib.FLAG_AUTO)
@@ -237,7 +241,7 @@ def _filter_axes(x, axes, order, transpose, device, overwrite=False, stream=None
     # Lines that fit the whole-line tile kernels are filtered in place from the second pass on
     # (like the reference; one temporary instead of two keeps the step's working set smaller);
     # longer lines ping-pong, because in place the block-recompute kernels cannot split a line.
-    inplace = all(int(x.shape[d]) <= 256 for d in axes) and not os.environ.get('EDHIP_FILTER_PINGPONG')
+    inplace = all(int(x.shape[d]) <= 256 for d in axes)
     if overwrite and inplace:
         bufs = [x, None]            # x is the caller's own temporary (dX): every pass in place
     else:
@@ -268,7 +272,7 @@ def _crop_windows(plan, shapes, dtypes, disp_desc, dflag, crop, prefilter, devic
     ones to below fp64 rounding, not bit for bit."""
     n = len(shapes)
     wins = [None] * n
-    if crop is None or not prefilter or (_flags & _lib.FLAG_EXACT) or os.environ.get('EDHIP_NO_CROP_WINDOW'):
+    if crop is None or not prefilter or (_flags & _lib.FLAG_EXACT):
         return wins
     todo = [i for i in range(n) if plan.order[i] > 1 and dtypes[i] in ('float32', 'float64')]
     if not todo:
@@ -337,6 +341,32 @@ def _prefilter_displacement(displacement, device):
     return _filter_axes(displacement, range(1, displacement.ndim), 3, False, device), 0
 
 
+def _lane_lookup(gradient, X, displacement, order, mode, cval, crop, prefilter, axis, X_shape,
+                 affine, rotate, zoom):
+    """(signature, lane) of a repeat call on device tensors (_fastlane.py); (None, None) for every
+    call the lane does not serve; (sig, None) for a signature seen for the first time."""
+    if _reduced or affine is not None or rotate is not None or zoom is not None or not _fastlane.enabled:
+        return None, None
+    sig = _fastlane.signature(gradient, X, displacement, order, mode, cval, crop, prefilter, axis,
+                              X_shape, _flags)
+    if sig is None:
+        return None, None
+    lane = _fastlane.lookup(sig)
+    if lane is None:
+        return sig, None
+    if lane is False or lane.max_saving >= CROP_WINDOW_MIN_SAVING:
+        return None, None
+    return sig, lane
+
+
+def _lane_build(sig, gradient, xs, dd, plan, prefilter, X_shape, crop):
+    """After the general path has served `sig` once: prepare the repeat-call lane for it."""
+    if dd.ndim < 2 or dd.numel() > _lib.RAW_DISPLACEMENT_MAX_POINTS:
+        _fastlane.remember(sig, False)
+        return
+    _fastlane.remember(sig, _fastlane.Lane(_this, gradient, xs, dd, plan, prefilter, X_shape, _flags, crop))
+
+
 def deform_random_grid(X, sigma=25, points=3, order=3, mode='constant', cval=0.0,
                        crop=None, prefilter=True, axis=None,
                        affine=None, rotate=None, zoom=None):
@@ -365,6 +395,10 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
     (naxis x naxis+1), rotate / zoom (2-D only) -- all with the reference's meaning, and order /
     mode / cval / axis may be per-input lists.  Returns the deformed array, or a list for a list.
     """
+    sig, lane = _lane_lookup(False, X, displacement, order, mode, cval, crop, prefilter, axis, None,
+                             affine, rotate, zoom)
+    if lane is not None:
+        return lane.run(_this, X, X if type(X) is list else (X,), displacement)
     Xs = _host.normalize_inputs(X)
     plan = _host.cached_plan(Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
 
@@ -409,6 +443,8 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
                     plan.inverse_affine, _flags | dflag | bflag, stream, prepared=_prepared(plan, len(Xd)))
         outs = [_narrow(o, xs) if w is not None else o for o, xs, w in zip(outs, Xs_dev, wide)]
         res = [_from_device(o, x) for o, x in zip(outs, Xs)]
+        if sig is not None:
+            _lane_build(sig, False, Xs_dev, dd, plan, prefilter, None, crop)
     return res if isinstance(X, list) else res[0]
 
 
@@ -420,6 +456,10 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
     adjoint, interpolation and prefilter included.  ``X_shape`` (tuple, or list of tuples) is
     required when ``crop`` is used.
     """
+    sig, lane = _lane_lookup(True, dY, displacement, order, mode, cval, crop, prefilter, axis, X_shape,
+                             affine, rotate, zoom)
+    if lane is not None:
+        return lane.run(_this, dY, dY if type(dY) is list else (dY,), displacement)
     dYs = _host.normalize_inputs(dY)
 
     if isinstance(X_shape, tuple):
@@ -476,6 +516,8 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
                 dXf.append(x)
         dXf = [_narrow(x, dy) if w is not None else x for x, dy, w in zip(dXf, dY_dev, wide)]
         res = [_from_device(x, dy) for x, dy in zip(dXf, dYs)]
+        if sig is not None:
+            _lane_build(sig, True, dY_dev, dd, plan, prefilter, X_shape, crop)
     return res if isinstance(dY, list) else res[0]
 
 

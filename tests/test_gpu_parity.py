@@ -1089,3 +1089,141 @@ def test_integer_fast_path_with_every_voxel_on_a_rounding_tie():
         want = orc.deform_grid(X, disp, **kw)
         got = ed.deform_grid(torch.from_numpy(X).cuda(), torch.from_numpy(disp).cuda(), **kw).cpu().numpy()
         np.testing.assert_array_equal(got, want)
+
+
+# ---- repeat-call lane (elasticdeform_amd/_fastlane.py) -------------------------------------------
+
+def _lane_cases():
+    rng = np.random.default_rng(77)
+    d3 = rng.standard_normal((3, 4, 4, 4)) * 2.0
+    d2 = rng.standard_normal((2, 3, 3)) * 12.0
+    return [
+        dict(name="3d", X=rng.random((32, 32, 32), dtype=np.float32), d=d3, kw=dict(order=3, mode="mirror")),
+        dict(name="3d crop", X=rng.random((40, 36, 33), dtype=np.float32), d=d3,
+             kw=dict(order=3, mode="constant", cval=0.25, crop=(slice(4, 30), slice(0, 36), slice(5, 25)))),
+        dict(name="2d long lines", X=rng.random((200, 300), dtype=np.float32), d=d2, kw=dict(order=3)),
+        dict(name="order 1, channels", X=rng.random((3, 24, 40), dtype=np.float64), d=d2,
+             kw=dict(order=1, mode="nearest", axis=(1, 2))),
+        dict(name="list", X=[rng.random((20, 28, 24), dtype=np.float32),
+                             rng.integers(0, 5, (20, 28, 24)).astype(np.uint8)], d=d3,
+             kw=dict(order=[3, 0], mode=["mirror", "nearest"])),
+        dict(name="order 5 wrap", X=rng.random((24, 24, 24), dtype=np.float32), d=d3, kw=dict(order=5, mode="wrap")),
+    ]
+
+
+@pytest.mark.parametrize("case", _lane_cases(), ids=lambda c: c["name"])
+def test_repeat_call_lane_equals_general_path(case):
+    """The second and later calls with the same layout skip the argument normalisation (_fastlane.py);
+    they must issue the same library calls: forward bit-equal, gradient within the float32 atomics' noise."""
+    from elasticdeform_amd import _fastlane
+    dev = torch.device("cuda", 0)
+    lst = isinstance(case["X"], list)
+    Xs = [torch.from_numpy(x).to(dev) for x in _aslist(case["X"])]
+    X = Xs if lst else Xs[0]
+    d = torch.from_numpy(case["d"]).to(dev)
+    kw = case["kw"]
+    _fastlane.clear()
+    _fastlane.enabled = False
+    try:
+        want = _aslist(ed.deform_grid(X, d, **kw))
+        dYs = [torch.ones_like(w) if w.dtype.is_floating_point else None for w in want]
+        assert not _fastlane._lanes
+    finally:
+        _fastlane.enabled = True
+    calls = []
+    run = _fastlane.Lane.run
+    _fastlane.Lane.run = lambda self, *a: (calls.append(self.gradient), run(self, *a))[1]
+    try:
+        for rep in range(3):
+            got = _aslist(ed.deform_grid(X, d, **kw))
+            for g_, w_ in zip(got, want):
+                assert torch.equal(g_, w_), (case["name"], rep)
+        assert calls == [False, False], calls          # first call: general path (builds the lane)
+        # new data, same layout: the lane must not have kept anything of the previous arrays
+        X2 = [x.flip(0).contiguous() for x in Xs]
+        _fastlane.enabled = False
+        want2 = _aslist(ed.deform_grid(X2 if lst else X2[0], d, **kw))
+        _fastlane.enabled = True
+        got2 = _aslist(ed.deform_grid(X2 if lst else X2[0], d, **kw))
+        for g_, w_ in zip(got2, want2):
+            assert torch.equal(g_, w_)
+        assert len(calls) == 3
+        if all(dy is not None for dy in dYs):
+            gkw = dict(kw, X_shape=[tuple(x.shape) for x in Xs] if lst else tuple(Xs[0].shape))
+            dY = dYs if lst else dYs[0]
+            _fastlane.enabled = False
+            gw = _aslist(ed.deform_grid_gradient(dY, d, **gkw))
+            _fastlane.enabled = True
+            del calls[:]
+            for rep in range(3):
+                gg = _aslist(ed.deform_grid_gradient(dY, d, **gkw))
+                for g_, w_ in zip(gg, gw):
+                    scale = float(w_.abs().max())
+                    tol = 1e-12 if w_.dtype == torch.float64 else 1e-5
+                    assert float((g_ - w_).abs().max()) <= tol * scale, (case["name"], rep)
+            assert calls == [True, True], calls
+    finally:
+        _fastlane.Lane.run = run
+        _fastlane.enabled = True
+
+
+def test_repeat_call_lane_leaves_other_calls_to_the_general_path():
+    from elasticdeform_amd import _fastlane
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    Xn = rng.random((24, 24), dtype=np.float32)
+    X = torch.from_numpy(Xn).to(dev)
+    dn = rng.standard_normal((2, 3, 3)) * 3
+    d = torch.from_numpy(dn).to(dev)
+    _fastlane.clear()
+    for _ in range(2):          # numpy in -> numpy out, never a lane
+        assert isinstance(ed.deform_grid(Xn, dn, order=3), np.ndarray)
+    assert not _fastlane._lanes
+    for _ in range(2):          # rotate / zoom / affine: general path
+        ed.deform_grid(X, d, order=3, rotate=10.0)
+    assert not _fastlane._lanes
+    a = ed.deform_grid(X, d, order=3)
+    b = ed.deform_grid(X, d, order=3)
+    assert len(_fastlane._lanes) == 1 and torch.equal(a, b)
+    # a different layout of the same shape is a different signature (and gives the same values)
+    Xt = X.t().contiguous().t()
+    c = ed.deform_grid(Xt, d, order=3)
+    assert len(_fastlane._lanes) == 2 and torch.equal(a, c)
+    # errors still come from the general path's checks
+    with pytest.raises(AssertionError):
+        ed.deform_grid(X, d[:1], order=3)
+    # the arithmetic switch is part of the signature
+    prev = ed.set_arithmetic("exact")
+    try:
+        e1 = ed.deform_grid(X, d, order=3)
+        e2 = ed.deform_grid(X, d, order=3)
+        assert torch.equal(e1, e2) and len(_fastlane._lanes) == 3
+    finally:
+        ed.set_arithmetic(prev)
+
+
+def test_repeat_call_lane_from_two_threads():
+    import threading
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(6)
+    d = torch.from_numpy(rng.standard_normal((3, 3, 3, 3)) * 1.5).to(dev)
+    Xa = torch.from_numpy(rng.random((16, 16, 16), dtype=np.float32)).to(dev)
+    Xb = torch.from_numpy(rng.random((16, 16, 16), dtype=np.float32)).to(dev)
+    wa = ed.deform_grid(Xa, d, order=3, mode="mirror")
+    wb = ed.deform_grid(Xb, d, order=3, mode="mirror")
+    bad = []
+
+    def work(X, want):
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            for _ in range(200):
+                if not torch.equal(ed.deform_grid(X, d, order=3, mode="mirror"), want):
+                    bad.append(1)
+        s.synchronize()
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=work, args=a) for a in ((Xa, wa), (Xb, wb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad

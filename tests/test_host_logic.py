@@ -201,3 +201,19 @@ def test_reference_import_name_is_served_by_the_alias_package():
     import elasticdeform.torch as etorch
     import elasticdeform_amd.torch as etorch_amd
     assert etorch.deform_grid is etorch_amd.deform_grid
+
+
+def test_repeat_call_lane_only_recognises_device_tensors():
+    """_fastlane.signature: anything that is not a CUDA tensor (list) on the current device -> None,
+    i.e. the general path (no GPU needed to check that)."""
+    torch = pytest.importorskip("torch")
+    from elasticdeform_amd import _fastlane
+    x = torch.zeros((4, 4))
+    d = torch.zeros((2, 3, 3))
+    args = (3, 'constant', 0.0, None, True, None, None, 0)
+    assert _fastlane.signature(False, x, d, *args) is None
+    assert _fastlane.signature(False, np.zeros((4, 4)), np.zeros((2, 3, 3)), *args) is None
+    assert _fastlane.signature(False, [x], d, *args) is None
+    assert _fastlane.signature(False, (x,), d, *args) is None
+    assert _fastlane._hashable([3, 1]) == _fastlane._hashable([3, 1]) != _fastlane._hashable((3, 1))
+    assert _fastlane._crop_key((slice(1, 5), slice(None))) == ((1, 5, None), (None, None, None))
