@@ -138,10 +138,10 @@ __device__ __forceinline__ void transpose_line(double* ws, const int64_t wst, co
 // 8 LDS reads of a block are issued together and the dependent fp64 chain runs on registers.  With one
 // wave per CU nothing else hides the LDS latency, and the compiler does not pipeline the rolled loops
 // above.  Same operations on the same operands in the same order: same bits.
-constexpr int kTileLines = 64, kTilePitch = 65, kBlk = 8;
+constexpr int kBlk = 8;      // (row pitch W of a tile = lines per tile + 1 doubles: odd, conflict-free)
+template <int W>
 __device__ __forceinline__ void forward_line_tile(double* ws, const int n, const FilterParams& p)
 {
-    constexpr int W = kTilePitch;
     for (int h = 0; h < p.npoles; ++h) {
         const double z = p.pole[h];
         const double zn1 = p.pole_pow[h];
@@ -218,9 +218,9 @@ __device__ __forceinline__ void forward_line_tile(double* ws, const int n, const
 }
 
 // transpose_line for a line in an LDS tile, blocked like forward_line_tile (same operations, same order)
+template <int W>
 __device__ __forceinline__ void transpose_line_tile(double* ws, const int len, const FilterParams& p)
 {
-    constexpr int W = kTilePitch;
     for (int h = 0; h < p.npoles; ++h) {
         const double q = p.pole[h];
         const bool last = h == p.npoles - 1;
@@ -395,9 +395,10 @@ __device__ __forceinline__ void with_dtype(int dt, F&& f)
 #undef ED_DT_CASE
 }
 
-template <bool TRANSPOSE>
+template <int kTileLines, bool TRANSPOSE>
 __global__ __launch_bounds__(256) void prefilter_line_tile_kernel(const FilterParams p)
 {
+    constexpr int kTilePitch = kTileLines + 1;
     extern __shared__ double lws[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t line0 = (int64_t)blockIdx.x * kTileLines;
@@ -428,21 +429,26 @@ __global__ __launch_bounds__(256) void prefilter_line_tile_kernel(const FilterPa
                     lws[i * kTilePitch + l] = TRANSPOSE ? v : v * g;
                 }
             }
-        } else if (lane < nl) {
-            const char* base = p.in + s_in[lane];
+        } else {
+            // lanes <-> lines; tiles of fewer than 64 lines put 64 / kTileLines samples in one wave instruction
+            constexpr int SPW = 64 / kTileLines;
+            const int l = lane % kTileLines, sub = lane / kTileLines;
+            if (l < nl) {
+                const char* base = p.in + s_in[l];
 #pragma unroll 8
-            for (int i = wave; i < n; i += 4) {
-                const double v = load_as_double(base + (int64_t)i * p.in_axis_stride, DT);
-                lws[i * kTilePitch + lane] = TRANSPOSE ? v : v * g;
+                for (int i = wave * SPW + sub; i < n; i += 4 * SPW) {
+                    const double v = load_as_double(base + (int64_t)i * p.in_axis_stride, DT);
+                    lws[i * kTilePitch + l] = TRANSPOSE ? v : v * g;
+                }
             }
         }
     });
     __syncthreads();
     if (tid < nl) {
         if (TRANSPOSE)
-            transpose_line_tile(lws + tid, n, p);
+            transpose_line_tile<kTilePitch>(lws + tid, n, p);
         else
-            forward_line_tile(lws + tid, n, p);
+            forward_line_tile<kTilePitch>(lws + tid, n, p);
     }
     __syncthreads();
     with_dtype(p.out_dtype, [&](auto dt) {
@@ -454,11 +460,15 @@ __global__ __launch_bounds__(256) void prefilter_line_tile_kernel(const FilterPa
                 for (int i = lane; i < n; i += 64)
                     store_cast(base + (int64_t)i * p.out_axis_stride, DT, lws[i * kTilePitch + l]);
             }
-        } else if (lane < nl) {
-            char* base = p.out + s_out[lane];
+        } else {
+            constexpr int SPW = 64 / kTileLines;
+            const int l = lane % kTileLines, sub = lane / kTileLines;
+            if (l < nl) {
+                char* base = p.out + s_out[l];
 #pragma unroll 8
-            for (int i = wave; i < n; i += 4)
-                store_cast(base + (int64_t)i * p.out_axis_stride, DT, lws[i * kTilePitch + lane]);
+                for (int i = wave * SPW + sub; i < n; i += 4 * SPW)
+                    store_cast(base + (int64_t)i * p.out_axis_stride, DT, lws[i * kTilePitch + l]);
+            }
         }
     });
 }
@@ -545,37 +555,54 @@ hipError_t launch_spline_filter(const FilterParams& p, hipStream_t stream)
         return hipSuccess;
     static const bool no_ldsws = ed_env("EDHIP_FILTER_NO_LDSWS") != nullptr;      // A/B switch
     static const bool no_short_tile = ed_env("EDHIP_FILTER_NO_SHORT_TILE") != nullptr;
-    // 2 .. 313 samples (up to the lines of a 256^3 volume): tiles of 64 lines in LDS, moved by the whole
-    // workgroup.  (Short lines used to go to the one-thread-per-line kernel below: 21 us per pass for a
-    // 32^3 volume, its 32 dependent global loads per thread; the tile kernel takes 5.)
-    if (p.len <= 313 && p.len >= 2 && p.npoles > 0 && !no_ldsws && (p.len > 128 || !no_short_tile) && dtype_size(p.in_dtype) > 0 &&
+    // Lines of 2 .. 4000 samples: tiles of 64 / 16 / 4 lines in LDS (fp64, [len][lines + 1]), moved by the
+    // whole workgroup; one lane per line runs the recursion.  64 lines fit up to 313 samples (the lines of a
+    // 256^3 volume), 16 up to 1200, 4 up to 4000 (2-D images: a 1024^2 uint8 image took 0.85 ms per pass on
+    // the one-thread-per-line kernel below, its samples walked one dependent global round trip at a time).
+    // (Short lines used to go to the one-thread-per-line LDS kernel: 21 us per pass for a 32^3 volume.)
+    if (p.len >= 2 && p.npoles > 0 && !no_ldsws && (p.len > 128 || !no_short_tile) && dtype_size(p.in_dtype) > 0 &&
         dtype_size(p.out_dtype) > 0) {
-        const size_t lds = (size_t)p.len * kTilePitch * sizeof(double) + 2 * kTileLines * sizeof(int64_t);
-        const int64_t nblk = (p.nlines + kTileLines - 1) / kTileLines;
-        bool ok = nblk <= 0x7fffffffLL;
-        if (ok && lds > 64 * 1024) {
-            // (per device: a process may drive several GPUs)
-            static std::atomic<unsigned long long> allowed{0};
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            const unsigned long long bit = 1ull << (dev & 63);
-            if (!(allowed.load(std::memory_order_acquire) & bit)) {
-                ok = hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_line_tile_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                     hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_line_tile_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-                if (ok)
-                    allowed.fetch_or(bit, std::memory_order_release);
-                else
-                    (void)hipGetLastError();
+        const size_t budget = 160 * 1024 - 256;
+        auto lds_for = [&](int lines) {
+            return (size_t)p.len * (lines + 1) * sizeof(double) + 2 * (size_t)lines * sizeof(int64_t);
+        };
+        const int lines = lds_for(64) <= budget ? 64 : (lds_for(16) <= budget ? 16 : (lds_for(4) <= budget ? 4 : 0));
+        const int64_t nblk = lines ? (p.nlines + lines - 1) / lines : 0;
+        if (lines && nblk <= 0x7fffffffLL) {
+            const size_t lds = lds_for(lines);
+            hipError_t e = hipSuccess;
+            auto go = [&](auto kernel, int slot) {
+                if (lds > 64 * 1024) {
+                    // (per device and kernel: a process may drive several GPUs)
+                    static std::atomic<unsigned long long> allowed[6];
+                    int dev = 0;
+                    (void)hipGetDevice(&dev);
+                    const unsigned long long bit = 1ull << (dev & 63);
+                    if (!(allowed[slot].load(std::memory_order_acquire) & bit)) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                            (void)hipGetLastError();
+                            e = hipErrorNotSupported;
+                            return;
+                        }
+                        allowed[slot].fetch_or(bit, std::memory_order_release);
+                    }
+                }
+                hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(256), lds, stream, p);
+                e = hipGetLastError();
+            };
+            if (lines == 64) {
+                if (p.transpose) go(prefilter_line_tile_kernel<64, true>, 0);
+                else go(prefilter_line_tile_kernel<64, false>, 1);
+            } else if (lines == 16) {
+                if (p.transpose) go(prefilter_line_tile_kernel<16, true>, 2);
+                else go(prefilter_line_tile_kernel<16, false>, 3);
+            } else {
+                if (p.transpose) go(prefilter_line_tile_kernel<4, true>, 4);
+                else go(prefilter_line_tile_kernel<4, false>, 5);
             }
-        }
-        if (ok) {
-            if (p.transpose)
-                hipLaunchKernelGGL(prefilter_line_tile_kernel<true>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
-            else
-                hipLaunchKernelGGL(prefilter_line_tile_kernel<false>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
-            return hipGetLastError();
+            if (e != hipErrorNotSupported)
+                return e;
         }
     }
     // what is left with lines of up to 128 samples: one thread per line, working copy in LDS (64 KiB:
