@@ -1624,7 +1624,8 @@ bool deform_int_supported(const GridGeom& g, const IOView& v, int gradient)
 {
     if (g.naxis != 3 || gradient || v.order < 1 || v.order > 5 || v.in_dtype != v.out_dtype)
         return false;
-    if (v.in_dtype != EDHIP_U8 && v.in_dtype != EDHIP_I8 && v.in_dtype != EDHIP_U16 && v.in_dtype != EDHIP_I16)
+    if (v.in_dtype != EDHIP_U8 && v.in_dtype != EDHIP_I8 && v.in_dtype != EDHIP_U16 && v.in_dtype != EDHIP_I16 &&
+        v.in_dtype != EDHIP_U32 && v.in_dtype != EDHIP_I32)
         return false;
     IOView v0 = v;
     v0.order = 0;
@@ -1643,8 +1644,11 @@ hipError_t launch_deform_int(const GridGeom& g, const IOView& v, hipStream_t str
 {
     if (!deform_int_supported(g, v, 0))
         return hipErrorNotSupported;
-    return label_elem_size(v.in_dtype) == 1 ? launch_tile<uint8_t, 0, false, false>(g, v, stream, nullptr)
-                                            : launch_tile<uint16_t, 0, false, false>(g, v, stream, nullptr);
+    switch (label_elem_size(v.in_dtype)) {
+    case 1: return launch_tile<uint8_t, 0, false, false>(g, v, stream, nullptr);
+    case 2: return launch_tile<uint16_t, 0, false, false>(g, v, stream, nullptr);
+    default: return launch_tile<uint32_t, 0, false, false>(g, v, stream, nullptr);
+    }
 }
 
 hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream)

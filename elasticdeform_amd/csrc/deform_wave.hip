@@ -971,7 +971,16 @@ __device__ __forceinline__ bool int_coords(const HotGeom& hg, const HotParams* h
 
 // (ORDER + 1)^3 taps in fp64 from the float32 box (column-first contraction, see wave_gather for the
 // pair / parity scheme)
-template <int ORDER, int PITCH>
+// KIND: what a 4-byte cell of the box holds -- 0: the value as float32 (8- / 16-bit volumes, exact), 1: the bits
+// of an int32, 2: of a uint32 (32-bit volumes do not fit a float32 mantissa; v_cvt_f64_i32 costs what
+// v_cvt_f64_f32 does)
+template <int KIND>
+__device__ __forceinline__ double int_cell(float v)
+{
+    return KIND == 0 ? (double)v : (KIND == 1 ? (double)__float_as_int(v) : (double)__float_as_uint(v));
+}
+
+template <int ORDER, int PITCH, int KIND>
 __device__ __forceinline__ double int_gather(const float* bp, int ps, bool par, const double (&w0)[ORDER + 1],
                                              const double (&w1)[ORDER + 1], const double (&w2)[ORDER + 1])
 {
@@ -1006,7 +1015,7 @@ __device__ __forceinline__ double int_gather(const float* bp, int ps, bool par, 
         for (int l1 = 0; l1 < NT; ++l1)
 #pragma unroll
             for (int j = 0; j < NC; ++j)
-                c[j] = fma(w1[l1], (double)v[l1][j], c[j]);
+                c[j] = fma(w1[l1], int_cell<KIND>(v[l1][j]), c[j]);
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             S[j] = fma(w0[l0], c[j], S[j]);
@@ -1029,11 +1038,13 @@ template <typename TIN>
 __device__ __forceinline__ TIN int_store_value(double t)
 {
     constexpr bool is_signed = (TIN)(-1) < (TIN)0;
-    constexpr double lo = is_signed ? -(double)(1u << (8 * sizeof(TIN) - 1)) : 0.0;
-    constexpr double hi = is_signed ? (double)((1u << (8 * sizeof(TIN) - 1)) - 1) : (double)((1u << (8 * sizeof(TIN))) - 1);
+    constexpr double lo = is_signed ? -(double)(1ull << (8 * sizeof(TIN) - 1)) : 0.0;
+    constexpr double hi = is_signed ? (double)((1ull << (8 * sizeof(TIN) - 1)) - 1) : (double)((1ull << (8 * sizeof(TIN))) - 1);
     t = t > 0 ? t + 0.5 : (is_signed ? t - 0.5 : 0.0);
     t = t > hi ? hi : t;
     t = t < lo ? lo : t;
+    if (sizeof(TIN) == 4)
+        return (TIN)(long long)t;
     return (TIN)(int)t;          // (NaN: the tie test below sends the voxel to the exact kernel)
 }
 
@@ -1075,6 +1086,14 @@ __global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, c
     }
     const int last = hg.out_len[2] - 1;
     const TIN cst_value = int_store_value<TIN>(hg.cvald);
+    constexpr int KIND = sizeof(TIN) < 4 ? 0 : (((TIN)(-1) < (TIN)0) ? 1 : 2);
+    auto encode = [](TIN x) -> float {
+        return KIND == 0 ? (float)x : (KIND == 1 ? __int_as_float((int)x) : __uint_as_float((unsigned)x));
+    };
+    // 32-bit volumes: the band around a rounding tie grows with the magnitude of the data (the fast and
+    // the exact coordinates differ by ~1e-13 relative, and a tap sum of 2e9 carries that as 1e-3): 1e-9 of
+    // the largest |sample| of the box -- the same margin the 1e-4 leaves a full-range int16 volume
+    float boxmax = 0.0f;
 
     for (int ti = 0; ti < sp.ntile; ++ti) {
         const int ox_tile = (sp.tx0 + ti) * kT;
@@ -1112,14 +1131,19 @@ __global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, c
                                           bl.b0[1] + bl.ext[1] <= hg.in_len[1] && bl.b0[2] >= 0 &&
                                           bl.b0[2] + bl.ext[2] <= hg.in_len[2];
                     __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): the previous gather's reads
+                    float vmax = 0.0f;
                     if (interior) {
                         // four rows per wave instruction, 16 lanes along x; all loads of the box in flight
                         const TIN* p0 = src + ((bl.b0[0] * hg.vol_sz + bl.b0[1] * hg.vol_sy) + bl.b0[2] + sx);
 #pragma unroll 4
                         for (int r = lane >> 4; r < nrows; r += 4) {
                             const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * bl.ext[1];
-                            if (sx < bl.ext[2])
-                                box[zr * ps + yr * pitch + sx] = (float)p0[zr * hg.vol_sz + yr * hg.vol_sy];
+                            if (sx < bl.ext[2]) {
+                                const TIN x = p0[zr * hg.vol_sz + yr * hg.vol_sy];
+                                box[zr * ps + yr * pitch + sx] = encode(x);
+                                if (KIND)
+                                    vmax = fmaxf(vmax, fabsf((float)x));
+                            }
                         }
                     } else {
                         const int xs = mirror_i32(bl.b0[2] + min(sx, bl.ext[2] - 1), hg.in_len[2]);
@@ -1127,9 +1151,19 @@ __global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, c
                             const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * bl.ext[1];
                             const int zs = mirror_i32(bl.b0[0] + zr, hg.in_len[0]);
                             const int ys = mirror_i32(bl.b0[1] + yr, hg.in_len[1]);
-                            if (sx < bl.ext[2])
-                                box[zr * ps + yr * pitch + sx] = (float)src[zs * hg.vol_sz + ys * hg.vol_sy + xs];
+                            if (sx < bl.ext[2]) {
+                                const TIN x = src[zs * hg.vol_sz + ys * hg.vol_sy + xs];
+                                box[zr * ps + yr * pitch + sx] = encode(x);
+                                if (KIND)
+                                    vmax = fmaxf(vmax, fabsf((float)x));
+                            }
                         }
+                    }
+                    if (KIND) {
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1)
+                            vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+                        boxmax = vmax;
                     }
                     __builtin_amdgcn_s_waitcnt(0xC07F);
                     asm volatile("" ::: "memory");
@@ -1137,9 +1171,9 @@ __global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, c
                 TIN* op = img + (img_off + obase);
                 // the lane's voxels of this (sub-)tile are packed and stored together: 8 or 16 contiguous
                 // bytes per lane instead of one 1- / 2-byte store per voxel
-                unsigned long long pk0 = 0, pk1 = 0;
+                unsigned long long pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0;
                 constexpr int kBits = 8 * (int)sizeof(TIN);
-                constexpr int kPer64 = 64 / kBits;             // voxels per 64-bit word: 8 or 4
+                constexpr int kPer64 = 64 / kBits;             // voxels per 64-bit word: 8, 4 or 2
                 XEntry xe;
                 xentry_load(xt, min(ox0, last), xe);
 #pragma unroll 1
@@ -1169,7 +1203,9 @@ __global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, c
                     weights_from_frac<double, ORDER>(fr[1], w1);
                     weights_from_frac<double, ORDER>(fr[2], w2);
                     double t = 0.0;
+                    double band = kIntTieBand;
                     if (direct) {
+                        float dmax = 0.0f;
                         if (live) {
                             // taps straight from global memory, mirror-mapped (rolled: rare)
 #pragma unroll 1
@@ -1181,9 +1217,12 @@ __global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, c
                                     const int ys = mirror_i32(st[1] + l1, hg.in_len[1]);
                                     double a2 = 0.0;
 #pragma unroll
-                                    for (int l2 = 0; l2 < NT; ++l2)
-                                        a2 = fma(w2[l2], (double)src[zs * hg.vol_sz + ys * hg.vol_sy +
-                                                                     mirror_i32(st[2] + l2, hg.in_len[2])], a2);
+                                    for (int l2 = 0; l2 < NT; ++l2) {
+                                        const TIN x = src[zs * hg.vol_sz + ys * hg.vol_sy + mirror_i32(st[2] + l2, hg.in_len[2])];
+                                        a2 = fma(w2[l2], (double)x, a2);
+                                        if (KIND)
+                                            dmax = fmaxf(dmax, fabsf((float)x));
+                                    }
                                     double wy = w1[0];
 #pragma unroll
                                     for (int l = 1; l < NT; ++l)
@@ -1197,17 +1236,21 @@ __global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, c
                                 t = fma(wz, a1, t);
                             }
                         }
+                        if (KIND)
+                            band = kIntTieBand + 1e-9 * (double)dmax;
                     } else if (bl.any) {
+                        if (KIND)
+                            band = kIntTieBand + 1e-9 * (double)boxmax;
                         const int rz = live ? st[0] - bl.b0[0] : 0, ry = live ? st[1] - bl.b0[1] : 0,
                                   rx = live ? st[2] - bl.b0[2] : 0;
                         const float* bp = box + (rz * ps + ry * pitch + (rx & ~1));
-                        t = pitch == 16 ? int_gather<ORDER, 16>(bp, ps, rx & 1, w0, w1, w2)
-                                        : int_gather<ORDER, 12>(bp, ps, rx & 1, w0, w1, w2);
+                        t = pitch == 16 ? int_gather<ORDER, 16, KIND>(bp, ps, rx & 1, w0, w1, w2)
+                                        : int_gather<ORDER, 12, KIND>(bp, ps, rx & 1, w0, w1, w2);
                     }
                     // value within the band of a rounding tie (x.5), or not a number: exact kernel
                     const double at = fabs(t);
                     const double ft = at - floor(at);
-                    const bool tie = live && (!(fabs(ft - 0.5) >= kIntTieBand) || !(t == t));
+                    const bool tie = live && (!(fabs(ft - 0.5) >= band) || !(t == t));
                     if (inside) {
                         if ((near || tie) && hg.tie_list) {
                             const int slot = atomicAdd(&hg.tie_list[0], 1);
@@ -1218,27 +1261,40 @@ __global__ __launch_bounds__(64, 3) void wave_int_fwd_kernel(const HotGeom hg, c
                     {
                         typedef typename std::make_unsigned<TIN>::type UT;
                         const unsigned long long bits = (unsigned long long)(UT)(live ? int_store_value<TIN>(t) : cst_value);
-                        if (k < kPer64)        // (k is wave-uniform)
-                            pk0 |= bits << (kBits * k);
+                        const int word = k / kPer64, sh = kBits * (k % kPer64);        // (k is wave-uniform)
+                        if (word == 0)
+                            pk0 |= bits << sh;
+                        else if (word == 1)
+                            pk1 |= bits << sh;
+                        else if (word == 2)
+                            pk2 |= bits << sh;
                         else
-                            pk1 |= bits << (kBits * (k - kPer64));
+                            pk3 |= bits << sh;
                     }
                 }
                 if (rw.vzy) {
                     TIN* o = op + ox0;
-                    const int nbytes = nx * (int)sizeof(TIN);          // 4, 8 or 16
+                    const int nbytes = nx * (int)sizeof(TIN);          // 4, 8, 16 or 32
                     const bool whole = ox0 + nx - 1 <= last && (((size_t)o) & (nbytes >= 8 ? 7 : 3)) == 0;
                     if (whole) {
+                        unsigned long long* o8 = reinterpret_cast<unsigned long long*>(o);
                         if (nbytes == 4)
                             __builtin_nontemporal_store((unsigned)pk0, reinterpret_cast<unsigned*>(o));
                         else
-                            __builtin_nontemporal_store(pk0, reinterpret_cast<unsigned long long*>(o));
-                        if (nbytes == 16)
-                            __builtin_nontemporal_store(pk1, reinterpret_cast<unsigned long long*>(o) + 1);
+                            __builtin_nontemporal_store(pk0, o8);
+                        if (nbytes >= 16)
+                            __builtin_nontemporal_store(pk1, o8 + 1);
+                        if (nbytes == 32) {
+                            __builtin_nontemporal_store(pk2, o8 + 2);
+                            __builtin_nontemporal_store(pk3, o8 + 3);
+                        }
                     } else {
                         for (int k = 0; k < nx; ++k)
-                            if (ox0 + k <= last)
-                                o[k] = (TIN)((k < kPer64 ? pk0 >> (kBits * k) : pk1 >> (kBits * (k - kPer64))));
+                            if (ox0 + k <= last) {
+                                const int word = k / kPer64;
+                                const unsigned long long w = word == 0 ? pk0 : (word == 1 ? pk1 : (word == 2 ? pk2 : pk3));
+                                o[k] = (TIN)(w >> (kBits * (k % kPer64)));
+                            }
                     }
                 }
             }
@@ -1266,6 +1322,8 @@ hipError_t launch_wave_int_o(const HotGeom& hg, int dtype, const void* vol, void
     case EDHIP_I8: return launch_wave_int_t<ORDER, int8_t>(hg, vol, img, nblk, lds, stream);
     case EDHIP_U16: return launch_wave_int_t<ORDER, uint16_t>(hg, vol, img, nblk, lds, stream);
     case EDHIP_I16: return launch_wave_int_t<ORDER, int16_t>(hg, vol, img, nblk, lds, stream);
+    case EDHIP_U32: return launch_wave_int_t<ORDER, uint32_t>(hg, vol, img, nblk, lds, stream);
+    case EDHIP_I32: return launch_wave_int_t<ORDER, int32_t>(hg, vol, img, nblk, lds, stream);
     default: return hipErrorNotSupported;
     }
 }

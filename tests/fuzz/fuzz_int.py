@@ -32,7 +32,7 @@ for case in range(ncases):
     order = int(rng.integers(1, 6))
     mode = str(rng.choice(MODES))
     sigma = float(rng.choice([0.0, 0.5, 2.0, 5.0, 12.0, 30.0]))
-    dtype = rng.choice([np.uint8, np.int8, np.uint16, np.int16])
+    dtype = rng.choice([np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32])
     info = np.iinfo(dtype)
     kw = dict(order=order, mode=mode, cval=float(rng.integers(-3, 4)) * 0.75, prefilter=bool(rng.integers(0, 2)))
     full = shape
