@@ -934,9 +934,20 @@ ED_UNROLL(ED_K2_U2)
                     for (int l1 = 0; l1 < NT; ++l1) {
                         const float g1 = g0 * w1[l1];
                         int* rp = bp + (l0 * by + l1) * pitch;
+                        // (the NT products of a row as packed multiplies: v_pk_mul_f32 does two per issue)
+                        typedef float f2_t __attribute__((ext_vector_type(2)));
+                        float pr[NT + 1];
+#pragma unroll
+                        for (int l2 = 0; l2 + 1 < NT + 1; l2 += 2) {
+                            const f2_t wv = {w2[l2], l2 + 1 < NT ? w2[l2 + 1] : 0.f};
+                            const f2_t gg = {g1, g1};
+                            const f2_t pv = wv * gg;
+                            pr[l2] = pv.x;
+                            pr[l2 + 1] = pv.y;
+                        }
 #pragma unroll
                         for (int l2 = 0; l2 < NT; ++l2)
-                            atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)round_half_up_i32(g1 * w2[l2]));
+                            atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)round_half_up_i32(pr[l2]));
                     }
                 }
             }
