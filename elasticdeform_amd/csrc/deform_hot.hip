@@ -247,14 +247,13 @@ __device__ __forceinline__ void hot_step_offsets(const HotParams* hp, long long 
 // 64-tap (order 3) separable gather of one voxel from the staged box; PITCH is a template argument so
 // that the row offsets are immediates.  `bp` points at tap (0, 0, 0) in the copy whose shift matches
 // the parity of the window's x start: every x-run is a sequence of aligned ds_read_b64.
-template <int ORDER, int PITCH, bool FENCE = false, int DUP = 0>
+template <int ORDER, int PITCH>
 __device__ __forceinline__ float hot_gather(const float* bp, int plane, const float* w0, const float* w1,
                                             const float* w2)
 {
     constexpr int NT = ORDER + 1;
     constexpr int NTX = NT + (NT & 1);
     float a0 = 0.f;
-    float d0 = 0.f;      // DUP (experiment): a second, independent copy of the arithmetic / of the reads
 #pragma unroll
     for (int l0 = 0; l0 < NT; ++l0) {
         const float* pp = bp + l0 * plane;
@@ -262,37 +261,18 @@ __device__ __forceinline__ float hot_gather(const float* bp, int plane, const fl
 #pragma unroll
         for (int l1 = 0; l1 < NT; ++l1) {
             const float* rp = pp + l1 * PITCH;
-            float a2 = 0.f, d2 = 0.f;
+            float a2 = 0.f;
 #pragma unroll
             for (int l2 = 0; l2 < NTX; l2 += 2) {
-                float2 pr;
-                if (DUP == 3) {          // experiment: two ds_read_b32 (what a single, unshifted copy needs)
-                    pr.x = rp[l2];
-                    ED_NO_DS_MERGE();
-                    pr.y = rp[l2 + 1];
-                    ED_NO_DS_MERGE();
-                } else
-                    pr = *reinterpret_cast<const float2*>(rp + l2);
-                if (FENCE)
-                    ED_NO_DS_MERGE();
+                const float2 pr = *reinterpret_cast<const float2*>(rp + l2);
                 a2 = fmaf(w2[l2], pr.x, a2);
                 a2 = fmaf(w2[l2 + 1], pr.y, a2);
-                if (DUP == 1) {          // twice the FMAs on the same data
-                    d2 = fmaf(w1[l2 % NT], pr.x, d2);
-                    d2 = fmaf(w0[(l2 + 1) % NT], pr.y, d2);
-                }
-                if (DUP == 2) {          // twice the LDS reads (a second box row), one extra add
-                    const float2 qr = *reinterpret_cast<const float2*>(rp + l2 + 4 * PITCH * 0 + plane * 4);
-                    d2 += qr.x;
-                }
             }
             a1 = fmaf(w1[l1], a2, a1);
-            if (DUP)
-                d0 = fmaf(w1[l1], d2, d0);
         }
         a0 = fmaf(w0[l0], a1, a0);
     }
-    return DUP ? a0 + d0 * 1e-30f : a0;
+    return a0;
 }
 
 // ================================================================================================
@@ -477,6 +457,8 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         const int nrows = ext[0] * by;
         const bool fits = pitch > 0 && nrows * pitch <= hg.box_cap;
         const bool staged = any && fits;
+        if (any && hg.hint && tid == 0 && !(pitch > 0 && nrows * pitch <= hg.small_cap))
+            atomicAdd(hg.hint, 1);         // spill feedback: would not fit the standard box
         if (any && !fits && tid == 0) {    // hand the whole tile to the general kernels
             const int slot = atomicAdd(&hg.spill[0], 1);
             hg.spill[1 + slot] = sp.sample * hg.ntiles +
@@ -601,9 +583,8 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
                         const int rz = start[i][0] - b0[0], ry = start[i][1] - b0[1], rx = start[i][2] - b0[2];
                         // aligned pairs from the copy whose shift matches the parity of rx
                         const float* bp = ((rx & 1) ? box1 - 1 : box0) + ((rz * by + ry) * pitch + rx);
-                        constexpr int DUP = (ABL & 32768) ? 3 : (ABL & 8192) ? 1 : ((ABL & 16384) ? 2 : 0);
-                        val = pitch == 16 ? hot_gather<ORDER, 16, (ABL & 128) != 0, DUP>(bp, plane, w0, w1, w2)
-                                          : hot_gather<ORDER, 48, (ABL & 128) != 0, DUP>(bp, plane, w0, w1, w2);
+                        val = pitch == 16 ? hot_gather<ORDER, 16>(bp, plane, w0, w1, w2)
+                                          : hot_gather<ORDER, 48>(bp, plane, w0, w1, w2);
                     }
                     // streaming store (a tile writes 32-byte row segments; see deform_tile.hip)
                     if (!(ABL & 64) || val == -12345.678f)
@@ -839,6 +820,8 @@ ED_UNROLL(ED_K2_U1)
         const int by = ext[1];
         const int nrows = ext[0] * by;
         const int nbox = nrows * pitch;
+        if (hg.hint && tid == 0 && (pitch == 0 || nbox > hg.small_cap))
+            atomicAdd(hg.hint, TX / kT);   // spill feedback, in 8-wide tiles
         if (pitch == 0 || nbox > hg.box_cap) {
             if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < hg.tiles[2]) {
                 const int slot = atomicAdd(&hg.spill[0], 1);
@@ -1033,7 +1016,7 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
             if constexpr (ORDER == 3) {
                 switch (atoi(ed_env("EDHIP_HOT_ABL"))) {
 #define ED_ABL_CASE(A) case A: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, A>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
-                ED_ABL_CASE(32768) ED_ABL_CASE(8192) ED_ABL_CASE(16384) ED_ABL_CASE(16512) ED_ABL_CASE(128) ED_ABL_CASE(16) ED_ABL_CASE(1024) ED_ABL_CASE(4096) ED_ABL_CASE(5120) ED_ABL_CASE(7168) ED_ABL_CASE(3072) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
+                ED_ABL_CASE(16) ED_ABL_CASE(1024) ED_ABL_CASE(4096) ED_ABL_CASE(5120) ED_ABL_CASE(7168) ED_ABL_CASE(3072) ED_ABL_CASE(2) ED_ABL_CASE(4) ED_ABL_CASE(6) ED_ABL_CASE(46) ED_ABL_CASE(32)
 #undef ED_ABL_CASE
                 default: hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
                 }
@@ -1060,13 +1043,17 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
 
 // LDS: x table | reduction slots | wave sums | parameters | 64 Q rows | box.  Returns 0 when the
 // control grid is too wide for a useful box (the general kernels take the call).
-size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box)
+size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, bool large)
 {
     const size_t q = (size_t)kT * kT * 32 * (size_t)ncpx;
     const size_t off = (kOffQ + q + 15) & ~(size_t)15;
     *off_box = (int)off;
+    // Large boxes (three workgroups per CU instead of four) for strongly deformed volumes.  256^3 order 3,
+    // whole call, standard -> large: sigma 5 forward 262 -> 286 us, gradient 325 -> 357; sigma 10 forward
+    // 368 -> 340, gradient 501 -> 427; sigma 15 forward 614 -> 496, gradient 1412 -> 1264
+    // (profiles/r03_bench_misc.txt): launch_tile picks them when recent calls of the geometry spilled.
     if (gradient) {
-        size_t box = kGradBoxBytes;
+        size_t box = large ? 36 * 1024 : kGradBoxBytes;
         if (const char* kb = ed_env("EDHIP_GRAD_BOX_KB"))
             box = (size_t)atoi(kb) * 1024;
         *box_cap = (int)(box / 4);
@@ -1075,7 +1062,7 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box)
     }
     // forward: two shifted float copies; 4 workgroups per CU -> 40960 bytes each (wide control
     // grids: a 64 KiB block, fewer workgroups per CU)
-    size_t budget = 40 * 1024;
+    size_t budget = large ? 52 * 1024 : 40 * 1024;
     if (const char* kb = ed_env("EDHIP_HOT_FWD_KB"))      // experiment: fewer workgroups per CU
         budget = (size_t)atoi(kb) * 1024;
     if (const char* abl = ed_env("EDHIP_HOT_ABL")) {      // experiments (see hot_fwd_kernel)

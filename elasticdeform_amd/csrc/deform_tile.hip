@@ -79,6 +79,14 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     const int ncpy = (int)g.ncp[1], ncpx = (int)g.ncp[2];
     const int nyx = ncpy * ncpx;
     if (oz == 0 && sample == 0 && tid == 0) {      // reset both spill counters (saves two memset launches per call)
+        if (tg.hint) {
+            // the previous call on this stream: (sequence number, tiles beyond the standard box) -> the host
+            if (tg.hint_host)
+                __hip_atomic_store(tg.hint_host, ((unsigned long long)(unsigned)tg.hint[1] << 32) | (unsigned)tg.hint[0],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            tg.hint[0] = 0;
+            tg.hint[1] = (int)tg.hint_seq;
+        }
         tg.spill[0] = 0;
         tg.spill_next[0] = 0;
         if (tg.label_list)
@@ -270,6 +278,16 @@ __device__ __forceinline__ void step_offsets(const IOView& v, int64_t ss, int64_
         r = q;
     }
 }
+
+// One tap of the separable gather.  Every forward kernel of the tile path -- the 4-wave and the
+// one-wave kernels of level 1 (deform_hot.hip, deform_wave.hip), the general kernels of levels 1 / 2 and
+// the direct kernel of level 3 -- accumulates x first, then y, then z, each as a chain of fused
+// multiply-adds starting from zero: a voxel gets the same bits whichever level serves its tile, so
+// results do not depend on the box configuration (spill feedback), on the batch a sample travels in,
+// or on a crop.  (Left to the compiler's contraction, `a += w * x` came out fused in some kernels
+// and not in others: 2-9 % of the voxels differed by an ulp between levels.)
+__device__ __forceinline__ float tap_fma(float w, float x, float a) { return __builtin_fmaf(w, x, a); }
+__device__ __forceinline__ double tap_fma(double w, double x, double a) { return __builtin_fma(w, x, a); }
 
 // ================================================================================================
 // K1: forward
@@ -503,10 +521,10 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_fwd_kernel(const GridG
                                 T a2 = 0;
 #pragma unroll
                                 for (int l2 = 0; l2 < NT; ++l2)
-                                    a2 += w2[l2] * rp[l2];
-                                a1 += w1[l1] * a2;
+                                    a2 = tap_fma(w2[l2], rp[l2], a2);
+                                a1 = tap_fma(w1[l1], a2, a1);
                             }
-                            a0 += w0[l0] * a1;
+                            a0 = tap_fma(w0[l0], a1, a0);
                         }
                     }
                     val = a0;
@@ -885,10 +903,10 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_direct_kernel(const GridG
                                 T a2 = 0;
 #pragma unroll
                                 for (int l2 = 0; l2 < NT; ++l2)
-                                    a2 += w[2][l2] * p1[tap[2][l2]];
-                                a1 += w[1][l1] * a2;
+                                    a2 = tap_fma(w[2][l2], p1[tap[2][l2]], a2);
+                                a1 = tap_fma(w[1][l1], a2, a1);
                             }
-                            a0 += w[0][l0] * a1;
+                            a0 = tap_fma(w[0][l0], a1, a0);
                         }
                         val = a0;
                     }
@@ -1199,6 +1217,11 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     ws = (char*)ws + kWorkspaceGridBytes;
     int* list_a = (int*)ws;
     int* list_b = (int*)((char*)ws + list_bytes);
+    // (a fixed place in the stream's workspace, whatever the geometry of the call: the unused tail of the
+    // control-grid head, in front of edhip_source_box's 64 result bytes)
+    tg.hint = (int*)((char*)ws - 128);
+    tg.hint_host = nullptr;
+    tg.hint_seq = 0;
     tg.xt_global = (const AxTab*)((char*)ws + 2 * list_bytes);
     tg.q_global = (const double*)((char*)ws + 2 * list_bytes + xt_bytes);
     tg.worklist = nullptr;
@@ -1209,6 +1232,29 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     if (std::is_integral<T>::value) {
         tg.label_list = (int*)((char*)ws + 2 * list_bytes + xt_bytes + q_all);
         tg.label_cap = (int)(label_list_bytes(g) / sizeof(int)) - 32;
+    }
+    // level-1 spill feedback (float32 orders 1-3, the 4-wave kernels of deform_hot.hip): what the recent
+    // calls of this geometry on this stream reported decides between the standard and the large boxes
+    SpillHint* sh = nullptr;
+    bool large_boxes = false;
+    if constexpr (std::is_same<T, float>::value && ORDER >= 1 && ORDER <= 3) {
+        sh = ed_env("EDHIP_NO_SPILL_HINT") ? nullptr : spill_hint(stream);
+        if (sh) {
+            unsigned long long key = 1469598103934665603ull;
+            auto mix = [&](unsigned long long x) { key = (key ^ x) * 1099511628211ull; };
+            for (int k = 0; k < 3; ++k) {
+                mix((unsigned long long)g.in_len[k]);
+                mix((unsigned long long)g.out_len[k]);
+                mix((unsigned long long)g.off[k]);
+                mix((unsigned long long)g.ncp[k]);
+            }
+            mix((unsigned long long)ORDER | ((unsigned long long)GRAD << 8) | ((unsigned long long)v.mode << 16) |
+                ((unsigned long long)g.has_affine << 24) | ((unsigned long long)nb << 32));
+            sh->absorb();
+            large_boxes = sh->fraction(key) > 0.10f;
+            tg.hint_host = sh->dev;
+            tg.hint_seq = sh->begin_call(key, (unsigned)(ntiles * nb));
+        }
     }
     {
         hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0], (unsigned)nb), dim3(kBlock),
@@ -1342,7 +1388,16 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 }
                 for (int k = 0; k < 12; ++k)
                     hg.affine[k] = tg.affine[k];
-                const size_t hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box);
+                size_t hlds = 0;
+                {
+                    int off_small = 0;
+                    (void)hot_lds_bytes(GRAD, tg.ncpx, &hg.small_cap, &off_small, false);
+                    if (large_boxes)
+                        hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box, true);
+                    if (!hlds)
+                        hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box, false);
+                    hg.hint = sh ? tg.hint : nullptr;
+                }
                 hg.lds_grp = (int)((hlds + 15) & ~(size_t)15);
                 // EDHIP_FLAG_KEEP_BOXES / USE_BOXES: the forward kernel's tile boxes live in a buffer of
                 // their own (nothing else writes it) under a host-side key of everything they depend on

@@ -181,9 +181,17 @@ __device__ __forceinline__ double map_coordinate_fast(double c, int len, int mod
 // B-spline basis weights from the fractional offset, in the data's own width.  Same closed forms
 // as deform.c:160-268 (last weight = 1 - sum of the others) with the divisions folded into
 // constants.  x is c - floor(c) (odd orders) or c - floor(c + 0.5) (even orders).
+// Every product-sum is written out as the fused multiply-add it is meant to be and the compiler's own
+// contraction is switched off: the function is inlined into a dozen kernels, and left to itself the
+// backend fused `0.75 - x * x` in some of them and not in others -- a voxel then got weights an ulp
+// apart depending on the level that served its tile (order 2: 6 % of the voxels).
+__device__ __forceinline__ float wt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double wt_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T, int ORDER>
 __device__ __forceinline__ void weights_from_frac(T x, T* w)
 {
+#pragma clang fp contract(off)
     const T z = (T)1 - x;
     if (ORDER == 0) {
         w[0] = (T)1;
@@ -192,42 +200,40 @@ __device__ __forceinline__ void weights_from_frac(T x, T* w)
     if (ORDER == 1) {
         w[0] = z;
     } else if (ORDER == 2) {
-        w[1] = (T)0.75 - x * x;
+        w[1] = wt_fma(-x, x, (T)0.75);
         const T y = (T)0.5 - x;
-        w[0] = (T)0.5 * y * y;
+        w[0] = ((T)0.5 * y) * y;
     } else if (ORDER == 3) {
         // all four cubic pieces in closed form (cheaper than "last = 1 - sum"; same polynomials)
         const T x2 = x * x, z2 = z * z;
-        w[0] = z2 * z * (T)(1.0 / 6.0);
-        w[3] = x2 * x * (T)(1.0 / 6.0);
-        w[1] = x2 * (x * (T)0.5 - (T)1) + (T)(2.0 / 3.0);
-        w[2] = z2 * (z * (T)0.5 - (T)1) + (T)(2.0 / 3.0);
+        w[0] = (z2 * z) * (T)(1.0 / 6.0);
+        w[3] = (x2 * x) * (T)(1.0 / 6.0);
+        w[1] = wt_fma(x2, wt_fma(x, (T)0.5, (T)-1), (T)(2.0 / 3.0));
+        w[2] = wt_fma(z2, wt_fma(z, (T)0.5, (T)-1), (T)(2.0 / 3.0));
         return;
     } else if (ORDER == 4) {
         T t = x * x;
-        w[2] = t * (t * (T)0.25 - (T)0.625) + (T)(115.0 / 192.0);
+        w[2] = wt_fma(t, wt_fma(t, (T)0.25, (T)-0.625), (T)(115.0 / 192.0));
         T y = (T)1 + x;
-        w[1] = y * (y * (y * ((T)5 - y) * (T)(1.0 / 6.0) - (T)1.25) + (T)(5.0 / 24.0)) +
-               (T)(55.0 / 96.0);
-        w[3] = z * (z * (z * ((T)5 - z) * (T)(1.0 / 6.0) - (T)1.25) + (T)(5.0 / 24.0)) +
-               (T)(55.0 / 96.0);
+        w[1] = wt_fma(y, wt_fma(y, wt_fma(y * ((T)5 - y), (T)(1.0 / 6.0), (T)-1.25), (T)(5.0 / 24.0)), (T)(55.0 / 96.0));
+        w[3] = wt_fma(z, wt_fma(z, wt_fma(z * ((T)5 - z), (T)(1.0 / 6.0), (T)-1.25), (T)(5.0 / 24.0)), (T)(55.0 / 96.0));
         y = (T)0.5 - x;
         t = y * y;
-        w[0] = t * t * (T)(1.0 / 24.0);
+        w[0] = (t * t) * (T)(1.0 / 24.0);
     } else {
         T t = x * x;
-        w[2] = t * (t * ((T)0.25 - x * (T)(1.0 / 12.0)) - (T)0.5) + (T)0.55;
+        w[2] = wt_fma(t, wt_fma(t, wt_fma(-x, (T)(1.0 / 12.0), (T)0.25), (T)-0.5), (T)0.55);
         t = z * z;
-        w[3] = t * (t * ((T)0.25 - z * (T)(1.0 / 12.0)) - (T)0.5) + (T)0.55;
+        w[3] = wt_fma(t, wt_fma(t, wt_fma(-z, (T)(1.0 / 12.0), (T)0.25), (T)-0.5), (T)0.55);
         T y = x + (T)1;
-        w[1] = y * (y * (y * (y * (y * (T)(1.0 / 24.0) - (T)0.375) + (T)1.25) - (T)1.75) +
-                    (T)0.625) + (T)0.425;
+        w[1] = wt_fma(y, wt_fma(y, wt_fma(y, wt_fma(y, wt_fma(y, (T)(1.0 / 24.0), (T)-0.375), (T)1.25), (T)-1.75), (T)0.625),
+                      (T)0.425);
         const T zz = z + (T)1;
-        w[4] = zz * (zz * (zz * (zz * (zz * (T)(1.0 / 24.0) - (T)0.375) + (T)1.25) - (T)1.75) +
-                     (T)0.625) + (T)0.425;
+        w[4] = wt_fma(zz, wt_fma(zz, wt_fma(zz, wt_fma(zz, wt_fma(zz, (T)(1.0 / 24.0), (T)-0.375), (T)1.25), (T)-1.75), (T)0.625),
+                      (T)0.425);
         y = (T)1 - x;
         t = y * y;
-        w[0] = y * t * t * (T)(1.0 / 120.0);
+        w[0] = ((y * t) * t) * (T)(1.0 / 120.0);
     }
     T last = (T)1;
 #pragma unroll
@@ -286,6 +292,12 @@ struct TileGeom {
     double affine[12];    // inverse map, 3 x 4
     int* spill;           // [0] = count, [1..] = tile ids that did not fit in LDS
     int* spill_next;      // the second level's spill list (its count is reset by the tables kernel)
+    // level-1 spill feedback (ed_workspace.h, SpillHint): hint[0] = tiles of this call whose box does not fit
+    // the standard level-1 box, hint[1] = this call's sequence number; the tables kernel of the next call
+    // on the stream reports the pair to hint_host (pinned host memory) before it resets them
+    int* hint;
+    unsigned long long* hint_host;
+    unsigned hint_seq;
     int* label_list;      // label kernel: [0] = count, [1..cap] = linear ids of near-tie voxels (or nullptr)
     int label_cap;
     const int* worklist;  // second-level pass: [0] = count, [1..] = tile ids to process (else nullptr)
@@ -355,6 +367,8 @@ struct HotGeom {
     const double* q;          // per-call tables (see tile_tables_kernel)
     const AxTab* xt;
     int* spill;               // tiles the LDS box cannot hold -> the general kernels
+    int* hint;                // [0]: count of the tiles whose box exceeds small_cap elements (or nullptr)
+    int small_cap;            // box_cap of the standard configuration (== box_cap unless the large boxes are in use)
     long long vol_bstride, img_bstride, q_bstride;      // elements between consecutive samples
     int in_len[3], out_len[3], off[3];
     int vol_sz, vol_sy;       // element strides of vol along z, y (x: 1)
@@ -385,7 +399,8 @@ struct HotGeom {
 // level-1 launch of the hot kernels; hipErrorNotSupported when (order, ...) has no instantiation
 hipError_t launch_hot_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds,
                              hipStream_t stream);
-size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box);
+// large: the configuration with one workgroup per CU fewer and larger boxes (chosen from the spill feedback)
+size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, bool large = false);
 
 // one-wavefront-per-tile kernels (deform_wave.hip): same argument block; `strip_tiles`, `strips_x`,
 // `nstrips`, `total_strips` describe the strips of the 64-thread workgroups, `box_cap` the floats /

@@ -29,6 +29,27 @@ struct KeepKey {
 };
 void* keep_reserve(hipStream_t stream, size_t bytes, KeepKey** key, hipError_t* err);
 
+// Level-1 spill feedback of the tile path, per (device, stream).  The tile kernels count the tiles whose
+// source box does not fit the standard (small) level-1 LDS box; the tables kernel of the NEXT call on
+// the stream reports that count into pinned host memory (one 8-byte store: sequence number << 32 |
+// count) and nobody waits for it.  The host reads whatever has arrived when it prepares a call and
+// picks the larger level-1 boxes (one workgroup per CU fewer) for geometries whose recent calls spilled
+// more than a tenth of their tiles.  A hint about speed only: results do not depend on the box size.
+// Callers hold the stream's StreamGuard.
+struct SpillHint {
+    volatile unsigned long long* host = nullptr;   // pinned + mapped
+    unsigned long long* dev = nullptr;             // the device's address of *host
+    unsigned seq = 0;                              // last sequence number handed out (never 0)
+    struct Call { unsigned seq; unsigned long long key; unsigned tiles; } ring[8] = {};
+    struct Entry { unsigned long long key; float frac; } table[8] = {};
+    int nring = 0, ntable = 0;
+
+    void absorb();                                  // fold the latest report into the table
+    float fraction(unsigned long long key) const;   // last known spilled fraction for a geometry, or 0
+    unsigned begin_call(unsigned long long key, unsigned tiles);   // -> this call's sequence number
+};
+SpillHint* spill_hint(hipStream_t stream);          // nullptr when pinned memory is not available
+
 // Drains the devices that own scratch and frees every cached buffer.
 void workspace_release_all();
 

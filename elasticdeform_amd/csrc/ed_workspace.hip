@@ -1,5 +1,6 @@
 #include "ed_workspace.h"
 
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -25,6 +26,11 @@ struct KeepBuffer {
     KeepKey key;
 };
 std::map<std::pair<int, hipStream_t>, KeepBuffer> g_keep;
+struct HintSlot {
+    SpillHint h;
+    bool tried = false;
+};
+std::map<std::pair<int, hipStream_t>, HintSlot> g_hints;      // (std::map: addresses are stable)
 // one host-side lock per (device, stream); entries are never erased, so the pointers stay valid
 std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::recursive_mutex>> g_stream_locks;
 }  // namespace
@@ -152,6 +158,82 @@ void* keep_reserve(hipStream_t stream, size_t bytes, KeepKey** key, hipError_t* 
     return b.ptr;
 }
 
+SpillHint* spill_hint(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    HintSlot& s = g_hints[std::make_pair(dev, stream)];
+    if (!s.tried) {
+        s.tried = true;
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hp &&
+            hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
+            memset(hp, 0, 64);
+            s.h.host = static_cast<volatile unsigned long long*>(hp);
+            s.h.dev = static_cast<unsigned long long*>(dp);
+        } else {
+            if (hp)
+                (void)hipHostFree(hp);
+            (void)hipGetLastError();
+        }
+    }
+    return s.h.host ? &s.h : nullptr;
+}
+
+void SpillHint::absorb()
+{
+    const unsigned long long v = *host;
+    const unsigned s = (unsigned)(v >> 32), count = (unsigned)v;
+    if (s == 0)
+        return;
+    for (int i = 0; i < nring; ++i) {
+        if (ring[i].seq != s)
+            continue;
+        const float f = ring[i].tiles ? (float)count / (float)ring[i].tiles : 0.f;
+        int slot = -1;
+        for (int t = 0; t < ntable; ++t)
+            if (table[t].key == ring[i].key)
+                slot = t;
+        if (slot < 0) {
+            if (ntable < 8)
+                slot = ntable++;
+            else {                      // (eight geometries in rotation on one stream: forget the oldest)
+                for (int t = 1; t < 8; ++t)
+                    table[t - 1] = table[t];
+                slot = 7;
+            }
+            table[slot].key = ring[i].key;
+        }
+        table[slot].frac = f;
+        ring[i].seq = 0;                // consumed
+        return;
+    }
+}
+
+float SpillHint::fraction(unsigned long long key) const
+{
+    for (int t = 0; t < ntable; ++t)
+        if (table[t].key == key)
+            return table[t].frac;
+    return 0.f;
+}
+
+unsigned SpillHint::begin_call(unsigned long long key, unsigned tiles)
+{
+    seq = seq + 1 ? seq + 1 : 1;
+    if (nring < 8)
+        ++nring;
+    for (int i = nring - 1; i > 0; --i)
+        ring[i] = ring[i - 1];
+    ring[0].seq = seq;
+    ring[0].key = key;
+    ring[0].tiles = tiles;
+    return seq;
+}
+
 void workspace_trim(hipStream_t stream)
 {
     int dev = 0;
@@ -196,6 +278,13 @@ void workspace_release_all()
         kv.second.ptr = nullptr;
         kv.second.cap = 0;
         kv.second.key = KeepKey();       // (entries stay: callers may hold the key's address)
+    }
+    for (auto& kv : g_hints) {
+        if (kv.second.h.host && hipSetDevice(kv.first.first) == hipSuccess) {
+            (void)hipDeviceSynchronize();
+            (void)hipHostFree(const_cast<unsigned long long*>(kv.second.h.host));
+        }
+        kv.second = HintSlot();          // (entries stay; the slot is allocated again on demand)
     }
     if (have_cur)
         (void)hipSetDevice(cur);

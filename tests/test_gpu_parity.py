@@ -1229,3 +1229,28 @@ def test_repeat_call_lane_from_two_threads():
     for t in ts:
         t.join()
     assert not bad
+
+
+def test_repeated_calls_with_spill_feedback_stay_identical():
+    """The tile path counts the tiles that do not fit its standard level-1 boxes and, from the third call or
+    so of a strongly deformed geometry on a stream, switches to larger boxes (SpillHint, ed_workspace.h).
+    The box size must not show in the results: forward bit-equal from call to call and to the oracle's
+    tolerance, gradient within the float atomics' noise."""
+    rng = np.random.default_rng(91)
+    n = 96
+    X = rng.random((n, n, n), dtype=np.float32)
+    dY = rng.random((n, n, n), dtype=np.float32)
+    disp = rng.standard_normal((3, 5, 5, 5)) * 9.0          # ~ sigma 24 at 256^3: most tiles leave the standard box
+    Xd, dYd, dd = (torch.from_numpy(a).cuda() for a in (X, dY, disp))
+    for order in (3, 1):
+        kw = dict(order=order, mode="mirror")
+        first = ed.deform_grid(Xd, dd, **kw)
+        gfirst = ed.deform_grid_gradient(dYd, dd, **kw)
+        for rep in range(6):
+            torch.cuda.synchronize()                        # let the reports of the earlier calls arrive
+            assert torch.equal(ed.deform_grid(Xd, dd, **kw), first), (order, rep)
+            g = ed.deform_grid_gradient(dYd, dd, **kw)
+            assert float((g - gfirst).abs().max()) <= 1e-5 * float(gfirst.abs().max()), (order, rep)
+        sl = (slice(20, 52), slice(24, 56), slice(30, 62))
+        ref = orc.deform_grid(X, disp, crop=sl, **kw)
+        np.testing.assert_allclose(first.cpu().numpy()[sl], ref, **F32_TOL)
