@@ -1233,11 +1233,11 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         tg.label_list = (int*)((char*)ws + 2 * list_bytes + xt_bytes + q_all);
         tg.label_cap = (int)(label_list_bytes(g) / sizeof(int)) - 32;
     }
-    // level-1 spill feedback (float32 orders 1-3, the 4-wave kernels of deform_hot.hip): what the recent
+    // level-1 spill feedback (float32, the kernels of deform_hot.hip and deform_wave.hip): what the recent
     // calls of this geometry on this stream reported decides between the standard and the large boxes
     SpillHint* sh = nullptr;
     bool large_boxes = false;
-    if constexpr (std::is_same<T, float>::value && ORDER >= 1 && ORDER <= 3) {
+    if constexpr (std::is_same<T, float>::value && ORDER >= 1) {
         sh = ed_env("EDHIP_NO_SPILL_HINT") ? nullptr : spill_hint(stream);
         if (sh) {
             unsigned long long key = 1469598103934665603ull;
@@ -1472,6 +1472,15 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                             occ = atoi(oc);
 #endif
                         size_t wlds = wave_lds_bytes(GRAD, occ, &wg.box_cap);
+                        // spill feedback: larger boxes (fewer waves per CU) once the geometry's calls spill.
+                        // 256^3 sigma 10, whole call: order 4 forward 453 -> 420 us, gradient 694 -> 662;
+                        // order 5 forward 1019 -> 657, gradient 1238 -> 1055 (sigma 5: +20 .. +40 us)
+                        wg.small_cap = wg.box_cap;
+                        wg.hint = sh ? tg.hint : nullptr;
+                        if (large_boxes) {
+                            wlds = (ORDER == 5 && !GRAD) ? 20480 : 16384;
+                            wg.box_cap = (int)((wlds - 416) / 4);
+                        }
 #ifdef EDHIP_EXPERIMENTS
                         if (const char* kb = ed_env("EDHIP_WAVE_LDS")) {
                             wlds = (size_t)atoi(kb);

@@ -511,12 +511,17 @@ __global__ __launch_bounds__(64, OCC) void wave_fwd_kernel(const HotGeom hg, con
         const int ox_tile = (sp.tx0 + ti) * kT;
         // whole tile first; if its box does not fit the wave's LDS, two halves along x
         int nsub = 1, nx = kT;
+        bool beyond = false;       // spill feedback: the tile would not fit the standard boxes
         for (int sub = 0; sub < nsub; ++sub) {
             const int ox0 = ox_tile + sub * nx;
             int lo[3], hi[3];
             row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox0, nx, lo, hi);
             BoxLayout bl;
             fwd_layout<ORDER>(lo, hi, hg.box_cap, nsub == 2, bl);
+            // (a whole tile that fits the large box only: its halves are taken as three quarters of it)
+            if (bl.any)
+                beyond = nsub == 1 ? (bl.fits && bl.ext[0] * bl.ps * 3 > hg.small_cap * 4)
+                                   : (beyond || !bl.fits || bl.ext[0] * bl.ps > hg.small_cap);
             if (nsub == 1 && hg.boxes && lane < 6) {      // EDHIP_FLAG_KEEP_BOXES: the box goes to the gradient call too
                 const int v = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2] : lane == 3 ? hi[0]
                               : lane == 4 ? hi[1] : hi[2];
@@ -617,6 +622,8 @@ __global__ __launch_bounds__(64, OCC) void wave_fwd_kernel(const HotGeom hg, con
                 }
             }
         }
+        if (beyond && hg.hint && lane == 0)
+            atomicAdd(hg.hint, 1);
     }
     }
 #ifdef EDHIP_EXPERIMENTS
@@ -743,6 +750,9 @@ __global__ __launch_bounds__(64, OCC) void wave_grad_kernel(const HotGeom hg, co
         int nsub = 1, nx = kT;
         CellLayout half0, half1;
         half0 = half1 = cl;
+        // spill feedback: the tile would not fit the standard boxes (a whole tile that fits the large box
+        // only: its halves are taken as three quarters of it)
+        bool beyond = cl.fits && cl.ext[0] * cl.ps * 3 > hg.small_cap * 4;
         if (!cl.fits) {
             // two halves along x, each with a box of its own; nothing has been scattered yet, so a
             // tile whose halves do not fit either can still go to the general kernels as a whole
@@ -751,6 +761,11 @@ __global__ __launch_bounds__(64, OCC) void wave_grad_kernel(const HotGeom hg, co
             grad_layout(lo, hi, hg.box_cap, half0);
             row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox_tile + kT / 2, kT / 2, lo, hi);
             grad_layout(lo, hi, hg.box_cap, half1);
+            beyond = !(half0.fits && half1.fits) || half0.ext[0] * half0.ps > hg.small_cap ||
+                     half1.ext[0] * half1.ps > hg.small_cap;
+            if (beyond && hg.hint && lane == 0)
+                atomicAdd(hg.hint, 1);
+            beyond = false;
             if (!(half0.fits && half1.fits)) {
                 if (lane == 0) {
                     const int slot = atomicAdd(&hg.spill[0], 1);
@@ -761,6 +776,8 @@ __global__ __launch_bounds__(64, OCC) void wave_grad_kernel(const HotGeom hg, co
             nsub = 2;
             nx = kT / 2;
         }
+        if (beyond && hg.hint && lane == 0)
+            atomicAdd(hg.hint, 1);
         for (int sub = 0; sub < nsub; ++sub) {
             if (nsub == 2)
                 cl = sub ? half1 : half0;

@@ -897,7 +897,9 @@ def test_gradient_with_forward_boxes(order, mode, affine):
     truth = orc.deform_grid_gradient(dY.cpu().numpy().astype(np.float64), D.cpu().numpy(), **kw)
     _f32_grad_check(handed.cpu().numpy(), want, truth, flat=order < 5)      # (order 5: see _f32_grad_check)
     scale = max(1.0, float(np.abs(truth).max()))
-    np.testing.assert_allclose(handed.cpu().numpy(), alone.cpu().numpy(), rtol=0, atol=2e-6 * scale)
+    # (the two gradient calls may run on different level-1 box sizes -- the spill feedback can switch between
+    # them -- so tiles move between the fixed-point cells of level 1 and the float atomics of level 2)
+    np.testing.assert_allclose(handed.cpu().numpy(), alone.cpu().numpy(), rtol=0, atol=5e-6 * scale)
 
 
 def test_gradient_with_stale_forward_boxes():
