@@ -941,7 +941,7 @@ def test_batch_gradient_with_forward_boxes():
         truth = orc.deform_grid_gradient(dY[b].cpu().numpy().astype(np.float64), D[b].cpu().numpy(), **kw)
         _f32_grad_check(handed[b].cpu().numpy(), want, truth)
     scale = max(1.0, float(alone.abs().max()))
-    np.testing.assert_allclose(handed.cpu().numpy(), alone.cpu().numpy(), rtol=0, atol=2e-6 * scale)
+    np.testing.assert_allclose(handed.cpu().numpy(), alone.cpu().numpy(), rtol=0, atol=5e-6 * scale)
     D.mul_(1.5)                                  # version bump: the next gradient stands alone again
     g2 = ed.deform_grid_gradient_batch(dY, D, **kw)
     want = orc.deform_grid_gradient(dY[1].cpu().numpy(), D[1].cpu().numpy(), **kw)
