@@ -106,7 +106,7 @@ enum edhip_status {
 /* arithmetic selection for edhip_deform / edhip_spline_filter1d */
 enum edhip_flags {
     EDHIP_FLAG_AUTO = 0,       /* float32 / float64 data -> fast path; integer and bool data -> bit-equal to the
-                                  exact path (order-0 label maps and 8- / 16-bit volumes of orders 1-5: fast
+                                  exact path (order-0 label maps and 8- / 16- / 32-bit integer volumes of orders 1-5: fast
                                   coordinates, near-tie voxels re-evaluated exactly; the rest: exact kernels) */
     EDHIP_FLAG_EXACT = 1,      /* fp64 arithmetic in the reference's own evaluation order (bit-comparable) */
     EDHIP_FLAG_FAST = 2,       /* fp64 coordinates, restructured (separable) sums, data-width tap accumulation
