@@ -34,8 +34,13 @@
  * (hipStreamSynchronize + hipFree + hipMalloc; not allowed under stream capture: warm the workspace
  * up with one call before capturing).  Requests above 320 MiB (the dense temporary of the float32
  * order-4/5 prefilter cascade on long lines, the fp64 line buffer of the exact filter on large
- * arrays) are stream-ordered allocations that are released when the call has enqueued its work.  Apart from that mutex-guarded
- * workspace cache the library keeps no mutable global state, so it is re-entrant and may be
+ * arrays) are stream-ordered allocations that are released when the call has enqueued its work.
+ * Next to the workspace the library keeps, per (device, stream), 64 bytes of pinned host memory into
+ * which the float32 tile kernels report how many of a call's tiles did not fit their standard LDS boxes
+ * (written by the NEXT call's first kernel, read by the host without waiting): later calls of the same
+ * geometry then start on larger boxes.  This changes speed only -- the forward result of a voxel is the
+ * same bits whichever box size or tile level served it.  Apart from these mutex-guarded per-stream
+ * caches the library keeps no mutable global state, so it is re-entrant and may be
  * called concurrently from several host threads on different streams / devices
  * (reference: single-threaded, GIL released for the whole call, deform.c:377-379).
  *
