@@ -1256,3 +1256,52 @@ def test_repeated_calls_with_spill_feedback_stay_identical():
         sl = (slice(20, 52), slice(24, 56), slice(30, 62))
         ref = orc.deform_grid(X, disp, crop=sl, **kw)
         np.testing.assert_allclose(first.cpu().numpy()[sl], ref, **F32_TOL)
+
+
+def test_channel_last_layouts_are_relaid_out_and_match_the_oracle():
+    """Deformed axes that are not the innermost ones (channel-last volumes) are transposed on the device to
+    'step axes first' and back (deform_grid._relayout_perms); same values as the oracle on the caller's
+    own layout: float32 within tolerance, integers bit-equal, gradients within the measured bound, numpy in
+    -> numpy out, lists with mixed layouts."""
+    rng = np.random.default_rng(17)
+    disp = rng.standard_normal((3, 4, 3, 4)) * 2.5
+    Xf = rng.random((40, 44, 36, 3), dtype=np.float32)              # (D, H, W, C), axis=(0, 1, 2)
+    Xi = rng.integers(0, 255, (40, 44, 36, 3)).astype(np.uint8)
+    X5 = rng.random((2, 24, 40, 36, 2), dtype=np.float32)           # step axes on both sides
+    kw = dict(order=3, mode="mirror", axis=(0, 1, 2))
+    want = orc.deform_grid(Xf, disp, **kw)
+    got = ed.deform_grid(torch.from_numpy(Xf).cuda(), torch.from_numpy(disp).cuda(), **kw)
+    assert got.is_contiguous() and tuple(got.shape) == want.shape
+    np.testing.assert_allclose(got.cpu().numpy(), want, **F32_TOL)
+    got_np = ed.deform_grid(Xf, disp, **kw)                         # numpy in -> numpy out
+    assert isinstance(got_np, np.ndarray)
+    np.testing.assert_array_equal(got_np, got.cpu().numpy())
+    # a crop, and a list that mixes a channel-last float volume with a channel-last label map
+    kwc = dict(order=[3, 1], mode=["mirror", "nearest"], axis=(0, 1, 2), crop=(slice(4, 30), slice(0, 44), slice(6, 31)))
+    wl = orc.deform_grid([Xf, Xi], disp, **kwc)
+    gl = ed.deform_grid([torch.from_numpy(Xf).cuda(), torch.from_numpy(Xi).cuda()], torch.from_numpy(disp).cuda(), **kwc)
+    np.testing.assert_allclose(gl[0].cpu().numpy(), wl[0], **F32_TOL)
+    np.testing.assert_array_equal(gl[1].cpu().numpy(), wl[1])
+    # integer volume, order 3 (integer fast path after the transpose): bit-equal
+    wi = orc.deform_grid(Xi, disp, **kw)
+    gi = ed.deform_grid(torch.from_numpy(Xi).cuda(), torch.from_numpy(disp).cuda(), **kw)
+    np.testing.assert_array_equal(gi.cpu().numpy(), wi)
+    # step axes on both sides of the deformed ones
+    kw5 = dict(order=2, mode="constant", cval=0.5, axis=(1, 2, 3))
+    w5 = orc.deform_grid(X5, disp, **kw5)
+    g5 = ed.deform_grid(torch.from_numpy(X5).cuda(), torch.from_numpy(disp).cuda(), **kw5)
+    np.testing.assert_allclose(g5.cpu().numpy(), w5, **F32_TOL)
+    # gradient, with a crop and X_shape in the caller's layout
+    kwg = dict(order=3, mode="mirror", axis=(0, 1, 2), crop=(slice(4, 30), slice(0, 44), slice(6, 31)))
+    dY = rng.random((26, 44, 25, 3), dtype=np.float32)
+    gw = orc.deform_grid_gradient(dY, disp, X_shape=Xf.shape, **kwg)
+    truth = orc.deform_grid_gradient(dY.astype(np.float64), disp, X_shape=Xf.shape, **kwg)
+    gg = ed.deform_grid_gradient(torch.from_numpy(dY).cuda(), torch.from_numpy(disp).cuda(), X_shape=Xf.shape, **kwg)
+    assert tuple(gg.shape) == Xf.shape and gg.is_contiguous()
+    _f32_grad_check(gg.cpu().numpy(), gw, truth)
+    # autograd through the wrapper
+    import elasticdeform_amd.torch as et
+    xt = torch.from_numpy(Xf).cuda().requires_grad_()
+    y = et.deform_grid(xt, torch.from_numpy(disp).cuda(), **kwg)
+    y.backward(torch.from_numpy(dY).cuda())
+    _f32_grad_check(xt.grad.cpu().numpy(), gw, truth)
