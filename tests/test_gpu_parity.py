@@ -1305,3 +1305,39 @@ def test_channel_last_layouts_are_relaid_out_and_match_the_oracle():
     y = et.deform_grid(xt, torch.from_numpy(disp).cuda(), **kwg)
     y.backward(torch.from_numpy(dY).cuda())
     _f32_grad_check(xt.grad.cpu().numpy(), gw, truth)
+
+
+def test_calls_can_be_captured_in_a_hip_graph():
+    """After one warm-up call per layout (scratch, pinned slot and kernel attributes are set up then) the
+    library only enqueues kernels on the caller's stream: a forward + gradient pair captured into a HIP graph
+    (torch.cuda.graph) replays on new data with the results of the eager calls."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(3)
+    n = 48
+    x = torch.from_numpy(rng.random((n, n, n), dtype=np.float32)).to(dev)
+    dy = torch.from_numpy(rng.random((n, n, n), dtype=np.float32)).to(dev)
+    d = torch.from_numpy(rng.standard_normal((3, 4, 4, 4)) * 2.0).to(dev)
+    kw = dict(order=3, mode="mirror")
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):                          # warm-up on the capture stream
+            ed.deform_grid(x, d, **kw)
+            ed.deform_grid_gradient(dy, d, **kw)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        y = ed.deform_grid(x, d, **kw)
+        gx = ed.deform_grid_gradient(dy, d, **kw)
+    for rep in range(3):
+        x.copy_(torch.from_numpy(rng.random((n, n, n), dtype=np.float32)))
+        dy.copy_(torch.from_numpy(rng.random((n, n, n), dtype=np.float32)))
+        d.copy_(torch.from_numpy(rng.standard_normal((3, 4, 4, 4)) * 2.0))
+        g.replay()
+        torch.cuda.synchronize()
+        y_rep, gx_rep = y.clone(), gx.clone()
+        y_eager = ed.deform_grid(x, d, **kw)
+        gx_eager = ed.deform_grid_gradient(dy, d, **kw)
+        assert torch.equal(y_rep, y_eager), rep
+        assert float((gx_rep - gx_eager).abs().max()) <= 1e-5 * float(gx_eager.abs().max()), rep

@@ -65,3 +65,28 @@ for name, fn, n in cases:
     t_lane = wall(fn, n)
     g = gpu_only(fn)
     print("%-40s general path %6.1f us   repeat-call lane %6.1f us   (GPU time of the launches %5.1f us)" % (name, t_gen, t_lane, g))
+
+# the same forward + gradient pair (library level, no autograd) captured once in a HIP graph and replayed
+print()
+for n in (32, 64, 128):
+    x = torch.rand((n, n, n), device=dev)
+    dy = torch.rand((n, n, n), device=dev)
+    d = torch.from_numpy(np.random.default_rng(33).standard_normal((3, 5, 5, 5)) * 2.5 * n / 128).to(dev)
+    kw = dict(order=3, mode="mirror")
+
+    def pair():
+        ed.deform_grid(x, d, **kw)
+        ed.deform_grid_gradient(dy, d, **kw)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            pair()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        pair()
+    t_eager = wall(pair, 1500)
+    t_graph = wall(g.replay, 1500)
+    print("%d^3 deform_grid + deform_grid_gradient: eager (repeat-call lane) %6.1f us   HIP-graph replay %6.1f us" % (n, t_eager, t_graph))
