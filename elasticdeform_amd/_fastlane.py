@@ -198,14 +198,14 @@ class Lane(object):
             if self.gradient:
                 res = []
                 for i in range(self.n):
-                    dx = torch.zeros(self.shapes[i], dtype=self.dtypes[i], device=self.dev)
+                    dx = torch.empty(self.shapes[i], dtype=self.dtypes[i], device=self.dev)      # cleared by the library
                     self.ins[i].data = dx.data_ptr()
                     self.outs[i].data = xs[i].data_ptr()
                     res.append(dx)
                 bflag = dgm._box_flag_gradient(displacement, displacement, self.dev, stream)
                 st = L.edhip_deform(1, self.n, self.ins, ctypes.byref(self.disp), a.off, self.outs, a.naxis,
-                                    a.axis, a.orders, a.modes, a.cvals, a.aff, self.flags | bflag, stream,
-                                    ebuf, 256)
+                                    a.axis, a.orders, a.modes, a.cvals, a.aff,
+                                    self.flags | bflag | _lib.FLAG_ZERO_GRADIENT, stream, ebuf, 256)
                 if st:
                     _lib.raise_for_status(st, ebuf)
                 for i, f in enumerate(self.filters):

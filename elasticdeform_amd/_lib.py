@@ -19,6 +19,7 @@ FLAG_AUTO, FLAG_EXACT, FLAG_FAST = 0, 1, 2
 FLAG_RAW_DISPLACEMENT = 4      # edhip_deform prefilters the control grid itself (<= 4096 points)
 FLAG_KEEP_BOXES = 8            # forward: leave the tiles' bounding boxes for the gradient call that follows
 FLAG_USE_BOXES = 16            # gradient: same displacement contents and geometry as that forward call
+FLAG_ZERO_GRADIENT = 32        # gradient: the library clears the (dense) accumulators itself before scattering
 RAW_DISPLACEMENT_MAX_POINTS = 4096
 
 # enum edhip_dtype

@@ -43,6 +43,7 @@
 // overlap stays inside one L2 -- and 85 MB written; algorithmic bytes are 4 + 4 per voxel.
 #include <atomic>
 #include <type_traits>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -75,6 +76,19 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     const int tid = threadIdx.x;
     const int oz = blockIdx.x;
     const int sample = blockIdx.y;        // one control grid (and one Q table) per volume of a batch
+    if (oz >= tg.out_len[0]) {
+        // spare workgroups: clear the gradient accumulators (EDHIP_FLAG_ZERO_GRADIENT) while the others
+        // compute the tables -- 64 MB in ~15 us next to an 8 us kernel instead of a 21 us launch in front of it
+        const long long nfill = (long long)(gridDim.x - tg.out_len[0]) * kBlock;
+        const long long me = (long long)(oz - tg.out_len[0]) * kBlock + tid;
+        const long long n16 = tg.zero_bytes >> 4;
+        int4* p16 = reinterpret_cast<int4*>(tg.zero_ptr);
+        for (long long i = me; i < n16; i += nfill)
+            p16[i] = make_int4(0, 0, 0, 0);
+        if (me < (tg.zero_bytes & 15))
+            tg.zero_ptr[(n16 << 4) + me] = 0;
+        return;
+    }
     const char* disp = g.disp + (int64_t)sample * tg.disp_bstride;
     const int ncpy = (int)g.ncp[1], ncpx = (int)g.ncp[2];
     const int nyx = ncpy * ncpx;
@@ -292,6 +306,10 @@ __device__ __forceinline__ double tap_fma(double w, double x, double a) { return
 // ================================================================================================
 // K1: forward
 // ================================================================================================
+// (Tried: a level-2 launch that finds only a handful of tiles on its list -- 2 of 32768 for the benchmark
+// volume -- passes them on to the direct level instead of spending a ~14 us launch on them.  The direct
+// kernel evaluates the displacement spline from the control grid for every voxel: a lone tile takes it
+// longer than level 2 does; 256^3 forward call 250 -> 263 us.)
 // ABL: compile-time ablation switches for profiling (0 in production): 1 skip staging loads,
 // 2 skip gather, 4 skip coordinates, 16 prologue only, 32 skip staging entirely, 64 skip the output store
 // (Tried: level 3 folded into the level-2 kernels -- the direct path called where a tile overflows
@@ -1257,7 +1275,17 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         }
     }
     {
-        hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0], (unsigned)nb), dim3(kBlock),
+        unsigned fill_blocks = 0;
+        tg.zero_ptr = nullptr;
+        tg.zero_bytes = 0;
+        if (GRAD && batch && batch->zero_ptr && !batch->zero_done && nb == 1 && ((uintptr_t)batch->zero_ptr & 15) == 0) {
+            tg.zero_ptr = batch->zero_ptr;
+            tg.zero_bytes = batch->zero_bytes;
+            const long long want = (batch->zero_bytes + 65535) / 65536;       // 64 KiB per workgroup and round
+            fill_blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+            batch->zero_done = true;
+        }
+        hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0] + fill_blocks, (unsigned)nb), dim3(kBlock),
                            sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
         e = hipGetLastError();
     }

@@ -298,6 +298,10 @@ struct TileGeom {
     int* hint;
     unsigned long long* hint_host;
     unsigned hint_seq;
+    // EDHIP_FLAG_ZERO_GRADIENT: the tables kernel's blocks beyond out_len[0] clear this block (16-byte
+    // aligned start, any length)
+    char* zero_ptr;
+    long long zero_bytes;
     int* label_list;      // label kernel: [0] = count, [1..cap] = linear ids of near-tie voxels (or nullptr)
     int label_cap;
     const int* worklist;  // second-level pass: [0] = count, [1..] = tile ids to process (else nullptr)

@@ -205,6 +205,41 @@ const char* edhip_status_string(int status)
     }
 }
 
+// the array's elements form one contiguous block (any axis order, no gaps, no overlap): its start and size
+static bool dense_block(const edhip_array& a, char** ptr, long long* bytes)
+{
+    const long long esz = dtype_size(a.dtype);
+    if (esz <= 0)
+        return false;
+    int order[EDHIP_MAX_DIMS], n = 0;
+    long long total = esz;
+    for (int d = 0; d < a.ndim; ++d) {
+        if (a.shape[d] == 0) {
+            *ptr = (char*)a.data;
+            *bytes = 0;
+            return true;
+        }
+        total *= a.shape[d];
+        if (a.shape[d] > 1)
+            order[n++] = d;
+    }
+    for (int i = 1; i < n; ++i)            // by ascending stride
+        for (int j = i; j > 0 && a.stride_bytes[order[j]] < a.stride_bytes[order[j - 1]]; --j) {
+            const int t = order[j];
+            order[j] = order[j - 1];
+            order[j - 1] = t;
+        }
+    long long expect = esz;
+    for (int i = 0; i < n; ++i) {
+        if (a.stride_bytes[order[i]] != expect)
+            return false;
+        expect *= a.shape[order[i]];
+    }
+    *ptr = (char*)a.data;
+    *bytes = total;
+    return true;
+}
+
 int edhip_device_count(void)
 {
     int n = 0;
@@ -278,8 +313,25 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         if (st != EDHIP_OK)
             return st;
     }
-    if (g.nvox <= 0)
+    // EDHIP_FLAG_ZERO_GRADIENT: the dense blocks to clear (checked for every input before anything is enqueued)
+    const bool zero = gradient && (flags & EDHIP_FLAG_ZERO_GRADIENT);
+    char* zero_ptr[EDHIP_MAX_INPUTS];
+    long long zero_bytes[EDHIP_MAX_INPUTS];
+    if (zero) {
+        for (int i = 0; i < ninputs; ++i)
+            if (!dense_block(inputs[i], &zero_ptr[i], &zero_bytes[i]))
+                return fail(err, errlen, EDHIP_ERR_INVALID, "EDHIP_FLAG_ZERO_GRADIENT needs dense gradient arrays");
+    }
+    auto clear_now = [&](int i) -> hipError_t {
+        return zero_bytes[i] > 0 ? hipMemsetAsync(zero_ptr[i], 0, (size_t)zero_bytes[i], stream) : hipSuccess;
+    };
+    if (g.nvox <= 0) {
+        if (zero)
+            for (int i = 0; i < ninputs; ++i)
+                if (clear_now(i) != hipSuccess)
+                    return fail(err, errlen, EDHIP_ERR_DEVICE, "clearing the gradient arrays failed");
         return EDHIP_OK;
+    }
 
     // ---- one launch per input/output pair -----------------------------------------------------------
     for (int i = 0; i < ninputs; ++i) {
@@ -292,8 +344,11 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
             if (st != EDHIP_OK)
                 return st;
         }
-        if (v.nsteps <= 0)
+        if (v.nsteps <= 0) {
+            if (zero && clear_now(i) != hipSuccess)
+                return fail(err, errlen, EDHIP_ERR_DEVICE, "clearing the gradient arrays failed");
             continue;
+        }
 
         bool use_fast;
         if (flags & EDHIP_FLAG_EXACT)
@@ -308,14 +363,19 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
                                in.dtype != EDHIP_F64 && deform_label_supported(g, v, gradient);
         // 8- / 16-bit integer volumes, orders 1-5: bit-equal as well (near-tie voxels redone exactly)
         const bool use_int = !(flags & EDHIP_FLAG_EXACT) && !use_fast && !use_label && deform_int_supported(g, v, gradient);
-        hipError_t e;
-        if (use_label)
+        hipError_t e = hipSuccess;
+        const bool tile = !use_label && !use_int && use_fast && deform_tile_supported(g, v, gradient != 0);
+        if (zero && !tile)
+            e = clear_now(i);
+        if (e != hipSuccess)
+            ;
+        else if (use_label)
             e = launch_deform_label(g, v, stream);
         else if (use_int)
             e = launch_deform_int(g, v, stream);
         else if (!use_fast)
             e = launch_deform_exact(g, v, gradient != 0, stream);
-        else if (deform_tile_supported(g, v, gradient != 0)) {
+        else if (tile) {
             DeformBatch one;
             one.nbatch = 1;
             one.in_bstride = one.out_bstride = one.disp_bstride = 0;
@@ -325,7 +385,17 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
             one.raw = (flags & EDHIP_FLAG_RAW_DISPLACEMENT) ? 1 : 0;
             // (several inputs share the geometry: the boxes are those of the last forward launch,
             // which is what a gradient call with the same inputs reads them for)
+            if (zero) {
+                one.zero_ptr = zero_ptr[i];
+                one.zero_bytes = zero_bytes[i];
+            }
             e = launch_deform_tile(g, v, gradient != 0, stream, &one);
+            // (the tile path either cleared the block in its tables launch or has not touched it yet)
+            if (zero && !one.zero_done && (e == hipSuccess || e == hipErrorNotSupported)) {
+                const hipError_t ce = clear_now(i);
+                if (e == hipSuccess)
+                    e = ce;
+            }
         }
         else
             e = launch_deform_fast(g, v, gradient != 0, stream);
@@ -348,6 +418,18 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
     if (nbatch == 0)
         return EDHIP_OK;          // nothing to do (and no descriptor to read)
     ed::StreamGuard guard((hipStream_t)hip_stream);
+    if (gradient && (flags & EDHIP_FLAG_ZERO_GRADIENT)) {
+        // batches: cleared up front, item by item (the single-launch path below shares one tables launch)
+        for (int b = 0; b < nbatch; ++b) {
+            char* zp = nullptr;
+            long long zb = 0;
+            if (!dense_block(inputs[b], &zp, &zb))
+                return fail(err, errlen, EDHIP_ERR_INVALID, "EDHIP_FLAG_ZERO_GRADIENT needs dense gradient arrays");
+            if (zb > 0 && hipMemsetAsync(zp, 0, (size_t)zb, (hipStream_t)hip_stream) != hipSuccess)
+                return fail(err, errlen, EDHIP_ERR_DEVICE, "clearing the gradient arrays failed");
+        }
+        flags &= ~(uint32_t)EDHIP_FLAG_ZERO_GRADIENT;
+    }
     // ---- one set of launches for the whole batch (the strip index of the tile kernels carries the
     //      sample): same-shaped float volumes at a constant distance, one prefiltered grid each ------
     {

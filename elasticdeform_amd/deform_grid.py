@@ -542,8 +542,9 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         dY_dev = [_to_device(dy, device) for dy in dYs]
         wide = [_widen(dy, int(plan.order[i]), prefilter) for i, dy in enumerate(dY_dev)]
         dYd = [w if w is not None else dy for w, dy in zip(wide, dY_dev)]
-        # gradient accumulators start at zero (deform_grid.py:243)
-        dXs = [torch.zeros(tuple(int(v) for v in s), dtype=dy.dtype, device=device)
+        # gradient accumulators start at zero (deform_grid.py:243): cleared by the library next to its
+        # tables kernel (EDHIP_FLAG_ZERO_GRADIENT) instead of by a fill launch of their own
+        dXs = [torch.empty(tuple(int(v) for v in s), dtype=dy.dtype, device=device)
                for s, dy in zip(X_shape, dYd)]
 
         dd = _to_device(displacement, device)
@@ -552,7 +553,8 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         stream = _stream(device)
         _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
                     [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine, _flags | dflag | _box_flag_gradient(displacement, df, device, stream),
+                    plan.inverse_affine,
+                    _flags | dflag | _lib.FLAG_ZERO_GRADIENT | _box_flag_gradient(displacement, df, device, stream),
                     stream, prepared=_prepared(plan, len(dXs)))
 
         # gradient of the prefilter: its transpose along each deformed axis (deform_grid.py:276-286).

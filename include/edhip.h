@@ -134,7 +134,14 @@ enum edhip_flags {
      * the buffer instead of computing every window twice.  The boxes are a HINT: a voxel whose window
      * does not lie in its tile's box is scattered straight to global memory, so a broken promise
      * costs time, never correctness. */
-    EDHIP_FLAG_USE_BOXES = 16
+    EDHIP_FLAG_USE_BOXES = 16,
+    /* gradient = 1: the library clears the gradient accumulators (`inputs`) itself before it scatters
+     * into them -- the reference's numpy.zeros (deform_grid.py:243) -- so the caller may hand over
+     * uninitialised memory.  The arrays must be dense (their elements one contiguous block, in any axis
+     * order); float32 volumes on the tile kernels get the fill from spare workgroups of the per-call tables
+     * launch (it overlaps that kernel instead of being a bandwidth-bound launch of its own), every other
+     * route a hipMemsetAsync.  Without the flag the accumulators are added to as they are. */
+    EDHIP_FLAG_ZERO_GRADIENT = 32
 };
 
 /* strided N-d array in device memory: the POD stand-in for PyArrayObject* */

@@ -1341,3 +1341,41 @@ def test_calls_can_be_captured_in_a_hip_graph():
         gx_eager = ed.deform_grid_gradient(dy, d, **kw)
         assert torch.equal(y_rep, y_eager), rep
         assert float((gx_rep - gx_eager).abs().max()) <= 1e-5 * float(gx_eager.abs().max()), rep
+
+
+def test_zero_gradient_flag_clears_dense_accumulators_on_every_route():
+    """EDHIP_FLAG_ZERO_GRADIENT: the library clears the gradient accumulators itself (next to the tables
+    kernel on the float32 tile path, a memset elsewhere).  Buffers pre-filled with garbage must come out as
+    the gradient; without the flag the call accumulates; a non-dense accumulator is refused."""
+    from elasticdeform_amd import _lib
+    import importlib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(8)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    cases = [((40, 36, 44), (3, 3, 3, 3), np.float32, 3, (0, 1, 2)),        # tile path (hot kernels)
+             ((40, 36, 44), (3, 3, 3, 3), np.float64, 3, (0, 1, 2)),        # tile path (general kernels)
+             ((3, 40, 44), (2, 3, 3), np.float32, 3, (1, 2)),               # 2-D fast path, channel axis
+             ((500,), (1, 5), np.float32, 1, (0,)),                         # 1-D
+             ((12, 10, 9, 8), (4, 2, 2, 2, 2), np.float32, 1, (0, 1, 2, 3))]    # 4 axes: exact kernels
+    for shape, dshape, dt, order, axes in cases:
+        dY = torch.from_numpy(rng.random(shape).astype(dt)).to(dev)
+        d = torch.from_numpy(rng.standard_normal(dshape) * 1.5).to(dev)
+        want = ed.deform_grid_gradient(dY, d, order=order, mode="mirror", axis=axes, prefilter=False)
+        for garbage in (7.0, float("nan")):
+            dX = torch.full(shape, garbage, dtype=dY.dtype, device=dev)
+            _lib.deform(True, [dgm._desc(dX)], dgm._desc(d), None, [dgm._desc(dY)], [axes], [order], [3], [0.0], None,
+                        _lib.FLAG_AUTO | _lib.FLAG_RAW_DISPLACEMENT | _lib.FLAG_ZERO_GRADIENT, stream)
+            scale = max(1.0, float(want.abs().max()))
+            assert float((dX - want).abs().max()) <= 1e-5 * scale, (shape, garbage)
+        acc = torch.full(shape, 2.0, dtype=dY.dtype, device=dev)        # no flag: adds to what is there
+        _lib.deform(True, [dgm._desc(acc)], dgm._desc(d), None, [dgm._desc(dY)], [axes], [order], [3], [0.0], None,
+                    _lib.FLAG_AUTO | _lib.FLAG_RAW_DISPLACEMENT, stream)
+        assert float((acc - 2.0 - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), shape
+    # a strided (non-dense) accumulator is refused
+    big = torch.zeros((40, 36, 88), dtype=torch.float32, device=dev)
+    dY = torch.rand((40, 36, 44), device=dev)
+    d = torch.zeros((3, 3, 3, 3), dtype=torch.float64, device=dev)
+    with pytest.raises(Exception):
+        _lib.deform(True, [dgm._desc(big[:, :, ::2])], dgm._desc(d), None, [dgm._desc(dY)], [(0, 1, 2)], [3], [3], [0.0],
+                    None, _lib.FLAG_AUTO | _lib.FLAG_RAW_DISPLACEMENT | _lib.FLAG_ZERO_GRADIENT, stream)

@@ -46,6 +46,7 @@ def test_header_constants_match_the_python_binding():
     assert enums["EDHIP_FLAG_RAW_DISPLACEMENT"] == _lib.FLAG_RAW_DISPLACEMENT
     assert enums["EDHIP_FLAG_KEEP_BOXES"] == _lib.FLAG_KEEP_BOXES
     assert enums["EDHIP_FLAG_USE_BOXES"] == _lib.FLAG_USE_BOXES
+    assert enums["EDHIP_FLAG_ZERO_GRADIENT"] == _lib.FLAG_ZERO_GRADIENT
     flags = [v for k, v in enums.items() if k.startswith("EDHIP_FLAG_") and v]
     assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)     # distinct bits
     assert defs["EDHIP_MAX_DIMS"] == _lib.MAX_DIMS and defs["EDHIP_MAX_AXES"] == _lib.MAX_AXES
