@@ -46,6 +46,7 @@ struct SpillHint {
 
     void absorb();                                  // fold the latest report into the table
     float fraction(unsigned long long key) const;   // last known spilled fraction for a geometry, or 0
+    bool known(unsigned long long key) const;       // a report for this geometry has arrived
     unsigned begin_call(unsigned long long key, unsigned tiles);   // -> this call's sequence number
 };
 SpillHint* spill_hint(hipStream_t stream);          // nullptr when pinned memory is not available

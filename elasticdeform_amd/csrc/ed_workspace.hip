@@ -221,6 +221,14 @@ float SpillHint::fraction(unsigned long long key) const
     return 0.f;
 }
 
+bool SpillHint::known(unsigned long long key) const
+{
+    for (int t = 0; t < ntable; ++t)
+        if (table[t].key == key)
+            return true;
+    return false;
+}
+
 unsigned SpillHint::begin_call(unsigned long long key, unsigned tiles)
 {
     seq = seq + 1 ? seq + 1 : 1;

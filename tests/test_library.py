@@ -151,3 +151,21 @@ def test_shipped_library_has_no_environment_switches():
     blob = open(lib, "rb").read()
     for name in (b"EDHIP_HOT_ABL", b"EDHIP_TILE_DBG", b"EDHIP_GRAD_DUO", b"EDHIP_WAVE"):
         assert name not in blob, name
+
+
+def test_spill_feedback_bookkeeping_host_logic(tmp_path):
+    """SpillHint (csrc/ed_workspace.h): the per-stream ring of calls and table of geometries behind the
+    level-1 spill feedback, driven from a host-only C++ program (no GPU, no HIP call): reports are matched
+    by sequence number, consumed once, garbage and stale reports ignored, old geometries forgotten."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "elasticdeform_amd", "csrc")
+    exe = str(tmp_path / "spill_hint_test")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-w", "-I" + csrc,
+                    "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx", "spill_hint_test.cpp"),
+                    os.path.join(csrc, "ed_workspace.hip"), "-o", exe], check=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
