@@ -1299,6 +1299,15 @@ def test_channel_last_layouts_are_relaid_out_and_match_the_oracle():
     gg = ed.deform_grid_gradient(torch.from_numpy(dY).cuda(), torch.from_numpy(disp).cuda(), X_shape=Xf.shape, **kwg)
     assert tuple(gg.shape) == Xf.shape and gg.is_contiguous()
     _f32_grad_check(gg.cpu().numpy(), gw, truth)
+    # 2-D colour images (H, W, 3) with a rotation and a zoom (the affine is built on the deformed axes)
+    img = rng.random((300, 260, 3), dtype=np.float32)
+    lab = rng.integers(0, 255, (300, 260, 3)).astype(np.uint8)
+    d2 = rng.standard_normal((2, 3, 3)) * 6.0
+    kw2 = dict(order=[3, 1], mode="mirror", axis=(0, 1), rotate=12.0, zoom=1.1)
+    w2 = orc.deform_grid([img, lab], d2, **kw2)
+    g2 = ed.deform_grid([torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()], torch.from_numpy(d2).cuda(), **kw2)
+    np.testing.assert_allclose(g2[0].cpu().numpy(), w2[0], **F32_TOL)
+    np.testing.assert_array_equal(g2[1].cpu().numpy(), w2[1])
     # autograd through the wrapper
     import elasticdeform_amd.torch as et
     xt = torch.from_numpy(Xf).cuda().requires_grad_()
