@@ -217,3 +217,27 @@ def test_repeat_call_lane_only_recognises_device_tensors():
     assert _fastlane.signature(False, (x,), d, *args) is None
     assert _fastlane._hashable([3, 1]) == _fastlane._hashable([3, 1]) != _fastlane._hashable((3, 1))
     assert _fastlane._crop_key((slice(1, 5), slice(None))) == ((1, 5, None), (None, None, None))
+
+
+def test_relayout_permutations_for_non_innermost_deformed_axes():
+    """deform_grid._relayout_perms: which inputs are transposed to 'step axes first' (pure host logic)."""
+    import importlib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    S = _host.ShapeOnly
+    disp = np.zeros((3, 3, 3, 3))
+
+    def perms(shapes, axis, order=3):
+        xs = [S(s) for s in shapes]
+        return dgm._relayout_perms(_host.Plan(xs, disp, order, 'constant', 0.0, None, axis, None, None, None), xs)
+    big = (64, 64, 64)
+    assert perms([big], None) is None                                         # all axes deformed
+    assert perms([(4,) + big], (1, 2, 3)) is None                             # channel-first: already trailing
+    assert perms([big + (4,)], (0, 1, 2)) == [[3, 0, 1, 2]]                   # channel-last
+    assert perms([(2,) + big + (3,)], (1, 2, 3)) == [[0, 4, 1, 2, 3]]         # step axes on both sides
+    assert perms([big + (4,), (4,) + big], [(0, 1, 2), (1, 2, 3)]) == [[3, 0, 1, 2], None]
+    assert perms([(8, 8, 8, 4)], (0, 1, 2)) is None                           # small: not worth two transposes
+    assert perms([big + (4,)], (0, 1, 2), order=0) is None                    # order 0: one strided load either way
+    assert perms([big + (4,), big + (4,)], (0, 1, 2), order=[0, 3]) == [None, [3, 0, 1, 2]]
+    for p in ([3, 0, 1, 2], [0, 4, 1, 2, 3]):
+        inv = dgm._inverse_perm(p)
+        assert [p[i] for i in inv] == list(range(len(p))) and [inv[a] for a in p] == list(range(len(p)))
