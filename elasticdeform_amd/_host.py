@@ -314,6 +314,10 @@ def prefilter_window(box, in_shape, axes, order, slack_last=0):
         n = int(in_shape[a])
         extra = slack_last if k == len(box) - 1 else 0
         w0, w1 = max(0, lo - max(m, extra)), min(n, hi + 1 + max(m, extra))
+        if k == len(box) - 1:
+            # rows of the window start and end on 16-byte boundaries of the array's rows, so that the
+            # whole-line tile kernels move them as vectors (an odd start sent every pass to the scalar variants)
+            w0, w1 = w0 & ~3, min(n, (w1 + 3) & ~3)
         win.append((w0, w1))
         sub *= w1 - w0
         full *= n

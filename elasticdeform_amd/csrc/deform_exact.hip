@@ -450,8 +450,103 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
     return hipGetLastError();
 }
 
-hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream)
+// The conservative form: a B-spline is a convex combination of its coefficients (the cubic basis is
+// non-negative and sums to one), so over the output box the displacement component h stays inside
+// [min, max] of the (prefiltered) control points whose basis functions reach the box, and the affine part
+// is extremal at the box's corners.  One workgroup walks the control points -- O(grid) instead of the
+// O(voxels) of source_box_kernel (933 us for a 256^3 output): floor / ceil of that hull, a superset of
+// the exact box (a few samples wider for the grids elastic deformation uses).
+__global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, int* box)
 {
+    __shared__ double smin[kMaxAxes][4], smax[kMaxAxes][4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int naxis = g.naxis;
+    // control-point index range per axis whose basis functions reach the output box
+    int64_t lo_i[kMaxAxes], n_i[kMaxAxes], total = 1;
+    for (int k = 0; k < naxis; ++k) {
+        const double c0 = control_coordinate(g.ncp[k], g.off[k], g.in_len[k]);
+        const double c1 = control_coordinate(g.ncp[k], g.out_len[k] - 1 + g.off[k], g.in_len[k]);
+        int64_t a = (int64_t)floor(c0 < c1 ? c0 : c1) - 1, b = (int64_t)floor(c0 < c1 ? c1 : c0) + 2;
+        // indices beyond the grid mirror back into it: widen the range by what sticks out, then clip
+        if (a < 0) {
+            b = b > -a ? b : -a;
+            a = 0;
+        }
+        if (b > g.ncp[k] - 1) {
+            const int64_t over = b - (g.ncp[k] - 1);
+            a = a < g.ncp[k] - 1 - over ? a : g.ncp[k] - 1 - over;
+            b = g.ncp[k] - 1;
+        }
+        a = a < 0 ? 0 : a;
+        if (!(c0 == c0) || !(c1 == c1)) {      // (cannot happen for in_len >= 2; be safe)
+            a = 0;
+            b = g.ncp[k] - 1;
+        }
+        lo_i[k] = a;
+        n_i[k] = b - a + 1;
+        total *= n_i[k];
+    }
+    for (int h = 0; h < naxis; ++h) {
+        double mn = 1e300, mx = -1e300;
+        for (int64_t e = tid; e < total; e += 256) {
+            int64_t r = e, off = g.disp_stride[0] * h;
+            for (int k = naxis - 1; k >= 0; --k) {
+                const int64_t q = r / n_i[k];
+                off += (lo_i[k] + (r - q * n_i[k])) * g.disp_stride[k + 1];
+                r = q;
+            }
+            const double v = load_as_double(g.disp + off, g.disp_dtype);
+            if (v == v) {                       // NaN grid entries: no constraint (like the exact kernel)
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+            }
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double a = __shfl_xor(mn, m), b = __shfl_xor(mx, m);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if ((tid & 63) == 0) {
+            smin[h][wave] = mn;
+            smax[h][wave] = mx;
+        }
+    }
+    __syncthreads();
+    if (tid < naxis) {
+        const int h = tid;
+        double mn = smin[h][0], mx = smax[h][0];
+        for (int w = 1; w < 4; ++w) {
+            mn = smin[h][w] < mn ? smin[h][w] : mn;
+            mx = smax[h][w] > mx ? smax[h][w] : mx;
+        }
+        if (mn > mx)
+            mn = mx = 0.0;                      // every entry NaN
+        double blo, bhi;
+        if (g.has_affine) {
+            blo = bhi = g.affine[h * (naxis + 1) + naxis];
+            for (int l = 0; l < naxis; ++l) {
+                const double t = g.affine[h * (naxis + 1) + l] * (double)(g.out_len[l] - 1);
+                blo += t < 0.0 ? t : 0.0;
+                bhi += t > 0.0 ? t : 0.0;
+            }
+        } else {
+            blo = 0.0;
+            bhi = (double)(g.out_len[h] - 1);
+        }
+        double lo = blo + (double)g.off[h] + mn, hi = bhi + (double)g.off[h] + mx;
+        lo = !(lo == lo) ? -1e9 : (lo < -1e9 ? -1e9 : (lo > 1e9 ? 1e9 : lo));
+        hi = !(hi == hi) ? 1e9 : (hi < -1e9 ? -1e9 : (hi > 1e9 ? 1e9 : hi));
+        box[2 * h] = (int)floor(lo) - 1;        // (one sample for the rounding of the sums above)
+        box[2 * h + 1] = (int)ceil(hi) + 1;
+    }
+}
+
+hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream, bool conservative)
+{
+    if (conservative && g.nvox > 0) {
+        hipLaunchKernelGGL(source_box_hull_kernel, dim3(1), dim3(256), 0, stream, g, box);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(source_box_init_kernel, dim3(1), dim3(64), 0, stream, box, g.naxis);
     if (g.nvox <= 0)
         return hipGetLastError();

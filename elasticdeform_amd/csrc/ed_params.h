@@ -54,7 +54,8 @@ hipError_t launch_deform_exact_list(const GridGeom& g, const IOView& v, const in
 
 // edhip_source_box: box[2h] = floor(min), box[2h+1] = ceil(max) of the raw (unmapped) source
 // coordinate along axis h over every output voxel; `box` = 2 * naxis device ints
-hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream);
+// conservative: the convex hull of the control coefficients (a superset of the exact box, O(grid points))
+hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream, bool conservative = false);
 
 // fast path: returns hipErrorNotSupported (without launching) when the case is outside its
 // envelope so that the caller can route it to the exact kernels instead.

@@ -569,7 +569,7 @@ int edhip_source_box(const edhip_array* displacement, const int64_t* in_len, con
     if (!ws)
         return hip_fail(err, errlen, e, "scratch allocation");
     int* dbox = (int*)(ws + kWorkspaceGridBytes - 64);
-    e = launch_source_box(g, dbox, stream);
+    e = launch_source_box(g, dbox, stream, (flags & EDHIP_FLAG_FAST) != 0);
     if (e == hipErrorNotSupported)
         return fail(err, errlen, EDHIP_ERR_UNSUPPORTED,
                     "edhip_source_box: control grids are limited to 7680 values and 4 deformed axes");

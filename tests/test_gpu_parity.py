@@ -445,6 +445,8 @@ def test_crop_aware_prefilter_matches_whole_volume(mode, dtype):
     orig = dgm._crop_windows
     saving = dgm.CROP_WINDOW_MIN_SAVING
     dgm.CROP_WINDOW_MIN_SAVING = 0.0        # small test volumes: engage regardless of the pay-off
+    fraction = dgm.CROP_WINDOW_MAX_FRACTION
+    dgm.CROP_WINDOW_MAX_FRACTION = 1.0
 
     def spy(*a, **k):
         w = orig(*a, **k)
@@ -454,7 +456,10 @@ def test_crop_aware_prefilter_matches_whole_volume(mode, dtype):
     try:
         cases = [
             # shape, axis, points, sigma, crop, affine
-            ((150, 160, 170), None, (3, 3, 3), 3.0, (slice(60, 84), slice(70, 90), slice(80, 110)), None),
+            # (sigma 0.5: the window comes from the convex hull of the control coefficients -- +-10 voxels here,
+            # the prefiltered coefficients of a random grid are ~20x its sigma -- and a stronger grid on this small
+            # volume leaves less than 40 % to save)
+            ((150, 160, 170), None, (3, 3, 3), 0.5, (slice(60, 84), slice(70, 90), slice(80, 110)), None),
             ((2, 140, 150, 160), (1, 2, 3), (4, 3, 3), 2.0, (slice(5, 30), slice(100, 130), slice(60, 90)), "rot"),
             ((700, 900), None, (3, 3), 6.0, (slice(300, 360), slice(400, 480)), None),
             ((150, 160, 170), None, (3, 3, 3), 3.0, (slice(0, 20), slice(140, 160), slice(75, 95)), None),
@@ -496,6 +501,7 @@ def test_crop_aware_prefilter_matches_whole_volume(mode, dtype):
     finally:
         dgm._crop_windows = orig
         dgm.CROP_WINDOW_MIN_SAVING = saving
+        dgm.CROP_WINDOW_MAX_FRACTION = fraction
 
 
 def test_source_box_kernel_vs_oracle_coordinates():
@@ -514,6 +520,8 @@ def test_source_box_kernel_vs_oracle_coordinates():
     A = np.array([[1.1, 0.05, 0, -3.0], [0, 0.9, 0.1, 2.0], [0.02, 0, 1.0, 1.0]])
     for aff in (None, A):
         box = _lib.source_box(dgm._desc(dd), in_len, out_len, off, aff, _lib.FLAG_RAW_DISPLACEMENT, stream)
+        hull = _lib.source_box(dgm._desc(dd), in_len, out_len, off, aff, _lib.FLAG_RAW_DISPLACEMENT | _lib.FLAG_FAST,
+                               stream)
         o = np.stack(np.meshgrid(*[np.arange(n, dtype=np.float64) for n in out_len], indexing="ij"))
         cp = [(disp.shape[k + 1] - 1) * (o[k] + off[k]) / (in_len[k] - 1) for k in range(3)]
         for h in range(3):
@@ -521,6 +529,13 @@ def test_source_box_kernel_vs_oracle_coordinates():
             base = o[h] if aff is None else sum(aff[h, l] * o[l] for l in range(3)) + aff[h, 3]
             c = base + off[h] + d
             assert box[h, 0] == np.floor(c.min()) and box[h, 1] == np.ceil(c.max()), (h, box[h], c.min(), c.max())
+            # EDHIP_FLAG_FAST: the convex hull of the control coefficients -- contains the exact box, and for a
+            # grid like this one stays within the displacement's own amplitude of it
+            assert hull[h, 0] <= box[h, 0] and hull[h, 1] >= box[h, 1], (h, hull[h], box[h])
+            # ... and is no wider than the hull of ALL prefiltered coefficients (it uses those that reach the box)
+            coef = scipy.ndimage.spline_filter(disp[h], order=3, mode="mirror")
+            assert hull[h, 0] >= np.floor(base.min() + off[h] + coef.min()) - 2, (h, hull[h], coef.min())
+            assert hull[h, 1] <= np.ceil(base.max() + off[h] + coef.max()) + 2, (h, hull[h], coef.max())
 
 
 def test_device_side_random_grid():
