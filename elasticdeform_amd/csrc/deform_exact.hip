@@ -456,6 +456,8 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
 // is extremal at the box's corners.  One workgroup walks the control points -- O(grid) instead of the
 // O(voxels) of source_box_kernel (933 us for a 256^3 output): floor / ceil of that hull, a superset of
 // the exact box (a few samples wider for the grids elastic deformation uses).
+constexpr int kHullCap = 4096;          // doubles per refinement buffer
+
 __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, int* box)
 {
     __shared__ double smin[kMaxAxes][4], smax[kMaxAxes][4];
@@ -486,8 +488,101 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
         n_i[k] = b - a + 1;
         total *= n_i[k];
     }
+    // Subdivision (Lane-Riesenfeld, cubic): every level halves the knot spacing -- new points
+    // (c[j] + 6 c[j+1] + c[j+2]) / 8 and (c[j+1] + c[j+2]) / 2 -- and the spline stays the same, so the hull of
+    // the refined points that reach the output box is still a superset, four times closer per level.  For a
+    // random 5^3 grid the raw hull is 9x wider than the displacement's true range over a half-size crop, after
+    // two levels 1.2x (profiles/r03_design_sims.txt).  Between levels every axis is trimmed to the points
+    // within three spacings of the box, so the refined block stays small; up to two levels, as many as fit
+    // the two 32 KiB buffers (large crops of fine grids: fewer levels, then the raw hull below).
+    __shared__ double sbuf[2][kHullCap];
+    double c0[kMaxAxes], c1[kMaxAxes];
+    for (int k = 0; k < naxis; ++k) {
+        const double a = control_coordinate(g.ncp[k], g.off[k], g.in_len[k]);
+        const double b = control_coordinate(g.ncp[k], g.out_len[k] - 1 + g.off[k], g.in_len[k]);
+        c0[k] = a < b ? a : b;
+        c1[k] = a < b ? b : a;
+    }
+    int levels = -1;
+    for (int L = 2; L >= 0 && levels < 0; --L) {
+        double t = 1.0;
+        bool ok = naxis <= 4;
+        for (int k = 0; k < naxis; ++k) {
+            if (!(c0[k] == c0[k]) || !(c1[k] == c1[k]) || c1[k] - c0[k] > 1e6)
+                ok = false;
+            else
+                t *= ceil((c1[k] - c0[k]) * (double)(1 << L)) + 9.0;      // bound of an axis' points at any step
+        }
+        if (ok && t <= (double)kHullCap)
+            levels = L;
+    }
     for (int h = 0; h < naxis; ++h) {
         double mn = 1e300, mx = -1e300;
+        if (levels >= 0) {
+            int n[4] = {1, 1, 1, 1};
+            double T[4] = {0, 0, 0, 0}, hs[4] = {1, 1, 1, 1};
+            int tot = 1;
+            for (int k = 0; k < naxis; ++k) {
+                const int lo = (int)floor(c0[k]) - 3;
+                n[k] = (int)floor(c1[k]) + 4 - lo + 1;
+                T[k] = (double)lo;
+                tot *= n[k];
+            }
+            int cur = 0;
+            for (int e = tid; e < tot; e += 256) {          // level 0: the mirror-extended coefficients
+                int r = e;
+                int64_t off = g.disp_stride[0] * h;
+                for (int k = naxis - 1; k >= 0; --k) {
+                    const int q = r / n[k];
+                    off += mirror_index((int64_t)T[k] + (r - q * n[k]), g.ncp[k]) * g.disp_stride[k + 1];
+                    r = q;
+                }
+                sbuf[0][e] = load_as_double(g.disp + off, g.disp_dtype);
+            }
+            __syncthreads();
+            for (int l = 0; l < levels; ++l) {
+                for (int ax = 0; ax < naxis; ++ax) {
+                    const int na = n[ax];
+                    const double Tn = T[ax] + hs[ax], hn = 0.5 * hs[ax];
+                    const int nb = 2 * na - 5;
+                    int ia = (int)floor((c0[ax] - 3.0 * hn - Tn) / hn), ib = (int)ceil((c1[ax] + 3.0 * hn - Tn) / hn);
+                    ia = ia < 0 ? 0 : ia;
+                    ib = ib > nb - 1 ? nb - 1 : ib;
+                    const int nn = ib - ia + 1;
+                    int sA = 1;                              // stride of `ax` in the source block (last axis fastest)
+                    for (int k = naxis - 1; k > ax; --k)
+                        sA *= n[k];
+                    int inner = sA, tot_out = 1;
+                    for (int k = 0; k < naxis; ++k)
+                        tot_out *= k == ax ? nn : n[k];
+                    const double* A = sbuf[cur];
+                    double* B = sbuf[cur ^ 1];
+                    for (int e = tid; e < tot_out; e += 256) {
+                        const int in_idx = e % inner;                    // axes after ax
+                        const int r = e / inner;
+                        const int m = ia + r % nn;                       // refined index along ax
+                        const int outer = r / nn;                        // axes before ax
+                        const int j = m >> 1;
+                        const double* a = A + ((size_t)outer * na + j) * inner + in_idx;
+                        B[e] = (m & 1) ? 0.5 * (a[sA] + a[2 * sA]) : 0.125 * (a[0] + 6.0 * a[sA] + a[2 * sA]);
+                    }
+                    __syncthreads();
+                    cur ^= 1;
+                    n[ax] = nn;
+                    T[ax] = Tn + ia * hn;
+                    hs[ax] = hn;
+                    tot = tot_out;
+                }
+            }
+            for (int e = tid; e < tot; e += 256) {
+                const double v = sbuf[cur][e];
+                if (v == v) {                   // NaN grid entries: no constraint (like the exact kernel)
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+            }
+            __syncthreads();                    // the next component reuses the buffers
+        } else
         for (int64_t e = tid; e < total; e += 256) {
             int64_t r = e, off = g.disp_stride[0] * h;
             for (int k = naxis - 1; k >= 0; --k) {

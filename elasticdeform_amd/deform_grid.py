@@ -263,12 +263,11 @@ def _filter_axes(x, axes, order, transpose, device, overwrite=False, stream=None
 # box to the host), which exposes ~0.25 ms of host-side launch latency: about what filtering
 # 48M float32 voxels along three axes costs on an MI355X.
 CROP_WINDOW_MIN_SAVING = 48e6
-# ... and only when the output box plus the filter margins is at most this fraction of the input: the window
-# is sized from the convex hull of the control coefficients (edhip_source_box with EDHIP_FLAG_FAST), which
-# for random grids is several times wider than the displacement itself, so larger crops end up filtering
-# nearly everything after having paid the synchronisation (512^3, measured: crop 128^3 forward 745 -> 577 us,
-# crop 256^3 913 -> 979 us, crop 320^3 1076 -> 1151 us; profiles/r03_bench_misc.txt)
-CROP_WINDOW_MAX_FRACTION = 0.10
+# ... and only when the output box plus the filter margins is at most this fraction of the input: beyond it
+# the window's passes + the read-back's synchronisation cost more than they save (512^3 float32 order 3,
+# window / whole volume: crop 128^3 forward 272 / 722 us, crop 256^3 735 / 885 us, crop 320^3 1161 / 1061 us;
+# profiles/r03_bench_misc.txt)
+CROP_WINDOW_MAX_FRACTION = 0.30
 
 
 def _crop_windows(plan, shapes, dtypes, disp_desc, dflag, crop, prefilter, device):
@@ -302,8 +301,9 @@ def _crop_windows(plan, shapes, dtypes, disp_desc, dflag, crop, prefilter, devic
         return wins
     if sum(volume(i, at_least(i)) for i in todo) > CROP_WINDOW_MAX_FRACTION * sum(volume(i, in_len) for i in todo):
         return wins
-    # (the conservative box of the control coefficients' convex hull: microseconds on the device, where the
-    # exact scan of every output voxel took 0.9 ms for a 256^3 output -- more than the window saved)
+    # (the box of the control coefficients' convex hull after two levels of subdivision: microseconds on the
+    # device and within ~20 % of the exact range, where the exact scan of every output voxel took 0.9 ms for a
+    # 256^3 output -- more than the window saved)
     cbox = _lib.source_box(disp_desc, in_len, out_len, plan.output_offset, plan.inverse_affine,
                            _flags | dflag | _lib.FLAG_FAST, _stream(device))
     saving = 0.0

@@ -275,9 +275,10 @@ double edhip_profile_last_us(void);
  * the deformed extents of inputs[0] / outputs[0].  The box is returned to the host, so this call
  * SYNCHRONISES `hip_stream`.  Control grids of more than 7680 values (naxis * prod ncp) are
  * refused with EDHIP_ERR_UNSUPPORTED.  With EDHIP_FLAG_FAST the box is the conservative one of the
- * spline's convex hull -- [min, max] of the control coefficients that reach the output box, plus the
- * affine part at the box's corners: a superset of the exact box, a few samples wider, computed from the
- * control grid alone (microseconds, where the exact scan visits every output voxel).
+ * spline's convex hull -- [min, max] of the control coefficients that reach the output box, refined by up
+ * to two levels of B-spline subdivision, plus the affine part at the box's corners: a superset of the exact
+ * box (about 1.2x the displacement's true range for a random 5^3 grid; the unrefined hull is 9x), computed
+ * from the control grid alone in microseconds, where the exact scan visits every output voxel.
  *
  * No counterpart in the reference.  It lets the host layer restrict the input prefilter
  * (deform_grid.py:155-164) to the part of a volume that a cropped output can reach.
