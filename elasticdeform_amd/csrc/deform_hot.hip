@@ -349,7 +349,7 @@ __device__ __forceinline__ void hot_tile_coords(const HotGeom& hg, const HotPara
 // Tile loop, software-pipelined: once the box of tile t is known its staging copies are issued as
 // asynchronous LDS-DMA, and the coordinates + bounding box of tile t + 1 are computed while they are
 // in flight; the gather of tile t follows the barrier that retires the copies.
-template <int ORDER, bool AFFINE, int ABL = 0, int NTH = kBlock, int WAVES = ((ABL & 2048) ? 5 : 4)>
+template <int ORDER, bool AFFINE, int ABL = 0, int NTH = kBlock, int WAVES = ((ABL & 2048) ? 5 : 4), bool REC_ONLY = false>
 __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
 {
     // NTH = 256: two voxels per lane (z = wave, wave + 4); NTH = 512: one voxel per lane, eight waves
@@ -364,6 +364,10 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     HotStrip sp;
     if (!hot_strip(hg, sp, blockIdx.x))
+        return;
+    // records-only launch (first half of a gradient call): nothing to do for a sample whose records were
+    // made by a forward call from these very displacement values (flag written by the tables kernel)
+    if (REC_ONLY && hg.rec_valid && hg.rec_valid[sp.sample])
         return;
     // (per-workgroup issue priorities (s_setprio) and a staggered start of the workgroups of a CU, to
     // push co-resident workgroups into complementary phases, were tried: no change)
@@ -437,6 +441,26 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         if (hg.boxes && tid < 6)       // EDHIP_FLAG_KEEP_BOXES: the box goes to the gradient call too
             hg.boxes[(size_t)(sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti) * 8 +
                      tid] = red[tid] - ((tid == 5 && any) ? kPadX : 0);      // (without the forward gather's padding tap)
+        if (hg.rec) {
+            // coordinate records for the gradient kernel (hot_grad2_kernel): window start relative to this
+            // tile's box + the three fractions, for every voxel of the output -- also of a tile that is
+            // handed to the spill list below (the gradient's tiles are twice as long and hold other boxes)
+            typedef float f4_t __attribute__((ext_vector_type(4)));
+            const int ox = (sp.tx0 + ti) * kT + xx;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (valid[i]) {
+                    unsigned w = kRecDead;
+                    if (!constant[i])
+                        w = (unsigned)min(start[i][0] - b0[0], 255) | ((unsigned)min(start[i][1] - b0[1], 255) << 8) |
+                            ((unsigned)min(start[i][2] - b0[2], 255) << 16);
+                    const f4_t r = {frac[i][0], frac[i][1], frac[i][2], __uint_as_float(w)};
+                    f4_t* dst = reinterpret_cast<f4_t*>(hg.rec) +
+                                (sp.sample * hg.rec_bstride + ((long long)oz[i] * hg.out_len[1] + oy) * hg.out_len[2] + ox);
+                    __builtin_nontemporal_store(r, dst);
+                }
+            }
+        }
         if (ABL & 8) {        // (only meaningful together with ABL & 4: identity coordinates)
             any = true;
             b0[0] = min(max(sp.tz * kT + hg.off[0] - 1, 0), hg.in_len[0] - 4);
@@ -457,9 +481,9 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         const int nrows = ext[0] * by;
         const bool fits = pitch > 0 && nrows * pitch <= hg.box_cap;
         const bool staged = any && fits;
-        if (any && hg.hint && tid == 0 && !(pitch > 0 && nrows * pitch <= hg.small_cap))
+        if (!REC_ONLY && any && hg.hint && tid == 0 && !(pitch > 0 && nrows * pitch <= hg.small_cap))
             atomicAdd(hg.hint, 1);         // spill feedback: would not fit the standard box
-        if (any && !fits && tid == 0) {    // hand the whole tile to the general kernels
+        if (!REC_ONLY && any && !fits && tid == 0) {    // hand the whole tile to the general kernels
             const int slot = atomicAdd(&hg.spill[0], 1);
             hg.spill[1 + slot] = sp.sample * hg.ntiles +
                                  (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti;
@@ -533,7 +557,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         long long vol_off = 0, img_off = 0;
         if (hg.nstep)
             hot_step_offsets(hp, 0, vol_off, img_off);
-        if (staged && !(ABL & 32))
+        if (!REC_ONLY && staged && !(ABL & 32))
             stage(vol + vol_off);
 
         // ---- phases A + B of the NEXT tile, while the copies are in flight ------------------------
@@ -548,7 +572,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
                                                 oy, (sp.tx0 + ti + 1) * kT, xx, lane, vzy, Pzy, nstart, nfrac,
                                                 nvalid, nconstant);
 
-        if (!(any && !fits)) {
+        if (!REC_ONLY && !(any && !fits)) {
             for (long long ss = 0; ss < hg.nsteps; ++ss) {
                 if (ss > 0) {
                     hot_step_offsets(hp, ss, vol_off, img_off);
@@ -984,6 +1008,378 @@ ED_UNROLL(ED_K2_U2)
     }
 }
 
+// ================================================================================================
+// K2 from records (hot_grad2_kernel): the gradient kernel of a step whose forward call (or a records-only
+// launch in front of it) left every voxel's window start and fractions in HBM (HotGeom::rec) and every
+// 8^3 tile's box (HotGeom::boxes).  No tables, no fp64, no boundary map: a voxel is 16 bytes of record +
+// 4 bytes of dY.  What the kernel is bound by is the LDS atomic unit (64 ds_add_u32 per voxel in
+// hot_grad_kernel, 73 % busy, profiles/r03_pmc_summary.txt), so the scatter works on PAIRS of x-neighbours:
+// when the second voxel's window starts one cell after the first's in the same (z, y) rows -- 78 % of the
+// pairs of the benchmark field, tools/sim/runs.py -- their 2 x 4 contributions to a row are merged in
+// registers into 5 cells: 80 atomics per pair instead of 128.  SIMD form: the lanes of a wave must all be
+// on the same path, so the tile's pairs are first classified from their packed starts (two words per pair)
+// and compacted into two LDS work lists -- regular pairs / single voxels -- from which every wave-step is
+// filled with items of one kind.  Tiles of 8 x 8 x TX voxels as before; the fixed-point scale, the
+// exchange flush and the spill list are hot_grad_kernel's.
+// ================================================================================================
+constexpr int kG2Sum = 416;                    // float[2][4]: per-wave sums of |dY|
+constexpr int kG2Cnt = 448;                    // int[3][2]: items on the two lists, three tiles in rotation
+constexpr int kG2ListA = 512;                  // u16[8 * 8 * TX / 2]: regular pairs
+template <int TX> constexpr int g2_list_b() { return kG2ListA + 2 * (8 * 8 * TX / 2); }       // u16[8 * 8 * TX]: single voxels
+template <int TX> constexpr int g2_cells() { return (g2_list_b<TX>() + 2 * (8 * 8 * TX) + 15) & ~15; }
+
+template <int ORDER, int TX>
+__global__ __launch_bounds__(kBlock, 4) void hot_grad2_kernel(const HotGeom hg)
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int NPX = TX / 2;                      // pairs along x
+    constexpr int NI = 8 * 8 * NPX / kBlock;         // pairs per lane and tile (TX 16: 2)
+    constexpr int ZSTEP = 8 / NI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    HotStrip sp;
+    if (!hot_strip(hg, sp, blockIdx.x))
+        return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    int* box = reinterpret_cast<int*>(smem + g2_cells<TX>());
+    int* cnt = reinterpret_cast<int*>(smem + kG2Cnt);
+    unsigned short* list_a = reinterpret_cast<unsigned short*>(smem + kG2ListA);
+    unsigned short* list_b = reinterpret_cast<unsigned short*>(smem + g2_list_b<TX>());
+    HotParams* hpw = reinterpret_cast<HotParams*>(smem);
+    // the accumulator cells start at zero and every flush leaves the cells it read at zero again
+    for (int e = tid * 4; e < hg.box_cap; e += kBlock * 4)
+        *reinterpret_cast<int4*>(box + e) = make_int4(0, 0, 0, 0);
+    if (tid < 8) {
+        hpw->step_len[tid] = hg.step_len[tid];
+        hpw->in_step_stride[tid] = hg.vol_step[tid];
+        hpw->out_step_stride[tid] = hg.img_step[tid];
+        if (tid < 6)
+            cnt[tid] = 0;
+        if (tid == 0)
+            hpw->nstep = hg.nstep;
+    }
+    __syncthreads();
+    const HotParams* hp = hpw;
+
+    // producer map, lane -> pair: 8 pairs along x, the 16 lanes that go through the LDS atomic unit
+    // together hold rows y and y + 2 (hot_grad_kernel's map; list order follows lane order)
+    const int xp = TX == 16 ? (tid & 7) : (tid & (NPX - 1));
+    const int yy = TX == 16 ? 2 * ((tid >> 3) & 1) + ((tid >> 4) & 1) + 4 * ((tid >> 5) & 1) : ((tid / NPX) & 7);
+    const int zq = tid / (NPX * 8);
+    const int ntile = (sp.ntile * kT + TX - 1) / TX;
+    float* dx = hg.vol_w + sp.sample * hg.vol_bstride;
+    const float* __restrict__ dy = hg.img_r + sp.sample * hg.img_bstride;
+    const float4* __restrict__ rec = hg.rec + sp.sample * hg.rec_bstride;
+    const int oy = sp.ty * kT + yy;
+    const int oz0 = sp.tz * kT + zq;
+    const int O1 = hg.out_len[1], O2 = hg.out_len[2];
+    int phase = 0;
+
+    for (int ti = 0; ti < ntile; ++ti) {
+        const int ox0 = sp.tx0 * kT + ti * TX;
+        int* tcnt = cnt + (ti % 3) * 2;
+        // ---- producer: classify this lane's pairs from the packed starts, sum |dY| -------------------
+        float gm = 0.f;
+        bool reg[NI], live[NI][2];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int oz = oz0 + ZSTEP * i;
+            const int ox = ox0 + 2 * xp;
+            const bool in0 = oz < hg.out_len[0] && oy < O1 && ox < O2;
+            const bool in1 = in0 && ox + 1 < O2;
+            const long long ridx = ((long long)oz * O1 + oy) * O2 + ox;
+            const int didx = oz * hg.img_sz + oy * hg.img_sy + ox;
+            unsigned w0 = kRecDead, w1 = kRecDead;
+            float g0 = 0.f, g1 = 0.f;
+            if (in0) {
+                w0 = __float_as_uint(rec[ridx].w);
+                g0 = dy[didx];
+            }
+            if (in1) {
+                w1 = __float_as_uint(rec[ridx + 1].w);
+                g1 = dy[didx + 1];
+            }
+            live[i][0] = !(w0 & kRecDead);
+            live[i][1] = !(w1 & kRecDead);
+            // one cell further along x, same rows: both voxels sit in the same 8^3 tile, so the packed
+            // starts refer to one box and differ by exactly the x unit
+            reg[i] = live[i][0] && live[i][1] && (w1 - w0) == 0x10000u;
+            gm += (__float_as_int(g0) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(g0);
+            gm += (__float_as_int(g1) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(g1);
+        }
+        gm = wave_sum(gm);
+        if (lane == 0)
+            reinterpret_cast<float*>(smem + kG2Sum)[(phase & 1) * 4 + wave] = gm;
+        {   // compaction: one returning LDS atomic per wave and list, ranks from the ballots
+            unsigned long long ma[NI], mb[NI][2];
+            int na = 0, nb = 0;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                ma[i] = __ballot(reg[i]);
+                mb[i][0] = __ballot(live[i][0] && !reg[i]);
+                mb[i][1] = __ballot(live[i][1] && !reg[i]);
+                na += __popcll(ma[i]);
+                nb += __popcll(mb[i][0]) + __popcll(mb[i][1]);
+            }
+            int base_a = 0, base_b = 0;
+            if (lane == 0) {
+                base_a = na ? atomicAdd(&tcnt[0], na) : 0;
+                base_b = nb ? atomicAdd(&tcnt[1], nb) : 0;
+            }
+            base_a = uni(base_a);
+            base_b = uni(base_b);
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int pid = ((zq + ZSTEP * i) * 8 + yy) * NPX + xp;
+                if (reg[i])
+                    list_a[base_a + __popcll(ma[i] & below)] = (unsigned short)pid;
+                base_a += __popcll(ma[i]);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    if (live[i][v] && !reg[i])
+                        list_b[base_b + __popcll(mb[i][v] & below)] = (unsigned short)(pid * 2 + v);
+                    base_b += __popcll(mb[i][v]);
+                }
+            }
+        }
+        // the tile's box: the union of the boxes of the 8-wide forward tiles it covers
+        int b0[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, bhi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+        int tb0[TX / kT][3];
+        {
+            const int t0 = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti * (TX / kT);
+            const int* bx = hg.boxes + (size_t)t0 * 8;
+#pragma unroll
+            for (int k = 0; k < TX / kT; ++k) {
+                const bool have = sp.tx0 + ti * (TX / kT) + k < hg.tiles[2];
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    tb0[k][h] = have ? uni(bx[k * 8 + h]) : 0x7fffffff;
+                    const int thi = have ? uni(bx[k * 8 + 3 + h]) : (int)0x80000000;
+                    b0[h] = min(b0[h], tb0[k][h]);
+                    bhi[h] = max(bhi[h], thi);
+                }
+            }
+        }
+        lds_barrier();     // B1: lists and sum known; the previous tile's flush is done (cells back at zero)
+        const int n_a = uni(tcnt[0]), n_b = uni(tcnt[1]);
+        if (tid < 2)
+            cnt[((ti + 2) % 3) * 2 + tid] = 0;       // re-arm the counters of tile ti + 2
+        const bool any = bhi[0] >= b0[0] && bhi[1] >= b0[1] && bhi[2] >= b0[2];
+        if (!any)
+            continue;      // no live voxel (uniform)
+        const int ext[3] = {bhi[0] - b0[0] + 1, bhi[1] - b0[1] + 1, bhi[2] - b0[2] + 1};
+        // 16 lanes of a row hit cells two apart; pitch 8 * odd keeps rows y and y + 2 on disjoint banks
+        int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
+        if ((unsigned)ext[0] > 255u || (unsigned)ext[1] > 255u)
+            pitch = 0;
+        const int by = ext[1];
+        const int nrows = ext[0] * by;
+        const int nbox = nrows * pitch;
+        if (hg.hint && tid == 0 && (pitch == 0 || nbox > hg.small_cap))
+            atomicAdd(hg.hint, TX / kT);   // spill feedback, in 8-wide tiles
+        if (pitch == 0 || nbox > hg.box_cap) {
+            if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < hg.tiles[2]) {
+                const int slot = atomicAdd(&hg.spill[0], 1);
+                hg.spill[1 + slot] = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] +
+                                     sp.tx0 + ti * (TX / kT) + tid;
+            }
+            continue;
+        }
+        const bool interior = b0[0] >= 0 && b0[0] + ext[0] <= hg.in_len[0] && b0[1] >= 0 &&
+                              b0[1] + ext[1] <= hg.in_len[1] && b0[2] >= 0 && b0[2] + ext[2] <= hg.in_len[2];
+        // packed (box of the voxel's forward tile) - (this tile's box): added to a record's packed start
+        unsigned delta[TX / kT];
+#pragma unroll
+        for (int k = 0; k < TX / kT; ++k)
+            delta[k] = ((unsigned)(tb0[k][0] - b0[0]) & 255u) | (((unsigned)(tb0[k][1] - b0[1]) & 255u) << 8) |
+                       (((unsigned)(tb0[k][2] - b0[2]) & 255u) << 16);
+
+        for (long long ss = 0; ss < hg.nsteps; ++ss, ++phase) {
+            long long vol_off = 0, img_off = 0;
+            if (hg.nstep)
+                hot_step_offsets(hp, ss, vol_off, img_off);
+            float* dst = dx + vol_off;
+            const float* __restrict__ dys = dy + img_off;
+            float* gsum = reinterpret_cast<float*>(smem + kG2Sum) + (phase & 1) * 4;
+            if (ss > 0) {
+                // later steps (channels) of the same tile: their own sum, after the previous flush
+                float gs2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int oz = oz0 + ZSTEP * i;
+                    const int ox = ox0 + 2 * xp;
+                    const int didx = oz * hg.img_sz + oy * hg.img_sy + ox;
+                    const bool in0 = oz < hg.out_len[0] && oy < O1 && ox < O2;
+                    const float g0 = in0 ? dys[didx] : 0.f;
+                    const float g1 = (in0 && ox + 1 < O2) ? dys[didx + 1] : 0.f;
+                    gs2 += (__float_as_int(g0) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(g0);
+                    gs2 += (__float_as_int(g1) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(g1);
+                }
+                gs2 = wave_sum(gs2);
+                if (lane == 0)
+                    gsum[wave] = gs2;
+                lds_barrier();           // sum known; the previous step's flush is done with the box
+            }
+            const float gtot = unif((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
+            // |sum in a cell| <= max tap weight * sum over the tile of |dY|: this scale cannot overflow
+            constexpr float kC = (float)((2147483648.0 - 1024.0) /
+                                         ((ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : ORDER == 3 ? 0.2963
+                                           : ORDER == 4 ? 0.2150 : 0.1664) * 1.001));
+            const float scale = gtot > 0.f ? fminf(kC * __frcp_rn(gtot), 3.0e38f) : 0.f;
+            const float inv_scale = gtot > 0.f ? __frcp_rn(scale) : 0.f;
+
+            // a voxel with an inf / NaN gradient has no fixed-point scale: its taps go straight to global
+            // memory with float atomics (rare, rolled loop; deform.c:791-813 for the mirror-mapped indices)
+            auto direct = [&](float gv, unsigned wrel, int k, const float* w0, const float* w1, const float* w2) {
+                const int st0 = (int)(wrel & 255u) + (k ? tb0[TX / kT - 1][0] : tb0[0][0]);
+                const int st1 = (int)((wrel >> 8) & 255u) + (k ? tb0[TX / kT - 1][1] : tb0[0][1]);
+                const int st2 = (int)((wrel >> 16) & 255u) + (k ? tb0[TX / kT - 1][2] : tb0[0][2]);
+#pragma unroll 1
+                for (int t = 0; t < NT * NT * NT; ++t) {
+                    const int l0 = t / (NT * NT), l1 = (t / NT) % NT, l2 = t % NT;
+                    const int zs = mirror_i32(st0 + l0, hg.in_len[0]);
+                    const int ys = mirror_i32(st1 + l1, hg.in_len[1]);
+                    const int xs = mirror_i32(st2 + l2, hg.in_len[2]);
+                    float wp = w0[0], wq = w1[0], wr = w2[0];
+#pragma unroll
+                    for (int l = 1; l < NT; ++l) {
+                        wp = l0 == l ? w0[l] : wp;
+                        wq = l1 == l ? w1[l] : wq;
+                        wr = l2 == l ? w2[l] : wr;
+                    }
+                    unsafeAtomicAdd(dst + (zs * hg.vol_sz + ys * hg.vol_sy + xs), gv * wp * wq * wr);
+                }
+            };
+            static_assert(TX / kT <= 2, "direct(): k selects between two forward tiles");
+
+            // ---- regular pairs: 5 cells per row ------------------------------------------------------
+            for (int j = tid; j < n_a; j += kBlock) {
+                const int pid = list_a[j];
+                const int pxp = pid % NPX, pyy = (pid / NPX) & 7, pz = pid / (NPX * 8);
+                const int oz = sp.tz * kT + pz, oyy = sp.ty * kT + pyy, ox = ox0 + 2 * pxp;
+                const long long ridx = ((long long)oz * O1 + oyy) * O2 + ox;
+                const int didx = oz * hg.img_sz + oyy * hg.img_sy + ox;
+                const float4 r0 = rec[ridx], r1 = rec[ridx + 1];
+                const float g0v = dys[didx], g1v = dys[didx + 1];
+                const int k = (2 * pxp) / kT;
+                float wz0[NT], wy0[NT], wx0[NT], wz1[NT], wy1[NT], wx1[NT];
+                weights_from_frac<float, ORDER>(r0.x, wz0);
+                weights_from_frac<float, ORDER>(r0.y, wy0);
+                weights_from_frac<float, ORDER>(r0.z, wx0);
+                weights_from_frac<float, ORDER>(r1.x, wz1);
+                weights_from_frac<float, ORDER>(r1.y, wy1);
+                weights_from_frac<float, ORDER>(r1.z, wx1);
+                const unsigned w0 = __float_as_uint(r0.w);
+                const bool nf0 = (__float_as_int(g0v) & 0x7f800000) == 0x7f800000;
+                const bool nf1 = (__float_as_int(g1v) & 0x7f800000) == 0x7f800000;
+                if (nf0 || nf1) {
+                    if (g0v != 0.f)
+                        direct(g0v, w0, k, wz0, wy0, wx0);
+                    if (g1v != 0.f)
+                        direct(g1v, __float_as_uint(r1.w), k, wz1, wy1, wx1);
+                    continue;
+                }
+                const unsigned rel = (w0 & 0xffffffu) + (k ? delta[TX / kT - 1] : delta[0]);
+                int* bp = box + (((int)(rel & 255u) * by + (int)((rel >> 8) & 255u)) * pitch + (int)(rel >> 16));
+                const float gs0 = g0v * scale, gs1 = g1v * scale;
+#pragma unroll
+                for (int l0 = 0; l0 < NT; ++l0) {
+                    const float a0 = gs0 * wz0[l0], a1 = gs1 * wz1[l0];
+#pragma unroll
+                    for (int l1 = 0; l1 < NT; ++l1) {
+                        const float p0 = a0 * wy0[l1], p1 = a1 * wy1[l1];
+                        int* rp = bp + (l0 * by + l1) * pitch;
+                        float c[NT + 1];
+                        c[0] = p0 * wx0[0];
+#pragma unroll
+                        for (int l2 = 1; l2 < NT; ++l2)
+                            c[l2] = fmaf(p1, wx1[l2 - 1], p0 * wx0[l2]);
+                        c[NT] = p1 * wx1[NT - 1];
+#pragma unroll
+                        for (int l2 = 0; l2 <= NT; ++l2)
+                            atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)round_half_up_i32(c[l2]));
+                    }
+                }
+            }
+            // ---- single voxels -------------------------------------------------------------------------
+            for (int j = tid; j < n_b; j += kBlock) {
+                const int vid = list_b[j];
+                const int pid = vid >> 1, v = vid & 1;
+                const int pxp = pid % NPX, pyy = (pid / NPX) & 7, pz = pid / (NPX * 8);
+                const int oz = sp.tz * kT + pz, oyy = sp.ty * kT + pyy, ox = ox0 + 2 * pxp + v;
+                const float4 r0 = rec[((long long)oz * O1 + oyy) * O2 + ox];
+                const float gv = dys[oz * hg.img_sz + oyy * hg.img_sy + ox];
+                if (gv == 0.f)
+                    continue;
+                const int k = (2 * pxp) / kT;
+                float w0[NT], w1[NT], w2[NT];
+                weights_from_frac<float, ORDER>(r0.x, w0);
+                weights_from_frac<float, ORDER>(r0.y, w1);
+                weights_from_frac<float, ORDER>(r0.z, w2);
+                const unsigned wr = __float_as_uint(r0.w);
+                if ((__float_as_int(gv) & 0x7f800000) == 0x7f800000) {
+                    direct(gv, wr, k, w0, w1, w2);
+                    continue;
+                }
+                const unsigned rel = (wr & 0xffffffu) + (k ? delta[TX / kT - 1] : delta[0]);
+                int* bp = box + (((int)(rel & 255u) * by + (int)((rel >> 8) & 255u)) * pitch + (int)(rel >> 16));
+                const float gs = gv * scale;
+#pragma unroll
+                for (int l0 = 0; l0 < NT; ++l0) {
+                    const float a0 = gs * w0[l0];
+#pragma unroll
+                    for (int l1 = 0; l1 < NT; ++l1) {
+                        const float p0 = a0 * w1[l1];
+                        int* rp = bp + (l0 * by + l1) * pitch;
+#pragma unroll
+                        for (int l2 = 0; l2 < NT; ++l2)
+                            atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)round_half_up_i32(p0 * w2[l2]));
+                    }
+                }
+            }
+            lds_barrier();               // B3: all contributions are in
+            // flush (hot_grad_kernel's): half a wave per box row, one float atomic per touched source element
+            {
+                constexpr int FL = 32, FR = kBlock / FL, FU = 4;
+                const int sub = tid & (FL - 1);
+                const int rslot = tid / FL;
+                const float inv_by = 1.f / (float)by;
+                for (int xo = 0; xo < ext[2]; xo += FL) {
+                    const int xi = xo + sub;
+                    const bool xin = xi < ext[2];
+                    const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
+                    for (int r0 = rslot; r0 < nrows; r0 += FU * FR) {
+                        int acc[FU];
+#pragma unroll
+                        for (int q = 0; q < FU; ++q) {
+                            const int r = r0 + q * FR;
+                            acc[q] = (xin && r < nrows) ? __hip_atomic_exchange(&box[r * pitch + xi], 0, __ATOMIC_RELAXED,
+                                                                                __HIP_MEMORY_SCOPE_WORKGROUP)
+                                                        : 0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < FU; ++q) {
+                            if (acc[q] != 0) {
+                                const int r = r0 + q * FR;
+                                const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                                int rowoff;
+                                if (interior)
+                                    rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
+                                else
+                                    rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
+                                             mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+                                unsafeAtomicAdd(dst + (rowoff + xs), (float)acc[q] * inv_scale);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int ORDER>
 hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t lds, hipStream_t stream)
 {
@@ -1040,6 +1436,44 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
 }
 
 }  // namespace
+
+// records-only launch of K1 (first half of a gradient call without a forward call to lean on): same grid
+// and LDS as the forward launch
+hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream)
+{
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(kBlock), lds, stream, hg);
+        return hipGetLastError();
+    };
+    switch (order * 2 + (hg.has_affine ? 1 : 0)) {
+    case 2: return go(hot_fwd_kernel<1, false, 0, kBlock, 4, true>);
+    case 3: return go(hot_fwd_kernel<1, true, 0, kBlock, 4, true>);
+    case 4: return go(hot_fwd_kernel<2, false, 0, kBlock, 4, true>);
+    case 5: return go(hot_fwd_kernel<2, true, 0, kBlock, 4, true>);
+    case 6: return go(hot_fwd_kernel<3, false, 0, kBlock, 4, true>);
+    case 7: return go(hot_fwd_kernel<3, true, 0, kBlock, 4, true>);
+    default: return hipErrorNotSupported;
+    }
+}
+
+// K2 from records: LDS = parameters | sums | counters | two work lists | cells
+size_t hot_grad2_lds_bytes(int* box_cap, bool large)
+{
+    const size_t cells = large ? 44 * 1024 : 32 * 1024;      // 3 / 4 workgroups per CU
+    *box_cap = (int)(cells / 4);
+    return (size_t)g2_cells<16>() + cells;
+}
+
+hipError_t launch_hot_grad2(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream)
+{
+    switch (order) {
+    case 1: hipLaunchKernelGGL((hot_grad2_kernel<1, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
+    case 2: hipLaunchKernelGGL((hot_grad2_kernel<2, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
+    case 3: hipLaunchKernelGGL((hot_grad2_kernel<3, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
+    default: return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
 
 // LDS: x table | reduction slots | wave sums | parameters | 64 Q rows | box.  Returns 0 when the
 // control grid is too wide for a useful box (the general kernels take the call).

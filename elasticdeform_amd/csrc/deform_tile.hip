@@ -122,6 +122,32 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     };
     if (tid == 0)
         entry(0, oz, tz_);
+    if (oz == 0 && tg.keep_mode) {
+        // the control-grid values this call works from: kept for (1) / compared with (2) the gradient
+        // call that wants to use the forward call's coordinate records
+        const int nz = (int)g.ncp[0];
+        const int ntot = 3 * nz * nyx;
+        double* stash = tg.keep_stash + (int64_t)sample * ntot;
+        int same = 1;
+        for (int e = tid; e < ntot; e += kBlock) {
+            const int h = e / (nz * nyx), r = e - h * (nz * nyx);
+            const int j0 = r / nyx, j = r - j0 * nyx;
+            const int j1 = j / ncpx, j2 = j - j1 * ncpx;
+            const double val = load_as_double(disp + g.disp_stride[0] * h + g.disp_stride[1] * j0 +
+                                                  g.disp_stride[2] * j1 + g.disp_stride[3] * j2, g.disp_dtype);
+            if (tg.keep_mode == 1) {
+                stash[e] = val;
+            } else if (__double_as_longlong(stash[e]) != __double_as_longlong(val)) {
+                same = 0;
+                stash[e] = val;       // the records-only launch behind this kernel remakes the records from `val`
+            }
+        }
+        if (tg.keep_mode == 2) {
+            same = __syncthreads_and(same);
+            if (tid == 0)
+                tg.keep_flags[sample] = same;
+        }
+    }
     if (oz == 0 && sample == 0) {
         AxTab* xt = const_cast<AxTab*>(tg.xt_global);
         for (int ox = tid; ox < tg.out_len[2]; ox += kBlock) {
@@ -1274,7 +1300,16 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
             tg.hint_seq = sh->begin_call(key, (unsigned)(ntiles * nb));
         }
     }
-    {
+    tg.keep_mode = 0;
+    tg.keep_stash = nullptr;
+    tg.keep_flags = nullptr;
+    // the per-call tables launch; the float32 benchmark route decides about the forward -> gradient
+    // hand-over first (the tables kernel keeps / checks the control-grid values for it)
+    bool tables_done = false;
+    auto launch_tables = [&]() {
+        if (tables_done || e != hipSuccess)
+            return;
+        tables_done = true;
         unsigned fill_blocks = 0;
         tg.zero_ptr = nullptr;
         tg.zero_bytes = 0;
@@ -1288,7 +1323,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0] + fill_blocks, (unsigned)nb), dim3(kBlock),
                            sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
         e = hipGetLastError();
-    }
+    };
+    if (std::is_integral<T>::value || ORDER < 1)
+        launch_tables();
     if constexpr (std::is_integral<T>::value) {
         if (nb != 1)
             return hipErrorNotSupported;      // the label kernels take one volume per call
@@ -1367,7 +1404,6 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // ---- level 1: strips, small boxes, highest occupancy ------------------------------------------
     bool hot_done = false;
     HotGeom hg;
-    profile_mark(false, stream);
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips * nb + 7) / 8) * 8);
         [[maybe_unused]] constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
@@ -1427,22 +1463,46 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     hg.hint = sh ? tg.hint : nullptr;
                 }
                 hg.lds_grp = (int)((hlds + 15) & ~(size_t)15);
-                // EDHIP_FLAG_KEEP_BOXES / USE_BOXES: the forward kernel's tile boxes live in a buffer of
-                // their own (nothing else writes it) under a host-side key of everything they depend on
+                // EDHIP_FLAG_KEEP_BOXES / USE_BOXES: the forward kernel's tile boxes -- and, orders 1-3, its
+                // per-voxel coordinate records -- live in a buffer of their own (nothing else writes it) under
+                // a host-side key of everything they depend on.  Layout: boxes | flags | grid copy | records.
                 KeepKey* key = nullptr;
                 KeepKey cur;
                 memset(&cur, 0, sizeof(cur));
                 const int box_mode = batch ? batch->box_mode : 0;
-                if (hlds && box_mode && !ed_env("EDHIP_NO_BOXES")) {
+                const size_t ngrid = 3 * (size_t)g.ncp[0] * (size_t)g.ncp[1] * (size_t)g.ncp[2];
+                const size_t nvox = (size_t)g.out_len[0] * (size_t)g.out_len[1] * (size_t)g.out_len[2];
+                const size_t kb_boxes = ((size_t)ntiles * nb * 8 * sizeof(int) + 255) & ~(size_t)255;
+                const size_t kb_flags = ((size_t)nb * sizeof(int) + 255) & ~(size_t)255;
+                const size_t kb_stash = ((size_t)nb * ngrid * sizeof(double) + 255) & ~(size_t)255;
+                // records: orders 1-3 on the 4-wave kernels (the one-wave kernels of orders 4 / 5 keep to boxes)
+                bool want_rec = ORDER <= 3 && ngrid <= 65536 && (double)nvox * nb * 16.0 <= (double)((size_t)16 << 30) &&
+                                !ed_env("EDHIP_NO_RECORDS");
+#ifdef EDHIP_EXPERIMENTS
+                if (ed_env("EDHIP_WAVE"))
+                    want_rec = false;
+#endif
+                // a gradient call takes the records route whenever it can: with the forward call's records
+                // when the key matches (and the tables kernel finds the grid values unchanged), with its own
+                // records-only launch otherwise
+                const bool rec_grad = GRAD && want_rec;
+                bool rec_route = false;
+                if (hlds && (box_mode || rec_grad) && !ed_env("EDHIP_NO_BOXES")) {
                     hipError_t ke = hipSuccess;
-                    int* kb = (int*)keep_reserve(stream, (size_t)ntiles * nb * 8 * sizeof(int), &key, &ke);
-                    if (kb) {
+                    const bool with_rec = want_rec && (rec_grad || box_mode == 1);
+                    char* kbuf = (char*)keep_reserve(stream, kb_boxes + kb_flags + kb_stash + (with_rec ? nvox * nb * 16 : 0),
+                                                     &key, &ke);
+                    if (kbuf) {
+                        int* kb = (int*)kbuf;
+                        int* kflags = (int*)(kbuf + kb_boxes);
+                        double* kstash = (double*)(kbuf + kb_boxes + kb_flags);
+                        float4* krec = (float4*)(kbuf + kb_boxes + kb_flags + kb_stash);
                         int n = 0;
                         cur.w[n++] = 1;                                   // valid
                         cur.w[n++] = (unsigned long long)(size_t)batch->disp_id;
                         cur.w[n++] = (unsigned long long)g.disp_dtype | ((unsigned long long)batch->raw << 8) |
                                      ((unsigned long long)ORDER << 16) | ((unsigned long long)tg.mode << 24) |
-                                     ((unsigned long long)g.has_affine << 32);
+                                     ((unsigned long long)g.has_affine << 32) | ((unsigned long long)with_rec << 40);
                         cur.w[n++] = (unsigned long long)nb;
                         cur.w[n++] = (unsigned long long)batch->disp_bstride;
                         for (int k = 0; k < 3; ++k) {
@@ -1458,7 +1518,27 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                                 memcpy(&cur.w[n++], &g.affine[k], sizeof(double));
                         if (!GRAD && box_mode == 1) {
                             hg.boxes = kb;
+                            if (with_rec) {
+                                hg.rec = krec;
+                                hg.rec_bstride = (long long)nvox;
+                                tg.keep_mode = 1;
+                                tg.keep_stash = kstash;
+                            }
                             *key = KeepKey();                  // not valid until this launch is in the stream
+                        } else if (rec_grad) {
+                            const bool match = box_mode == 2 && memcmp(key, &cur, sizeof(cur)) == 0;
+                            hg.boxes = kb;
+                            hg.rec = krec;
+                            hg.rec_bstride = (long long)nvox;
+                            hg.rec_valid = match ? kflags : nullptr;
+                            if (match) {
+                                tg.keep_mode = 2;
+                                tg.keep_stash = kstash;
+                                tg.keep_flags = kflags;
+                            } else {
+                                *key = KeepKey();              // this call's own records replace whatever was kept
+                            }
+                            rec_route = true;
                         } else if (GRAD && box_mode == 2 && ORDER >= 3 && memcmp(key, &cur, sizeof(cur)) == 0) {
                             // (orders 1 / 2: the box pass is a small part of a short tile, and the
                             // hand-over's bookkeeping costs more than it saves: 190 -> 196, 242 -> 252 us)
@@ -1467,6 +1547,42 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         }
                     }
                 }
+                launch_tables();
+                if (rec_route && e == hipSuccess) {
+                    // gradient from records: (1) K1 in records-only form -- its workgroups leave at once for the
+                    // samples whose records the forward call made from these very grid values -- (2) the
+                    // gradient kernel that reads records and boxes
+                    HotGeom rg = hg;
+                    int fcap = 0, foff = 0;
+                    const size_t flds = hot_lds_bytes(false, tg.ncpx, &fcap, &foff, false);
+                    rg.box_cap = fcap;
+                    rg.off_box = foff;
+                    rg.small_cap = fcap;
+                    rg.hint = nullptr;
+                    rg.rec_only = 1;
+                    hipError_t he = flds ? launch_hot_records(rg, ORDER, nblk, flds, stream) : hipErrorNotSupported;
+                    if (he == hipSuccess) {
+                        HotGeom gg = hg;
+                        gg.rec_valid = nullptr;
+                        int gcap = 0, scap = 0;
+                        (void)hot_grad2_lds_bytes(&scap, false);
+                        const size_t glds = hot_grad2_lds_bytes(&gcap, large_boxes);
+                        gg.box_cap = gcap;
+                        gg.small_cap = scap;
+                        profile_mark(false, stream);
+                        he = launch_hot_grad2(gg, ORDER, nblk, glds, stream);
+                        if (he == hipSuccess)
+                            hot_done = true;
+                    }
+                    if (he != hipSuccess && he != hipErrorNotSupported)
+                        e = he;
+                    if (!hot_done) {          // (cannot happen for orders 1-3; the old route needs its own state)
+                        hg.boxes = nullptr;
+                        hg.rec = nullptr;
+                    }
+                }
+                if (!hot_done)
+                    profile_mark(false, stream);
                 // Orders 4 / 5 run on the wave-per-tile kernels (deform_wave.hip: one wavefront per tile,
                 // one copy of the box, tiles that do not fit taken as two x-halves): the 4-wave kernels
                 // give up on a tile as soon as its 5- / 6-tap windows need the wide row pitch, and at
@@ -1479,7 +1595,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 if (const char* wm = ed_env("EDHIP_WAVE"))        // 1 forward, 2 gradient, 3 both, 0 neither
                     wave_mode = atoi(wm);
 #endif
-                if (hlds && (wave_mode & (GRAD ? 2 : 1))) {
+                if (hlds && !hot_done && (wave_mode & (GRAD ? 2 : 1))) {
                     HotGeom wg = hg;
                     wg.strip_tiles = 4;
 #ifdef EDHIP_EXPERIMENTS
@@ -1527,7 +1643,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                             e = he;
                     }
                 }
-                if (hlds && !wave_done && e == hipSuccess) {
+                if (hlds && !wave_done && !hot_done && e == hipSuccess) {
                     const hipError_t he = launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
                     if (he == hipSuccess) {
                         hot_done = true;
@@ -1538,6 +1654,10 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 }
 
             }
+        }
+        if (!tables_done) {
+            launch_tables();
+            profile_mark(false, stream);
         }
         if (hot_done || e != hipSuccess)
             ;

@@ -302,6 +302,13 @@ struct TileGeom {
     // aligned start, any length)
     char* zero_ptr;
     long long zero_bytes;
+    // forward -> gradient hand-over of the coordinate records (HotGeom::rec): the tables kernel of a
+    // KEEP forward call copies the control-grid values it reads into keep_stash (keep_mode 1); the tables
+    // kernel of a USE gradient call compares what it reads with the copy and writes keep_flags[sample]
+    // = 1 when every value is bit-equal, 0 otherwise (keep_mode 2).  nbatch * 3 * prod(ncp) doubles.
+    double* keep_stash;
+    int* keep_flags;
+    int keep_mode;
     int* label_list;      // label kernel: [0] = count, [1..cap] = linear ids of near-tie voxels (or nullptr)
     int label_cap;
     const int* worklist;  // second-level pass: [0] = count, [1..] = tile ids to process (else nullptr)
@@ -386,6 +393,18 @@ struct HotGeom {
     // the pointer is set; K2 reads them when `use_boxes` is set (see EDHIP_FLAG_USE_BOXES).
     int* boxes;
     int use_boxes;
+    // Per-voxel coordinate records handed from the forward to the gradient call, next to the boxes
+    // (deform_hot.hip, "records"): rec[sample * rec_bstride + (oz * O_y + oy) * O_x + ox] =
+    // {frac_z, frac_y, frac_x, bits of the packed window start relative to the voxel's 8^3 tile box}.
+    // K1 writes them when `rec` is set; rec_only: coordinates, boxes and records only (no staging, no
+    // gather, no output) -- the first half of a gradient call that has no forward call to lean on.
+    // rec_valid[sample] != 0 (device memory, written by the tables kernel of a gradient call): the
+    // records in the buffer were made from these very displacement values -- a rec_only launch
+    // leaves that sample alone.
+    float4* rec;
+    long long rec_bstride;
+    int rec_only;
+    const int* rec_valid;
     unsigned long long* dbgbuf;   // EDHIP_EXPERIMENTS builds: per-workgroup timestamps (else unused)
     // integer fast path (wave_int_fwd_kernel): near-tie voxels for the exact re-evaluation,
     // [0] = count, [1 .. tie_cap] = linear output voxel ids; the constant of 'constant' mode in fp64
@@ -400,11 +419,21 @@ struct HotGeom {
     double period[3], inv_period[3], affine[12];
 };
 
+// coordinate records (HotGeom::rec): .w holds (start_z - box_z) | (start_y - box_y) << 8 | (start_x - box_x) << 16,
+// each clamped to 255 (a tile with such a box is far beyond any LDS budget and goes to the general
+// kernels, which do not read records), or kRecDead for a voxel that maps to the constant (deform.c:928)
+constexpr unsigned kRecDead = 0x80000000u;
+
 // level-1 launch of the hot kernels; hipErrorNotSupported when (order, ...) has no instantiation
 hipError_t launch_hot_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds,
                              hipStream_t stream);
 // large: the configuration with one workgroup per CU fewer and larger boxes (chosen from the spill feedback)
 size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, bool large = false);
+// the records route of a gradient call: K1 in records-only form (grid / LDS of the forward launch), then the
+// gradient kernel that reads records and boxes (orders 1-3)
+hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream);
+size_t hot_grad2_lds_bytes(int* box_cap, bool large = false);
+hipError_t launch_hot_grad2(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream);
 
 // one-wavefront-per-tile kernels (deform_wave.hip): same argument block; `strip_tiles`, `strips_x`,
 // `nstrips`, `total_strips` describe the strips of the 64-thread workgroups, `box_cap` the floats /
