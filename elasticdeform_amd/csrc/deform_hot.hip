@@ -23,6 +23,8 @@
 // for the phase-by-phase mapping).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 
 #include "ed_device.h"
 #include "ed_params.h"
@@ -1022,30 +1024,42 @@ ED_UNROLL(ED_K2_U2)
 // filled with items of one kind.  Tiles of 8 x 8 x TX voxels as before; the fixed-point scale, the
 // exchange flush and the spill list are hot_grad_kernel's.
 // ================================================================================================
-constexpr int kG2Sum = 416;                    // float[2][4]: per-wave sums of |dY|
+constexpr int kG2Sum = 416;                    // float[2][4]: per-wave sums of |dY|, two tiles / steps in rotation
 constexpr int kG2Cnt = 448;                    // int[3][2]: items on the two lists, three tiles in rotation
-constexpr int kG2ListA = 512;                  // u16[8 * 8 * TX / 2]: regular pairs
-template <int TX> constexpr int g2_list_b() { return kG2ListA + 2 * (8 * 8 * TX / 2); }       // u16[8 * 8 * TX]: single voxels
-template <int TX> constexpr int g2_cells() { return (g2_list_b<TX>() + 2 * (8 * 8 * TX) + 15) & ~15; }
+constexpr int kG2List = 512;                   // two tiles in rotation: u16[8 * 8 * TX / 2] regular pairs | u16[8 * 8 * TX] single voxels
+template <int TX> constexpr int g2_list_bytes() { return 2 * (8 * 8 * TX / 2) + 2 * (8 * 8 * TX); }
+template <int TX> constexpr int g2_cells() { return (kG2List + 2 * g2_list_bytes<TX>() + 15) & ~15; }
 
-template <int ORDER, int TX>
-__global__ __launch_bounds__(kBlock, 4) void hot_grad2_kernel(const HotGeom hg)
+// Software pipeline over the tiles of a strip (measured on the first, unpipelined form: producer + barrier
+// alone 121 of 405 us, flush 127 us against hot_grad_kernel's 40 -- on this target stores and atomics count
+// in vmcnt IN ORDER with loads, so every load issued behind a flush waits for the flush's global atomics):
+//   * the packed starts, dY and boxes a producer needs are requested two tiles ahead of their flush;
+//   * the producer of tile t + 1 runs in front of the consumers of tile t (two sets of lists);
+//   * after the barrier that closes the scatter of tile t every lane requests its first work item of tile
+//     t + 1, and only then issues the flush's atomics; later items are requested one item ahead.
+template <int ORDER, int TX, int WGS = 4>
+__global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg)
 {
     constexpr int NT = ORDER + 1;
     constexpr int NPX = TX / 2;                      // pairs along x
     constexpr int NI = 8 * 8 * NPX / kBlock;         // pairs per lane and tile (TX 16: 2)
     constexpr int ZSTEP = 8 / NI;
+    constexpr int NK = TX / kT;                      // forward tiles per tile
+    static_assert(NK <= 2, "two forward tiles per gradient tile at most");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     HotStrip sp;
     if (!hot_strip(hg, sp, blockIdx.x))
         return;
+    // The thread id goes through an empty asm statement wherever per-lane constants are derived from it: the
+    // compiler otherwise hoists every such value (pair coordinates, bounds tests, 64-bit addresses) out of the
+    // tile loop and keeps ~100 registers live across the consumers -- 158 VGPRs, or 15 spilled at 128.
+    auto fresh_tid = [] { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int tb = kBlock - 1 - tid;       // single voxels are dealt to the lanes in reverse: the last wave, which gets the fewest pairs, first
     int* box = reinterpret_cast<int*>(smem + g2_cells<TX>());
     int* cnt = reinterpret_cast<int*>(smem + kG2Cnt);
-    unsigned short* list_a = reinterpret_cast<unsigned short*>(smem + kG2ListA);
-    unsigned short* list_b = reinterpret_cast<unsigned short*>(smem + g2_list_b<TX>());
     HotParams* hpw = reinterpret_cast<HotParams*>(smem);
     // the accumulator cells start at zero and every flush leaves the cells it read at zero again
     for (int e = tid * 4; e < hg.box_cap; e += kBlock * 4)
@@ -1059,116 +1073,164 @@ __global__ __launch_bounds__(kBlock, 4) void hot_grad2_kernel(const HotGeom hg)
         if (tid == 0)
             hpw->nstep = hg.nstep;
     }
-    __syncthreads();
     const HotParams* hp = hpw;
 
     // producer map, lane -> pair: 8 pairs along x, the 16 lanes that go through the LDS atomic unit
     // together hold rows y and y + 2 (hot_grad_kernel's map; list order follows lane order)
-    const int xp = TX == 16 ? (tid & 7) : (tid & (NPX - 1));
-    const int yy = TX == 16 ? 2 * ((tid >> 3) & 1) + ((tid >> 4) & 1) + 4 * ((tid >> 5) & 1) : ((tid / NPX) & 7);
-    const int zq = tid / (NPX * 8);
+    auto pair_xp = [](int t) { return TX == 16 ? (t & 7) : (t & (NPX - 1)); };
+    auto pair_yy = [](int t) { return TX == 16 ? 2 * ((t >> 3) & 1) + ((t >> 4) & 1) + 4 * ((t >> 5) & 1) : ((t / NPX) & 7); };
+    auto pair_zq = [](int t) { return t / (NPX * 8); };
     const int ntile = (sp.ntile * kT + TX - 1) / TX;
     float* dx = hg.vol_w + sp.sample * hg.vol_bstride;
     const float* __restrict__ dy = hg.img_r + sp.sample * hg.img_bstride;
     const float4* __restrict__ rec = hg.rec + sp.sample * hg.rec_bstride;
-    const int oy = sp.ty * kT + yy;
-    const int oz0 = sp.tz * kT + zq;
     const int O1 = hg.out_len[1], O2 = hg.out_len[2];
-    int phase = 0;
 
-    for (int ti = 0; ti < ntile; ++ti) {
-        const int ox0 = sp.tx0 * kT + ti * TX;
-        int* tcnt = cnt + (ti % 3) * 2;
-        // ---- producer: classify this lane's pairs from the packed starts, sum |dY| -------------------
-        float gm = 0.f;
-        bool reg[NI], live[NI][2];
+    // ---- requests: what the producer of tile t needs, into registers ---------------------------------
+    unsigned nw[NI][2];
+    float ng[NI][2];
+    int nbx = 0;              // lane 8 k + h: word h of forward tile k's box
+    auto request = [&](int t) {
+        const int ft = fresh_tid();
+        const int xp = pair_xp(ft), oy = sp.ty * kT + pair_yy(ft), oz0 = sp.tz * kT + pair_zq(ft);
+        const int ox = sp.tx0 * kT + t * TX + 2 * xp;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int oz = oz0 + ZSTEP * i;
-            const int ox = ox0 + 2 * xp;
             const bool in0 = oz < hg.out_len[0] && oy < O1 && ox < O2;
             const bool in1 = in0 && ox + 1 < O2;
             const long long ridx = ((long long)oz * O1 + oy) * O2 + ox;
             const int didx = oz * hg.img_sz + oy * hg.img_sy + ox;
-            unsigned w0 = kRecDead, w1 = kRecDead;
-            float g0 = 0.f, g1 = 0.f;
-            if (in0) {
-                w0 = __float_as_uint(rec[ridx].w);
-                g0 = dy[didx];
-            }
-            if (in1) {
-                w1 = __float_as_uint(rec[ridx + 1].w);
-                g1 = dy[didx + 1];
-            }
+            nw[i][0] = in0 ? __float_as_uint(rec[ridx].w) : kRecDead;
+            ng[i][0] = in0 ? dy[didx] : 0.f;
+            nw[i][1] = in1 ? __float_as_uint(rec[ridx + 1].w) : kRecDead;
+            ng[i][1] = in1 ? dy[didx + 1] : 0.f;
+        }
+        const int t0 = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + t * NK;
+        const int fl = ft & 63;
+        const bool have = fl < 8 * NK && sp.tx0 + t * NK + (fl >> 3) < hg.tiles[2];
+        nbx = have ? hg.boxes[(size_t)t0 * 8 + fl] : ((fl & 7) < 3 ? 0x7fffffff : (int)0x80000000);
+    };
+    // ---- producer of tile t: classify this lane's pairs from the packed starts, compact, sum |dY| -------
+    auto produce = [&](int t) {
+        unsigned short* la = reinterpret_cast<unsigned short*>(smem + kG2List + (t & 1) * g2_list_bytes<TX>());
+        unsigned short* lb = la + 8 * 8 * NPX;
+        int* tcnt = cnt + (t % 3) * 2;
+        float gm = 0.f;
+        bool reg[NI], live[NI][2];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const unsigned w0 = nw[i][0], w1 = nw[i][1];
             live[i][0] = !(w0 & kRecDead);
             live[i][1] = !(w1 & kRecDead);
             // one cell further along x, same rows: both voxels sit in the same 8^3 tile, so the packed
             // starts refer to one box and differ by exactly the x unit
             reg[i] = live[i][0] && live[i][1] && (w1 - w0) == 0x10000u;
-            gm += (__float_as_int(g0) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(g0);
-            gm += (__float_as_int(g1) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(g1);
+            gm += (__float_as_int(ng[i][0]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(ng[i][0]);
+            gm += (__float_as_int(ng[i][1]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(ng[i][1]);
         }
         gm = wave_sum(gm);
         if (lane == 0)
-            reinterpret_cast<float*>(smem + kG2Sum)[(phase & 1) * 4 + wave] = gm;
-        {   // compaction: one returning LDS atomic per wave and list, ranks from the ballots
-            unsigned long long ma[NI], mb[NI][2];
-            int na = 0, nb = 0;
+            reinterpret_cast<float*>(smem + kG2Sum)[(t & 1) * 4 + wave] = gm;
+        // compaction: one returning LDS atomic per wave and list, ranks from the ballots
+        unsigned long long ma[NI], mb[NI][2];
+        int na = 0, nb = 0;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                ma[i] = __ballot(reg[i]);
-                mb[i][0] = __ballot(live[i][0] && !reg[i]);
-                mb[i][1] = __ballot(live[i][1] && !reg[i]);
-                na += __popcll(ma[i]);
-                nb += __popcll(mb[i][0]) + __popcll(mb[i][1]);
-            }
-            int base_a = 0, base_b = 0;
-            if (lane == 0) {
-                base_a = na ? atomicAdd(&tcnt[0], na) : 0;
-                base_b = nb ? atomicAdd(&tcnt[1], nb) : 0;
-            }
-            base_a = uni(base_a);
-            base_b = uni(base_b);
-            const unsigned long long below = (1ull << lane) - 1ull;
+        for (int i = 0; i < NI; ++i) {
+            ma[i] = __ballot(reg[i]);
+            mb[i][0] = __ballot(live[i][0] && !reg[i]);
+            mb[i][1] = __ballot(live[i][1] && !reg[i]);
+            na += __popcll(ma[i]);
+            nb += __popcll(mb[i][0]) + __popcll(mb[i][1]);
+        }
+        int base_a = 0, base_b = 0;
+        if (lane == 0) {
+            base_a = na ? atomicAdd(&tcnt[0], na) : 0;
+            base_b = nb ? atomicAdd(&tcnt[1], nb) : 0;
+        }
+        base_a = uni(base_a);
+        base_b = uni(base_b);
+        const int ft = fresh_tid();
+        const unsigned long long below = (1ull << (ft & 63)) - 1ull;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int pid = ((zq + ZSTEP * i) * 8 + yy) * NPX + xp;
-                if (reg[i])
-                    list_a[base_a + __popcll(ma[i] & below)] = (unsigned short)pid;
-                base_a += __popcll(ma[i]);
+        for (int i = 0; i < NI; ++i) {
+            const int pid = ((pair_zq(ft) + ZSTEP * i) * 8 + pair_yy(ft)) * NPX + pair_xp(ft);
+            if (reg[i])
+                la[base_a + __popcll(ma[i] & below)] = (unsigned short)pid;
+            base_a += __popcll(ma[i]);
 #pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    if (live[i][v] && !reg[i])
-                        list_b[base_b + __popcll(mb[i][v] & below)] = (unsigned short)(pid * 2 + v);
-                    base_b += __popcll(mb[i][v]);
-                }
+            for (int v = 0; v < 2; ++v) {
+                if (live[i][v] && !reg[i])
+                    lb[base_b + __popcll(mb[i][v] & below)] = (unsigned short)(pid * 2 + v);
+                base_b += __popcll(mb[i][v]);
             }
         }
-        // the tile's box: the union of the boxes of the 8-wide forward tiles it covers
+    };
+    // ---- work items -----------------------------------------------------------------------------------
+    // (one register set for both kinds: a single voxel uses r0, g0, k)
+    struct Item { float4 r0, r1; float g0, g1; int k; };
+    auto fetch_a = [&](int t, const float* dys, int j, Item& it) {
+        const unsigned short* la = reinterpret_cast<const unsigned short*>(smem + kG2List + (t & 1) * g2_list_bytes<TX>());
+        const int pid = la[j];
+        const int pxp = pid % NPX, pyy = (pid / NPX) & 7, pz = pid / (NPX * 8);
+        const int oz = sp.tz * kT + pz, oyy = sp.ty * kT + pyy, ox = sp.tx0 * kT + t * TX + 2 * pxp;
+        const long long ridx = ((long long)oz * O1 + oyy) * O2 + ox;
+        const int didx = oz * hg.img_sz + oyy * hg.img_sy + ox;
+        it.r0 = rec[ridx];
+        it.r1 = rec[ridx + 1];
+        it.g0 = dys[didx];
+        it.g1 = dys[didx + 1];
+        it.k = (2 * pxp) / kT;
+    };
+    auto fetch_b = [&](int t, const float* dys, int j, Item& it) {
+        const unsigned short* lb = reinterpret_cast<const unsigned short*>(smem + kG2List + (t & 1) * g2_list_bytes<TX>()) + 8 * 8 * NPX;
+        const int vid = lb[j];
+        const int pid = vid >> 1, v = vid & 1;
+        const int pxp = pid % NPX, pyy = (pid / NPX) & 7, pz = pid / (NPX * 8);
+        const int oz = sp.tz * kT + pz, oyy = sp.ty * kT + pyy, ox = sp.tx0 * kT + t * TX + 2 * pxp + v;
+        it.r0 = rec[((long long)oz * O1 + oyy) * O2 + ox];
+        it.g0 = dys[oz * hg.img_sz + oyy * hg.img_sy + ox];
+        it.k = (2 * pxp) / kT;
+    };
+
+#ifdef EDHIP_EXPERIMENTS
+    // per-wave phase clocks (s_memtime ticks summed over the strip): produce, consume, wait B3, fetch + flush, wait B1
+    long long tacc[5] = {0, 0, 0, 0, 0};
+    long long tmark = 0;
+#define ED_TICK(K) do { if (hg.dbgbuf) { const long long now_ = __builtin_readcyclecounter(); tacc[K] += now_ - tmark; tmark = now_; } } while (0)
+#else
+#define ED_TICK(K) do { } while (0)
+#endif
+    request(0);
+    __syncthreads();          // cells, parameters, counters
+    produce(0);
+    int nbx_cur = nbx;
+    if (ntile > 1)
+        request(1);
+    lds_barrier();            // lists of tile 0
+    int n_a = uni(cnt[0]), n_b = uni(cnt[1]);
+    Item cur;
+    if (tid < n_a)
+        fetch_a(0, dy, tid, cur);
+    else if (tb < n_b)
+        fetch_b(0, dy, tb, cur);
+    int phase = 0;
+
+    for (int ti = 0; ti < ntile; ++ti) {
+        const int ox0 = sp.tx0 * kT + ti * TX;
+        // ---- this tile's box: the union of the boxes of the forward tiles it covers -----------------------
         int b0[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, bhi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-        int tb0[TX / kT][3];
-        {
-            const int t0 = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti * (TX / kT);
-            const int* bx = hg.boxes + (size_t)t0 * 8;
+        int tb0[NK][3];
 #pragma unroll
-            for (int k = 0; k < TX / kT; ++k) {
-                const bool have = sp.tx0 + ti * (TX / kT) + k < hg.tiles[2];
+        for (int k = 0; k < NK; ++k) {
 #pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    tb0[k][h] = have ? uni(bx[k * 8 + h]) : 0x7fffffff;
-                    const int thi = have ? uni(bx[k * 8 + 3 + h]) : (int)0x80000000;
-                    b0[h] = min(b0[h], tb0[k][h]);
-                    bhi[h] = max(bhi[h], thi);
-                }
+            for (int h = 0; h < 3; ++h) {
+                tb0[k][h] = __builtin_amdgcn_readlane(nbx_cur, 8 * k + h);
+                b0[h] = min(b0[h], tb0[k][h]);
+                bhi[h] = max(bhi[h], __builtin_amdgcn_readlane(nbx_cur, 8 * k + 3 + h));
             }
         }
-        lds_barrier();     // B1: lists and sum known; the previous tile's flush is done (cells back at zero)
-        const int n_a = uni(tcnt[0]), n_b = uni(tcnt[1]);
-        if (tid < 2)
-            cnt[((ti + 2) % 3) * 2 + tid] = 0;       // re-arm the counters of tile ti + 2
         const bool any = bhi[0] >= b0[0] && bhi[1] >= b0[1] && bhi[2] >= b0[2];
-        if (!any)
-            continue;      // no live voxel (uniform)
         const int ext[3] = {bhi[0] - b0[0] + 1, bhi[1] - b0[1] + 1, bhi[2] - b0[2] + 1};
         // 16 lanes of a row hit cells two apart; pitch 8 * odd keeps rows y and y + 2 on disjoint banks
         int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
@@ -1177,39 +1239,57 @@ __global__ __launch_bounds__(kBlock, 4) void hot_grad2_kernel(const HotGeom hg)
         const int by = ext[1];
         const int nrows = ext[0] * by;
         const int nbox = nrows * pitch;
-        if (hg.hint && tid == 0 && (pitch == 0 || nbox > hg.small_cap))
-            atomicAdd(hg.hint, TX / kT);   // spill feedback, in 8-wide tiles
-        if (pitch == 0 || nbox > hg.box_cap) {
-            if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < hg.tiles[2]) {
-                const int slot = atomicAdd(&hg.spill[0], 1);
-                hg.spill[1 + slot] = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] +
-                                     sp.tx0 + ti * (TX / kT) + tid;
-            }
-            continue;
+        const bool fits = pitch != 0 && nbox <= hg.box_cap;
+        const bool work = any && fits;
+        if (any && hg.hint && tid == 0 && (pitch == 0 || nbox > hg.small_cap))
+            atomicAdd(hg.hint, NK);        // spill feedback, in 8-wide tiles
+        if (any && !fits && tid < NK && sp.tx0 + ti * NK + tid < hg.tiles[2]) {
+            const int slot = atomicAdd(&hg.spill[0], 1);
+            hg.spill[1 + slot] = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti * NK + tid;
         }
         const bool interior = b0[0] >= 0 && b0[0] + ext[0] <= hg.in_len[0] && b0[1] >= 0 &&
                               b0[1] + ext[1] <= hg.in_len[1] && b0[2] >= 0 && b0[2] + ext[2] <= hg.in_len[2];
         // packed (box of the voxel's forward tile) - (this tile's box): added to a record's packed start
-        unsigned delta[TX / kT];
+        unsigned delta[NK];
 #pragma unroll
-        for (int k = 0; k < TX / kT; ++k)
+        for (int k = 0; k < NK; ++k)
             delta[k] = ((unsigned)(tb0[k][0] - b0[0]) & 255u) | (((unsigned)(tb0[k][1] - b0[1]) & 255u) << 8) |
                        (((unsigned)(tb0[k][2] - b0[2]) & 255u) << 16);
 
+        // ---- the NEXT tile's producer, in front of this tile's consumers ------------------------------
+#ifdef EDHIP_EXPERIMENTS
+        if (hg.dbgbuf && ti == 0)
+            tmark = __builtin_readcyclecounter();
+#endif
+        int nbx_next = 0;
+        if (ti + 1 < ntile) {
+            produce(ti + 1);
+            nbx_next = nbx;
+        }
+
+        ED_TICK(0);
         for (long long ss = 0; ss < hg.nsteps; ++ss, ++phase) {
             long long vol_off = 0, img_off = 0;
             if (hg.nstep)
                 hot_step_offsets(hp, ss, vol_off, img_off);
             float* dst = dx + vol_off;
             const float* __restrict__ dys = dy + img_off;
-            float* gsum = reinterpret_cast<float*>(smem + kG2Sum) + (phase & 1) * 4;
-            if (ss > 0) {
-                // later steps (channels) of the same tile: their own sum, after the previous flush
+            const bool last_step = ss + 1 == hg.nsteps;
+            float gtot;
+            if (ss == 0) {
+                const float* gsum = reinterpret_cast<const float*>(smem + kG2Sum) + (ti & 1) * 4;
+                gtot = unif((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
+            } else {
+                // later steps (channels) of the same tile: their own sum, in the NEXT tile's slot once that
+                // tile's producer is done with it... kept apart instead: slot 2 (bytes 32..47 of the counters' pad)
+                float* gsum = reinterpret_cast<float*>(smem + kG2Cnt + 32);
                 float gs2 = 0.f;
+                const int ft = fresh_tid();
+                const int oy = sp.ty * kT + pair_yy(ft), oz0 = sp.tz * kT + pair_zq(ft);
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int oz = oz0 + ZSTEP * i;
-                    const int ox = ox0 + 2 * xp;
+                    const int ox = ox0 + 2 * pair_xp(ft);
                     const int didx = oz * hg.img_sz + oy * hg.img_sy + ox;
                     const bool in0 = oz < hg.out_len[0] && oy < O1 && ox < O2;
                     const float g0 = in0 ? dys[didx] : 0.f;
@@ -1220,9 +1300,13 @@ __global__ __launch_bounds__(kBlock, 4) void hot_grad2_kernel(const HotGeom hg)
                 gs2 = wave_sum(gs2);
                 if (lane == 0)
                     gsum[wave] = gs2;
-                lds_barrier();           // sum known; the previous step's flush is done with the box
+                lds_barrier();           // (the previous step's flush ended with a barrier: slot free)
+                gtot = unif((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
+                if (tid < n_a)
+                    fetch_a(ti, dys, tid, cur);
+                else if (tb < n_b)
+                    fetch_b(ti, dys, tb, cur);
             }
-            const float gtot = unif((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
             // |sum in a cell| <= max tap weight * sum over the tile of |dY|: this scale cannot overflow
             constexpr float kC = (float)((2147483648.0 - 1024.0) /
                                          ((ORDER == 1 ? 1.0 : ORDER == 2 ? 0.4219 : ORDER == 3 ? 0.2963
@@ -1233,9 +1317,9 @@ __global__ __launch_bounds__(kBlock, 4) void hot_grad2_kernel(const HotGeom hg)
             // a voxel with an inf / NaN gradient has no fixed-point scale: its taps go straight to global
             // memory with float atomics (rare, rolled loop; deform.c:791-813 for the mirror-mapped indices)
             auto direct = [&](float gv, unsigned wrel, int k, const float* w0, const float* w1, const float* w2) {
-                const int st0 = (int)(wrel & 255u) + (k ? tb0[TX / kT - 1][0] : tb0[0][0]);
-                const int st1 = (int)((wrel >> 8) & 255u) + (k ? tb0[TX / kT - 1][1] : tb0[0][1]);
-                const int st2 = (int)((wrel >> 16) & 255u) + (k ? tb0[TX / kT - 1][2] : tb0[0][2]);
+                const int st0 = (int)(wrel & 255u) + (k ? tb0[NK - 1][0] : tb0[0][0]);
+                const int st1 = (int)((wrel >> 8) & 255u) + (k ? tb0[NK - 1][1] : tb0[0][1]);
+                const int st2 = (int)((wrel >> 16) & 255u) + (k ? tb0[NK - 1][2] : tb0[0][2]);
 #pragma unroll 1
                 for (int t = 0; t < NT * NT * NT; ++t) {
                     const int l0 = t / (NT * NT), l1 = (t / NT) % NT, l2 = t % NT;
@@ -1252,101 +1336,141 @@ __global__ __launch_bounds__(kBlock, 4) void hot_grad2_kernel(const HotGeom hg)
                     unsafeAtomicAdd(dst + (zs * hg.vol_sz + ys * hg.vol_sy + xs), gv * wp * wq * wr);
                 }
             };
-            static_assert(TX / kT <= 2, "direct(): k selects between two forward tiles");
-
-            // ---- regular pairs: 5 cells per row ------------------------------------------------------
-            for (int j = tid; j < n_a; j += kBlock) {
-                const int pid = list_a[j];
-                const int pxp = pid % NPX, pyy = (pid / NPX) & 7, pz = pid / (NPX * 8);
-                const int oz = sp.tz * kT + pz, oyy = sp.ty * kT + pyy, ox = ox0 + 2 * pxp;
-                const long long ridx = ((long long)oz * O1 + oyy) * O2 + ox;
-                const int didx = oz * hg.img_sz + oyy * hg.img_sy + ox;
-                const float4 r0 = rec[ridx], r1 = rec[ridx + 1];
-                const float g0v = dys[didx], g1v = dys[didx + 1];
-                const int k = (2 * pxp) / kT;
-                float wz0[NT], wy0[NT], wx0[NT], wz1[NT], wy1[NT], wx1[NT];
-                weights_from_frac<float, ORDER>(r0.x, wz0);
-                weights_from_frac<float, ORDER>(r0.y, wy0);
-                weights_from_frac<float, ORDER>(r0.z, wx0);
-                weights_from_frac<float, ORDER>(r1.x, wz1);
-                weights_from_frac<float, ORDER>(r1.y, wy1);
-                weights_from_frac<float, ORDER>(r1.z, wx1);
-                const unsigned w0 = __float_as_uint(r0.w);
-                const bool nf0 = (__float_as_int(g0v) & 0x7f800000) == 0x7f800000;
-                const bool nf1 = (__float_as_int(g1v) & 0x7f800000) == 0x7f800000;
-                if (nf0 || nf1) {
-                    if (g0v != 0.f)
-                        direct(g0v, w0, k, wz0, wy0, wx0);
-                    if (g1v != 0.f)
-                        direct(g1v, __float_as_uint(r1.w), k, wz1, wy1, wx1);
-                    continue;
-                }
-                const unsigned rel = (w0 & 0xffffffu) + (k ? delta[TX / kT - 1] : delta[0]);
-                int* bp = box + (((int)(rel & 255u) * by + (int)((rel >> 8) & 255u)) * pitch + (int)(rel >> 16));
-                const float gs0 = g0v * scale, gs1 = g1v * scale;
+#ifdef EDHIP_EXPERIMENTS
+            // (profiling build, EDHIP_TILE_DBG: 4 no flush, 8 no consumers)
+            const int n_a_ = (!work || (hg.dbg & 8)) ? 0 : n_a, n_b_ = (!work || (hg.dbg & 8)) ? 0 : n_b;
+            const int flush_x = (!work || (hg.dbg & 4)) ? 0 : ext[2];
+#else
+            const int n_a_ = work ? n_a : 0, n_b_ = work ? n_b : 0, flush_x = work ? ext[2] : 0;
+#endif
+            // (the row pitch as a compile-time constant: a row's cells are immediate offsets off four plane bases)
+            auto consume = [&](auto pitch_c) {
+                constexpr int PITCH = decltype(pitch_c)::value;
+                const int plane = by * PITCH;
+                // ---- regular pairs: 5 cells per row --------------------------------------------------
+                for (int j = tid; j < n_a_; j += kBlock) {
+                    const Item it = cur;
+                    if (j + kBlock < n_a_)
+                        fetch_a(ti, dys, j + kBlock, cur);
+                    else if (tb < n_b_)
+                        fetch_b(ti, dys, tb, cur);       // the lane's last pair: its first single voxel next
+                    const float4 r0 = it.r0, r1 = it.r1;
+                    const float g0v = it.g0, g1v = it.g1;
+                    const int k = it.k;
+                    float wz0[NT], wy0[NT], wx0[NT], wz1[NT], wy1[NT], wx1[NT];
+                    weights_from_frac<float, ORDER>(r0.x, wz0);
+                    weights_from_frac<float, ORDER>(r0.y, wy0);
+                    weights_from_frac<float, ORDER>(r0.z, wx0);
+                    weights_from_frac<float, ORDER>(r1.x, wz1);
+                    weights_from_frac<float, ORDER>(r1.y, wy1);
+                    weights_from_frac<float, ORDER>(r1.z, wx1);
+                    const unsigned w0 = __float_as_uint(r0.w);
+                    const bool nf0 = (__float_as_int(g0v) & 0x7f800000) == 0x7f800000;
+                    const bool nf1 = (__float_as_int(g1v) & 0x7f800000) == 0x7f800000;
+                    if (nf0 || nf1) {
+                        if (g0v != 0.f)
+                            direct(g0v, w0, k, wz0, wy0, wx0);
+                        if (g1v != 0.f)
+                            direct(g1v, __float_as_uint(r1.w), k, wz1, wy1, wx1);
+                        continue;
+                    }
+                    const unsigned rel = (w0 & 0xffffffu) + (k ? delta[NK - 1] : delta[0]);
+                    int* bp = box + (((int)(rel & 255u) * by + (int)((rel >> 8) & 255u)) * PITCH + (int)(rel >> 16));
+                    const float gs0 = g0v * scale, gs1 = g1v * scale;
 #pragma unroll
-                for (int l0 = 0; l0 < NT; ++l0) {
-                    const float a0 = gs0 * wz0[l0], a1 = gs1 * wz1[l0];
+                    for (int l0 = 0; l0 < NT; ++l0) {
+                        const float a0 = gs0 * wz0[l0], a1 = gs1 * wz1[l0];
+                        int* pl = bp + l0 * plane;
 #pragma unroll
-                    for (int l1 = 0; l1 < NT; ++l1) {
-                        const float p0 = a0 * wy0[l1], p1 = a1 * wy1[l1];
-                        int* rp = bp + (l0 * by + l1) * pitch;
-                        float c[NT + 1];
-                        c[0] = p0 * wx0[0];
+                        for (int l1 = 0; l1 < NT; ++l1) {
+                            const float p0 = a0 * wy0[l1], p1 = a1 * wy1[l1];
+                            int* rp = pl + l1 * PITCH;
+                            float c[NT + 1];
+                            c[0] = p0 * wx0[0];
 #pragma unroll
-                        for (int l2 = 1; l2 < NT; ++l2)
-                            c[l2] = fmaf(p1, wx1[l2 - 1], p0 * wx0[l2]);
-                        c[NT] = p1 * wx1[NT - 1];
+                            for (int l2 = 1; l2 < NT; ++l2)
+                                c[l2] = fmaf(p1, wx1[l2 - 1], p0 * wx0[l2]);
+                            c[NT] = p1 * wx1[NT - 1];
 #pragma unroll
-                        for (int l2 = 0; l2 <= NT; ++l2)
-                            atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)round_half_up_i32(c[l2]));
+                            for (int l2 = 0; l2 <= NT; ++l2)
+                                atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)round_half_up_i32(c[l2]));
+                        }
                     }
                 }
-            }
-            // ---- single voxels -------------------------------------------------------------------------
-            for (int j = tid; j < n_b; j += kBlock) {
-                const int vid = list_b[j];
-                const int pid = vid >> 1, v = vid & 1;
-                const int pxp = pid % NPX, pyy = (pid / NPX) & 7, pz = pid / (NPX * 8);
-                const int oz = sp.tz * kT + pz, oyy = sp.ty * kT + pyy, ox = ox0 + 2 * pxp + v;
-                const float4 r0 = rec[((long long)oz * O1 + oyy) * O2 + ox];
-                const float gv = dys[oz * hg.img_sz + oyy * hg.img_sy + ox];
-                if (gv == 0.f)
-                    continue;
-                const int k = (2 * pxp) / kT;
-                float w0[NT], w1[NT], w2[NT];
-                weights_from_frac<float, ORDER>(r0.x, w0);
-                weights_from_frac<float, ORDER>(r0.y, w1);
-                weights_from_frac<float, ORDER>(r0.z, w2);
-                const unsigned wr = __float_as_uint(r0.w);
-                if ((__float_as_int(gv) & 0x7f800000) == 0x7f800000) {
-                    direct(gv, wr, k, w0, w1, w2);
-                    continue;
-                }
-                const unsigned rel = (wr & 0xffffffu) + (k ? delta[TX / kT - 1] : delta[0]);
-                int* bp = box + (((int)(rel & 255u) * by + (int)((rel >> 8) & 255u)) * pitch + (int)(rel >> 16));
-                const float gs = gv * scale;
+                // ---- single voxels ---------------------------------------------------------------------
+                // (a lane's first single voxel was requested with the tile's first items when the lane had no
+                // pair to start with, otherwise under its last pair)
+                for (int j = tb; j < n_b_; j += kBlock) {
+                    const Item it = cur;
+                    if (j + kBlock < n_b_)
+                        fetch_b(ti, dys, j + kBlock, cur);
+                    const float4 r0 = it.r0;
+                    const float gv = it.g0;
+                    const int k = it.k;
+                    if (gv == 0.f)
+                        continue;
+                    float w0[NT], w1[NT], w2[NT];
+                    weights_from_frac<float, ORDER>(r0.x, w0);
+                    weights_from_frac<float, ORDER>(r0.y, w1);
+                    weights_from_frac<float, ORDER>(r0.z, w2);
+                    const unsigned wr = __float_as_uint(r0.w);
+                    if ((__float_as_int(gv) & 0x7f800000) == 0x7f800000) {
+                        direct(gv, wr, k, w0, w1, w2);
+                        continue;
+                    }
+                    const unsigned rel = (wr & 0xffffffu) + (k ? delta[NK - 1] : delta[0]);
+                    int* bp = box + (((int)(rel & 255u) * by + (int)((rel >> 8) & 255u)) * PITCH + (int)(rel >> 16));
+                    const float gs = gv * scale;
 #pragma unroll
-                for (int l0 = 0; l0 < NT; ++l0) {
-                    const float a0 = gs * w0[l0];
+                    for (int l0 = 0; l0 < NT; ++l0) {
+                        const float a0 = gs * w0[l0];
+                        int* pl = bp + l0 * plane;
 #pragma unroll
-                    for (int l1 = 0; l1 < NT; ++l1) {
-                        const float p0 = a0 * w1[l1];
-                        int* rp = bp + (l0 * by + l1) * pitch;
+                        for (int l1 = 0; l1 < NT; ++l1) {
+                            const float p0 = a0 * w1[l1];
+                            int* rp = pl + l1 * PITCH;
 #pragma unroll
-                        for (int l2 = 0; l2 < NT; ++l2)
-                            atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)round_half_up_i32(p0 * w2[l2]));
+                            for (int l2 = 0; l2 < NT; ++l2)
+                                atomicAdd(reinterpret_cast<unsigned*>(rp + l2), (unsigned)round_half_up_i32(p0 * w2[l2]));
+                        }
                     }
                 }
+            };
+            switch (pitch) {
+            case 8: consume(std::integral_constant<int, 8>()); break;
+            case 24: consume(std::integral_constant<int, 24>()); break;
+            case 40: consume(std::integral_constant<int, 40>()); break;
+            default: consume(std::integral_constant<int, 56>()); break;
             }
-            lds_barrier();               // B3: all contributions are in
-            // flush (hot_grad_kernel's): half a wave per box row, one float atomic per touched source element
+            // (requests for the producer of tile ti + 2: behind the consumers, whose registers they would
+            // crowd, still in front of this tile's flush)
+            if (last_step && ti + 2 < ntile)
+                request(ti + 2);
+            ED_TICK(1);
+            lds_barrier();               // B3: all contributions are in; the next tile's lists are complete
+            ED_TICK(2);
+            if (tid < 2)
+                cnt[(ti % 3) * 2 + tid] = 0;      // this tile's counts: read by every wave before this barrier; next used by tile ti + 3
+            int next_a = 0, next_b = 0;
+            if (last_step && ti + 1 < ntile) {
+                // the next tile's first items, requested in front of this tile's flush atomics
+                next_a = uni(cnt[((ti + 1) % 3) * 2]);
+                next_b = uni(cnt[((ti + 1) % 3) * 2 + 1]);
+                if (tid < next_a)
+                    fetch_a(ti + 1, dy, tid, cur);
+                else if (tb < next_b)
+                    fetch_b(ti + 1, dy, tb, cur);
+            }
+            // flush: half a wave per box row, one float atomic per touched source element.  Every exchange of a
+            // lane (read + reset of up to FU cells, rows FR apart) is issued before the first result is used: an
+            // LDS operation queues behind the other workgroups' scatter atomics.
             {
-                constexpr int FL = 32, FR = kBlock / FL, FU = 4;
-                const int sub = tid & (FL - 1);
-                const int rslot = tid / FL;
+                constexpr int FL = 32, FR = kBlock / FL, FU = 20;
+                const int ftf = fresh_tid();
+                const int sub = ftf & (FL - 1);
+                const int rslot = ftf / FL;
                 const float inv_by = 1.f / (float)by;
-                for (int xo = 0; xo < ext[2]; xo += FL) {
+                for (int xo = 0; xo < flush_x; xo += FL) {
                     const int xi = xo + sub;
                     const bool xin = xi < ext[2];
                     const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
@@ -1370,14 +1494,36 @@ __global__ __launch_bounds__(kBlock, 4) void hot_grad2_kernel(const HotGeom hg)
                                 else
                                     rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
                                              mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+#ifdef EDHIP_EXPERIMENTS
+                                if (hg.dbg & 32)      // timing experiment: plain stores instead of atomics (wrong results)
+                                    __builtin_nontemporal_store((float)acc[q] * inv_scale, dst + (rowoff + xs));
+                                else
+#endif
                                 unsafeAtomicAdd(dst + (rowoff + xs), (float)acc[q] * inv_scale);
                             }
                         }
                     }
                 }
             }
+            ED_TICK(3);
+            lds_barrier();               // B1: the cells are back at zero
+            ED_TICK(4);
+            if (last_step) {
+                n_a = next_a;
+                n_b = next_b;
+            }
         }
+        nbx_cur = nbx_next;
     }
+#ifdef EDHIP_EXPERIMENTS
+    if (hg.dbgbuf && lane == 0) {
+        unsigned long long* d = hg.dbgbuf + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int q = 0; q < 5; ++q)
+            d[q] = (unsigned long long)tacc[q];
+        d[5] = (unsigned long long)ntile;
+    }
+#endif
+#undef ED_TICK
 }
 
 template <int ORDER>
@@ -1459,13 +1605,21 @@ hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_
 // K2 from records: LDS = parameters | sums | counters | two work lists | cells
 size_t hot_grad2_lds_bytes(int* box_cap, bool large)
 {
-    const size_t cells = large ? 44 * 1024 : 32 * 1024;      // 3 / 4 workgroups per CU
+    size_t cells = large ? 44 * 1024 : 32 * 1024;      // 3 / 4 workgroups per CU
+    if (const char* kb = ed_env("EDHIP_G2_CELLS_KB"))
+        cells = (size_t)atoi(kb) * 1024;
     *box_cap = (int)(cells / 4);
     return (size_t)g2_cells<16>() + cells;
 }
 
 hipError_t launch_hot_grad2(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream)
 {
+#ifdef EDHIP_EXPERIMENTS
+    if (order == 3 && ed_env("EDHIP_G2_WG5")) {
+        hipLaunchKernelGGL((hot_grad2_kernel<3, 16, 5>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+        return hipGetLastError();
+    }
+#endif
     switch (order) {
     case 1: hipLaunchKernelGGL((hot_grad2_kernel<1, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
     case 2: hipLaunchKernelGGL((hot_grad2_kernel<2, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;

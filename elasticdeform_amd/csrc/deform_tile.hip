@@ -1569,6 +1569,10 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         const size_t glds = hot_grad2_lds_bytes(&gcap, large_boxes);
                         gg.box_cap = gcap;
                         gg.small_cap = scap;
+#ifdef EDHIP_EXPERIMENTS
+                        if (const char* pp = ed_env("EDHIP_DEBUG_PTR"))
+                            gg.dbgbuf = (unsigned long long*)strtoull(pp, nullptr, 16);
+#endif
                         profile_mark(false, stream);
                         he = launch_hot_grad2(gg, ORDER, nblk, glds, stream);
                         if (he == hipSuccess)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""dev tool (EXPERIMENTS build): where the waves of hot_grad2_kernel spend their time -- per-wave s_memtime
+sums of the five intervals of a tile (producer of the next tile, consumers, wait at B3, first requests +
+flush, wait at B1) on the bench workload.   python tools/g2_phases.py [sigma]"""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import elasticdeform_amd as ed  # noqa
+from elasticdeform_amd import _lib
+dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+n, order = 256, 3
+sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
+dev = torch.device("cuda", 0)
+X = torch.from_numpy(np.random.default_rng(2).random((n, n, n), dtype=np.float32)).to(dev)
+dY = torch.from_numpy(np.random.default_rng(7).random((n, n, n), dtype=np.float32)).to(dev)
+disp = torch.from_numpy(np.random.default_rng(22).standard_normal((3, 5, 5, 5)) * sigma).to(dev)
+Xf = dgm._filter_axes(X, [0, 1, 2], order, False, dev)
+df = dgm._filter_axes(disp, [1, 2, 3], 3, False, dev)
+out = torch.empty_like(X); dxs = torch.zeros_like(X)
+stream = torch.cuda.current_stream(dev).cuda_stream
+a_f = ([dgm._desc(Xf)], dgm._desc(df), None, [dgm._desc(out)], [(0, 1, 2)], [order], [3], [0.0], None, _lib.FLAG_AUTO | _lib.FLAG_KEEP_BOXES, stream)
+a_g = ([dgm._desc(dxs)], dgm._desc(df), None, [dgm._desc(dY)], [(0, 1, 2)], [order], [3], [0.0], None, _lib.FLAG_AUTO | _lib.FLAG_USE_BOXES, stream)
+for _ in range(3):
+    _lib.deform(False, *a_f); _lib.deform(True, *a_g)
+torch.cuda.synchronize()
+buf = torch.zeros((1 << 16, 8), dtype=torch.int64, device=dev)
+os.environ["EDHIP_DEBUG_PTR"] = "%x" % buf.data_ptr()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); _lib.deform(True, *a_g); e1.record()
+torch.cuda.synchronize()
+del os.environ["EDHIP_DEBUG_PTR"]
+b = buf.cpu().numpy().astype(np.float64)
+b = b[b[:, 5] > 0]
+names = ["produce(t+1)", "consume", "wait B3", "fetch+flush", "wait B1"]
+tot = b[:, :5].sum(axis=1)
+print("sigma %g: gradient call %.1f us; %d waves reported; ticks per wave and strip: mean %.0f" % (sigma, e0.elapsed_time(e1) * 1e3, len(b), tot.mean()))
+for k, nm in enumerate(names):
+    print("  %-14s mean %8.0f ticks (%.1f %%)   per tile %7.0f   p10 %8.0f p90 %8.0f" %
+          (nm, b[:, k].mean(), 100 * b[:, k].mean() / tot.mean(), (b[:, k] / b[:, 5]).mean(), np.percentile(b[:, k], 10), np.percentile(b[:, k], 90)))
+w = b.reshape(-1, 4, 8) if len(b) % 4 == 0 else None
+if w is not None:
+    for k in (1, 3):
+        print("  %-14s per wave id 0..3:" % names[k], " ".join("%.0f" % w[:, q, k].mean() for q in range(4)))
