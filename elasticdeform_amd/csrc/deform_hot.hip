@@ -1169,9 +1169,9 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
     // ---- work items -----------------------------------------------------------------------------------
     // (one register set for both kinds: a single voxel uses r0, g0, k)
     struct Item { float4 r0, r1; float g0, g1; int k; };
-    auto fetch_a = [&](int t, const float* dys, int j, Item& it) {
-        const unsigned short* la = reinterpret_cast<const unsigned short*>(smem + kG2List + (t & 1) * g2_list_bytes<TX>());
-        const int pid = la[j];
+    auto list_a = [&](int t) { return reinterpret_cast<const unsigned short*>(smem + kG2List + (t & 1) * g2_list_bytes<TX>()); };
+    auto list_b = [&](int t) { return list_a(t) + 8 * 8 * NPX; };
+    auto fetch_a_id = [&](int t, const float* dys, int pid, Item& it) {
         const int pxp = pid % NPX, pyy = (pid / NPX) & 7, pz = pid / (NPX * 8);
         const int oz = sp.tz * kT + pz, oyy = sp.ty * kT + pyy, ox = sp.tx0 * kT + t * TX + 2 * pxp;
         const long long ridx = ((long long)oz * O1 + oyy) * O2 + ox;
@@ -1182,9 +1182,8 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
         it.g1 = dys[didx + 1];
         it.k = (2 * pxp) / kT;
     };
-    auto fetch_b = [&](int t, const float* dys, int j, Item& it) {
-        const unsigned short* lb = reinterpret_cast<const unsigned short*>(smem + kG2List + (t & 1) * g2_list_bytes<TX>()) + 8 * 8 * NPX;
-        const int vid = lb[j];
+    auto fetch_a = [&](int t, const float* dys, int j, Item& it) { fetch_a_id(t, dys, list_a(t)[j], it); };
+    auto fetch_b_id = [&](int t, const float* dys, int vid, Item& it) {
         const int pid = vid >> 1, v = vid & 1;
         const int pxp = pid % NPX, pyy = (pid / NPX) & 7, pz = pid / (NPX * 8);
         const int oz = sp.tz * kT + pz, oyy = sp.ty * kT + pyy, ox = sp.tx0 * kT + t * TX + 2 * pxp + v;
@@ -1192,6 +1191,7 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
         it.g0 = dys[oz * hg.img_sz + oyy * hg.img_sy + ox];
         it.k = (2 * pxp) / kT;
     };
+    auto fetch_b = [&](int t, const float* dys, int j, Item& it) { fetch_b_id(t, dys, list_b(t)[j], it); };
 
 #ifdef EDHIP_EXPERIMENTS
     // per-wave phase clocks (s_memtime ticks summed over the strip): produce, consume, wait B3, fetch + flush, wait B1
@@ -1209,6 +1209,11 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
         request(1);
     lds_barrier();            // lists of tile 0
     int n_a = uni(cnt[0]), n_b = uni(cnt[1]);
+    float gtot0;        // sum of |dY| over the current tile (first step)
+    {
+        const float* gsum = reinterpret_cast<const float*>(smem + kG2Sum);
+        gtot0 = unif((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
+    }
     Item cur;
     if (tid < n_a)
         fetch_a(0, dy, tid, cur);
@@ -1277,8 +1282,7 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
             const bool last_step = ss + 1 == hg.nsteps;
             float gtot;
             if (ss == 0) {
-                const float* gsum = reinterpret_cast<const float*>(smem + kG2Sum) + (ti & 1) * 4;
-                gtot = unif((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
+                gtot = gtot0;
             } else {
                 // later steps (channels) of the same tile: their own sum, in the NEXT tile's slot once that
                 // tile's producer is done with it... kept apart instead: slot 2 (bytes 32..47 of the counters' pad)
@@ -1451,57 +1455,79 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
             ED_TICK(2);
             if (tid < 2)
                 cnt[(ti % 3) * 2 + tid] = 0;      // this tile's counts: read by every wave before this barrier; next used by tile ti + 3
-            int next_a = 0, next_b = 0;
-            if (last_step && ti + 1 < ntile) {
-                // the next tile's first items, requested in front of this tile's flush atomics
-                next_a = uni(cnt[((ti + 1) % 3) * 2]);
-                next_b = uni(cnt[((ti + 1) % 3) * 2 + 1]);
-                if (tid < next_a)
-                    fetch_a(ti + 1, dy, tid, cur);
-                else if (tb < next_b)
-                    fetch_b(ti + 1, dy, tb, cur);
+            // Behind the barrier every LDS operation of this wave queues behind the other workgroups' scatter
+            // atomics (about a microsecond per round trip, tools/g2_phases.py), so what the rest of the round
+            // needs from LDS is requested in ONE batch: the next tile's counts, this lane's first entries of its
+            // two lists (speculative: used only below the counts) and every exchange of the flush's first pass.
+            constexpr int FL = 32, FR = kBlock / FL, FU = 20;
+            const int ftf = fresh_tid();
+            const int sub = ftf & (FL - 1);
+            const int rslot = ftf / FL;
+            int next_a = 0, next_b = 0, first_a = 0, first_b = 0;
+            float4 next_sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool more = last_step && ti + 1 < ntile;
+            if (more) {
+                next_a = cnt[((ti + 1) % 3) * 2];
+                next_b = cnt[((ti + 1) % 3) * 2 + 1];
+                next_sum = *reinterpret_cast<const float4*>(smem + kG2Sum + ((ti + 1) & 1) * 16);
+                first_a = list_a(ti + 1)[tid];
+                first_b = list_b(ti + 1)[tb];
             }
-            // flush: half a wave per box row, one float atomic per touched source element.  Every exchange of a
-            // lane (read + reset of up to FU cells, rows FR apart) is issued before the first result is used: an
-            // LDS operation queues behind the other workgroups' scatter atomics.
-            {
-                constexpr int FL = 32, FR = kBlock / FL, FU = 20;
-                const int ftf = fresh_tid();
-                const int sub = ftf & (FL - 1);
-                const int rslot = ftf / FL;
-                const float inv_by = 1.f / (float)by;
+            auto exchange = [&](int xi, bool xin, int r0, int (&acc)[FU]) {
+#pragma unroll
+                for (int q = 0; q < FU; ++q) {
+                    const int r = r0 + q * FR;
+                    acc[q] = (xin && r < nrows) ? __hip_atomic_exchange(&box[r * pitch + xi], 0, __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_WORKGROUP)
+                                                : 0;
+                }
+            };
+            // one float atomic per touched source element, half a wave per box row (deform.c:791-813: mirror-mapped at the edges)
+            const float inv_by = 1.f / (float)by;
+            auto emit = [&](int xs, int r0, const int (&acc)[FU]) {
+#pragma unroll
+                for (int q = 0; q < FU; ++q) {
+                    if (acc[q] != 0) {
+                        const int r = r0 + q * FR;
+                        const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                        int rowoff;
+                        if (interior)
+                            rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
+                        else
+                            rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
+                                     mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+#ifdef EDHIP_EXPERIMENTS
+                        if (hg.dbg & 32)      // timing experiment: plain stores instead of atomics (wrong results)
+                            __builtin_nontemporal_store((float)acc[q] * inv_scale, dst + (rowoff + xs));
+                        else
+#endif
+                        unsafeAtomicAdd(dst + (rowoff + xs), (float)acc[q] * inv_scale);
+                    }
+                }
+            };
+            int acc0[FU];
+            const bool xin0 = sub < flush_x;
+            exchange(sub, xin0, rslot, acc0);
+            if (more) {
+                // the next tile's first items, requested in front of this tile's flush atomics
+                next_a = uni(next_a);
+                next_b = uni(next_b);
+                gtot0 = unif((next_sum.x + next_sum.y) + (next_sum.z + next_sum.w));
+                if (tid < next_a)
+                    fetch_a_id(ti + 1, dy, first_a, cur);
+                else if (tb < next_b)
+                    fetch_b_id(ti + 1, dy, first_b, cur);
+            }
+            if (flush_x > 0) {
+                emit(interior ? sub : mirror_i32(b0[2] + sub, hg.in_len[2]), rslot, acc0);
                 for (int xo = 0; xo < flush_x; xo += FL) {
                     const int xi = xo + sub;
                     const bool xin = xi < ext[2];
                     const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
-                    for (int r0 = rslot; r0 < nrows; r0 += FU * FR) {
+                    for (int r0 = rslot + (xo == 0 ? FU * FR : 0); r0 < nrows; r0 += FU * FR) {
                         int acc[FU];
-#pragma unroll
-                        for (int q = 0; q < FU; ++q) {
-                            const int r = r0 + q * FR;
-                            acc[q] = (xin && r < nrows) ? __hip_atomic_exchange(&box[r * pitch + xi], 0, __ATOMIC_RELAXED,
-                                                                                __HIP_MEMORY_SCOPE_WORKGROUP)
-                                                        : 0;
-                        }
-#pragma unroll
-                        for (int q = 0; q < FU; ++q) {
-                            if (acc[q] != 0) {
-                                const int r = r0 + q * FR;
-                                const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
-                                int rowoff;
-                                if (interior)
-                                    rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
-                                else
-                                    rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
-                                             mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
-#ifdef EDHIP_EXPERIMENTS
-                                if (hg.dbg & 32)      // timing experiment: plain stores instead of atomics (wrong results)
-                                    __builtin_nontemporal_store((float)acc[q] * inv_scale, dst + (rowoff + xs));
-                                else
-#endif
-                                unsafeAtomicAdd(dst + (rowoff + xs), (float)acc[q] * inv_scale);
-                            }
-                        }
+                        exchange(xi, xin, r0, acc);
+                        emit(xs, r0, acc);
                     }
                 }
             }
