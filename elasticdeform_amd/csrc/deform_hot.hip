@@ -1028,7 +1028,9 @@ constexpr int kG2Sum = 416;                    // float[2][4]: per-wave sums of 
 constexpr int kG2Cnt = 448;                    // int[3][2]: items on the two lists, three tiles in rotation
 constexpr int kG2List = 512;                   // two tiles in rotation: u16[8 * 8 * TX / 2] regular pairs | u16[8 * 8 * TX] single voxels
 template <int TX> constexpr int g2_list_bytes() { return 2 * (8 * 8 * TX / 2) + 2 * (8 * 8 * TX); }
-template <int TX> constexpr int g2_cells() { return (kG2List + 2 * g2_list_bytes<TX>() + 15) & ~15; }
+constexpr int kG2Rows = 512;                   // int[kG2Rows]: offset in the volume of each box row of the current tile (flush)
+template <int TX> constexpr int g2_rowtab() { return (kG2List + 2 * g2_list_bytes<TX>() + 15) & ~15; }
+template <int TX> constexpr int g2_cells() { return g2_rowtab<TX>() + 4 * kG2Rows; }
 
 // Software pipeline over the tiles of a strip (measured on the first, unpipelined form: producer + barrier
 // alone 121 of 405 us, flush 127 us against hot_grad_kernel's 40 -- on this target stores and atomics count
@@ -1261,6 +1263,19 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
             delta[k] = ((unsigned)(tb0[k][0] - b0[0]) & 255u) | (((unsigned)(tb0[k][1] - b0[1]) & 255u) << 8) |
                        (((unsigned)(tb0[k][2] - b0[2]) & 255u) << 16);
 
+        // offsets of the box rows in the volume, for the flush (deform.c:791-813: rows outside the array are
+        // mirror-mapped): a table instead of two divisions and two products per cell in the flush's inner loop
+        int* rowtab = reinterpret_cast<int*>(smem + g2_rowtab<TX>());
+        const bool tabled = nrows <= kG2Rows;
+        if (work && tabled) {
+            const float inv_by = 1.f / (float)by;
+            for (int r = fresh_tid(); r < nrows; r += kBlock) {
+                const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                rowtab[r] = interior ? (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2]
+                                     : mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
+                                       mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+            }
+        }
         // ---- the NEXT tile's producer, in front of this tile's consumers ------------------------------
 #ifdef EDHIP_EXPERIMENTS
         if (hg.dbgbuf && ti == 0)
@@ -1473,29 +1488,29 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
                 first_a = list_a(ti + 1)[tid];
                 first_b = list_b(ti + 1)[tb];
             }
-            auto exchange = [&](int xi, bool xin, int r0, int (&acc)[FU]) {
+            auto exchange = [&](int xi, bool xin, int r0, int (&acc)[FU], int (&roff)[FU]) {
 #pragma unroll
                 for (int q = 0; q < FU; ++q) {
                     const int r = r0 + q * FR;
-                    acc[q] = (xin && r < nrows) ? __hip_atomic_exchange(&box[r * pitch + xi], 0, __ATOMIC_RELAXED,
-                                                                        __HIP_MEMORY_SCOPE_WORKGROUP)
-                                                : 0;
+                    const bool on = xin && r < nrows;
+                    acc[q] = on ? __hip_atomic_exchange(&box[r * pitch + xi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+                    roff[q] = (on && tabled) ? rowtab[r] : 0;
                 }
             };
             // one float atomic per touched source element, half a wave per box row (deform.c:791-813: mirror-mapped at the edges)
             const float inv_by = 1.f / (float)by;
-            auto emit = [&](int xs, int r0, const int (&acc)[FU]) {
+            auto emit = [&](int xs, int r0, const int (&acc)[FU], const int (&roff)[FU]) {
 #pragma unroll
                 for (int q = 0; q < FU; ++q) {
                     if (acc[q] != 0) {
-                        const int r = r0 + q * FR;
-                        const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
-                        int rowoff;
-                        if (interior)
-                            rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
-                        else
-                            rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
-                                     mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+                        int rowoff = roff[q];
+                        if (!tabled) {       // (a box of more than kG2Rows rows: uniform, rare)
+                            const int r = r0 + q * FR;
+                            const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
+                            rowoff = interior ? (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2]
+                                              : mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
+                                                mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+                        }
 #ifdef EDHIP_EXPERIMENTS
                         if (hg.dbg & 32)      // timing experiment: plain stores instead of atomics (wrong results)
                             __builtin_nontemporal_store((float)acc[q] * inv_scale, dst + (rowoff + xs));
@@ -1505,9 +1520,9 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
                     }
                 }
             };
-            int acc0[FU];
+            int acc0[FU], roff0[FU];
             const bool xin0 = sub < flush_x;
-            exchange(sub, xin0, rslot, acc0);
+            exchange(sub, xin0, rslot, acc0, roff0);
             if (more) {
                 // the next tile's first items, requested in front of this tile's flush atomics
                 next_a = uni(next_a);
@@ -1519,15 +1534,15 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
                     fetch_b_id(ti + 1, dy, first_b, cur);
             }
             if (flush_x > 0) {
-                emit(interior ? sub : mirror_i32(b0[2] + sub, hg.in_len[2]), rslot, acc0);
+                emit(interior ? sub : mirror_i32(b0[2] + sub, hg.in_len[2]), rslot, acc0, roff0);
                 for (int xo = 0; xo < flush_x; xo += FL) {
                     const int xi = xo + sub;
                     const bool xin = xi < ext[2];
                     const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
                     for (int r0 = rslot + (xo == 0 ? FU * FR : 0); r0 < nrows; r0 += FU * FR) {
-                        int acc[FU];
-                        exchange(xi, xin, r0, acc);
-                        emit(xs, r0, acc);
+                        int acc[FU], roff[FU];
+                        exchange(xi, xin, r0, acc, roff);
+                        emit(xs, r0, acc, roff);
                     }
                 }
             }
@@ -1631,7 +1646,7 @@ hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_
 // K2 from records: LDS = parameters | sums | counters | two work lists | cells
 size_t hot_grad2_lds_bytes(int* box_cap, bool large)
 {
-    size_t cells = large ? 44 * 1024 : 32 * 1024;      // 3 / 4 workgroups per CU
+    size_t cells = large ? 42 * 1024 : 30 * 1024;      // 3 / 4 workgroups per CU
     if (const char* kb = ed_env("EDHIP_G2_CELLS_KB"))
         cells = (size_t)atoi(kb) * 1024;
     *box_cap = (int)(cells / 4);
