@@ -1028,9 +1028,7 @@ constexpr int kG2Sum = 416;                    // float[2][4]: per-wave sums of 
 constexpr int kG2Cnt = 448;                    // int[3][2]: items on the two lists, three tiles in rotation
 constexpr int kG2List = 512;                   // two tiles in rotation: u16[8 * 8 * TX / 2] regular pairs | u16[8 * 8 * TX] single voxels
 template <int TX> constexpr int g2_list_bytes() { return 2 * (8 * 8 * TX / 2) + 2 * (8 * 8 * TX); }
-constexpr int kG2Rows = 512;                   // int[kG2Rows]: offset in the volume of each box row of the current tile (flush)
-template <int TX> constexpr int g2_rowtab() { return (kG2List + 2 * g2_list_bytes<TX>() + 15) & ~15; }
-template <int TX> constexpr int g2_cells() { return g2_rowtab<TX>() + 4 * kG2Rows; }
+template <int TX> constexpr int g2_cells() { return (kG2List + 2 * g2_list_bytes<TX>() + 15) & ~15; }
 
 // Software pipeline over the tiles of a strip (measured on the first, unpipelined form: producer + barrier
 // alone 121 of 405 us, flush 127 us against hot_grad_kernel's 40 -- on this target stores and atomics count
@@ -1246,7 +1244,11 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
         const int by = ext[1];
         const int nrows = ext[0] * by;
         const int nbox = nrows * pitch;
-        const bool fits = pitch != 0 && nbox <= hg.box_cap;
+        // (flush: one reflection maps every box index into the array -- always so for boxes made of window
+        // starts inside the array; anything else is left to the general kernels)
+        const bool simple = b0[0] > -hg.in_len[0] && b0[0] + ext[0] < 2 * hg.in_len[0] && b0[1] > -hg.in_len[1] &&
+                            b0[1] + ext[1] < 2 * hg.in_len[1] && b0[2] > -hg.in_len[2] && b0[2] + ext[2] < 2 * hg.in_len[2];
+        const bool fits = pitch != 0 && nbox <= hg.box_cap && simple;
         const bool work = any && fits;
         if (any && hg.hint && tid == 0 && (pitch == 0 || nbox > hg.small_cap))
             atomicAdd(hg.hint, NK);        // spill feedback, in 8-wide tiles
@@ -1263,19 +1265,6 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
             delta[k] = ((unsigned)(tb0[k][0] - b0[0]) & 255u) | (((unsigned)(tb0[k][1] - b0[1]) & 255u) << 8) |
                        (((unsigned)(tb0[k][2] - b0[2]) & 255u) << 16);
 
-        // offsets of the box rows in the volume, for the flush (deform.c:791-813: rows outside the array are
-        // mirror-mapped): a table instead of two divisions and two products per cell in the flush's inner loop
-        int* rowtab = reinterpret_cast<int*>(smem + g2_rowtab<TX>());
-        const bool tabled = nrows <= kG2Rows;
-        if (work && tabled) {
-            const float inv_by = 1.f / (float)by;
-            for (int r = fresh_tid(); r < nrows; r += kBlock) {
-                const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
-                rowtab[r] = interior ? (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2]
-                                     : mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
-                                       mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
-            }
-        }
         // ---- the NEXT tile's producer, in front of this tile's consumers ------------------------------
 #ifdef EDHIP_EXPERIMENTS
         if (hg.dbgbuf && ti == 0)
@@ -1471,13 +1460,18 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
             if (tid < 2)
                 cnt[(ti % 3) * 2 + tid] = 0;      // this tile's counts: read by every wave before this barrier; next used by tile ti + 3
             // Behind the barrier every LDS operation of this wave queues behind the other workgroups' scatter
-            // atomics (about a microsecond per round trip, tools/g2_phases.py), so what the rest of the round
-            // needs from LDS is requested in ONE batch: the next tile's counts, this lane's first entries of its
-            // two lists (speculative: used only below the counts) and every exchange of the flush's first pass.
-            constexpr int FL = 32, FR = kBlock / FL, FU = 20;
+            // atomics, so what the rest of the round needs from LDS is requested in ONE batch: the next tile's
+            // counts and sums, this lane's first entries of its two lists (speculative: used only below the
+            // counts) and the exchanges of the flush's first pass.
+            // Flush: a lane owns a column of the box -- one (y, x) and every z -- so that a cell's address is the
+            // previous one plus a plane (LDS) / a slice of the volume (global): the row-walking form spent two
+            // divisions and two products per cell and a third of the wave's time (tools/g2_phases.py: the flush is
+            // bound by its instruction count).  8 y rows x 32 x per pass, FY passes of FZ planes per batch.
+            constexpr int FL = 32, FR = kBlock / FL, FY = 2, FZ = 8;
             const int ftf = fresh_tid();
-            const int sub = ftf & (FL - 1);
-            const int rslot = ftf / FL;
+            const int xl = ftf & (FL - 1);
+            const int yl = ftf / FL;
+            const int plane_cells = by * pitch;
             int next_a = 0, next_b = 0, first_a = 0, first_b = 0;
             float4 next_sum = make_float4(0.f, 0.f, 0.f, 0.f);
             const bool more = last_step && ti + 1 < ntile;
@@ -1488,41 +1482,54 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
                 first_a = list_a(ti + 1)[tid];
                 first_b = list_b(ti + 1)[tb];
             }
-            auto exchange = [&](int xi, bool xin, int r0, int (&acc)[FU], int (&roff)[FU]) {
+            // cells (z0 .. z0 + FZ, yo + 8 p + yl, xo + xl), p < FY: read and reset in one LDS operation each
+            auto exchange = [&](int xo, int yo, int z0, int (&acc)[FY][FZ]) {
 #pragma unroll
-                for (int q = 0; q < FU; ++q) {
-                    const int r = r0 + q * FR;
-                    const bool on = xin && r < nrows;
-                    acc[q] = on ? __hip_atomic_exchange(&box[r * pitch + xi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-                    roff[q] = (on && tabled) ? rowtab[r] : 0;
-                }
-            };
-            // one float atomic per touched source element, half a wave per box row (deform.c:791-813: mirror-mapped at the edges)
-            const float inv_by = 1.f / (float)by;
-            auto emit = [&](int xs, int r0, const int (&acc)[FU], const int (&roff)[FU]) {
+                for (int p = 0; p < FY; ++p) {
+                    const int yi = yo + FR * p + yl, xi = xo + xl;
 #pragma unroll
-                for (int q = 0; q < FU; ++q) {
-                    if (acc[q] != 0) {
-                        int rowoff = roff[q];
-                        if (!tabled) {       // (a box of more than kG2Rows rows: uniform, rare)
-                            const int r = r0 + q * FR;
-                            const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
-                            rowoff = interior ? (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2]
-                                              : mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
-                                                mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
-                        }
-#ifdef EDHIP_EXPERIMENTS
-                        if (hg.dbg & 32)      // timing experiment: plain stores instead of atomics (wrong results)
-                            __builtin_nontemporal_store((float)acc[q] * inv_scale, dst + (rowoff + xs));
-                        else
-#endif
-                        unsafeAtomicAdd(dst + (rowoff + xs), (float)acc[q] * inv_scale);
+                    for (int q = 0; q < FZ; ++q)
+                        acc[p][q] = 0;
+                    if (xi < ext[2] && yi < by) {
+                        // (planes beyond the box: the last plane once more -- it reads the zero the first visit left)
+                        int* cp = box + yi * pitch + xi;
+#pragma unroll
+                        for (int q = 0; q < FZ; ++q)
+                            acc[p][q] = __hip_atomic_exchange(cp + min(z0 + q, ext[0] - 1) * plane_cells, 0, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             };
-            int acc0[FU], roff0[FU];
-            const bool xin0 = sub < flush_x;
-            exchange(sub, xin0, rslot, acc0, roff0);
+            // one float atomic per touched source element.  A box that sticks out of the array holds the taps of
+            // windows at the array's ends, which the reference mirror-maps (deform.c:791-813); the window starts
+            // themselves lie inside the array, so one reflection is all a box index ever needs (`simple`, above).
+            auto mirror1 = [](int i, int n) { return min(max(i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i), 0), n - 1); };
+            auto emit = [&](int xo, int yo, int z0, const int (&acc)[FY][FZ]) {
+#pragma unroll
+                for (int p = 0; p < FY; ++p) {
+                    const int yi = yo + FR * p + yl, xi = xo + xl;
+                    if (interior) {
+                        float* col = dst + ((b0[0] + z0) * hg.vol_sz + (b0[1] + yi) * hg.vol_sy + b0[2] + xi);
+#pragma unroll
+                        for (int q = 0; q < FZ; ++q) {
+                            if (acc[p][q] != 0)
+                                unsafeAtomicAdd(col + q * hg.vol_sz, (float)acc[p][q] * inv_scale);
+                        }
+                    } else {
+                        float* col = dst + (mirror1(b0[1] + yi, hg.in_len[1]) * hg.vol_sy + mirror1(b0[2] + xi, hg.in_len[2]));
+                        int zv = b0[0] + z0;
+                        asm volatile("" : "+v"(zv));        // (vector arithmetic on purpose: 24 scalar mirror maps cost 270 spilled SGPRs)
+#pragma unroll
+                        for (int q = 0; q < FZ; ++q) {
+                            if (acc[p][q] != 0)
+                                unsafeAtomicAdd(col + mirror1(zv + q, hg.in_len[0]) * hg.vol_sz, (float)acc[p][q] * inv_scale);
+                        }
+                    }
+                }
+            };
+            int acc0[FY][FZ];
+            if (flush_x > 0)
+                exchange(0, 0, 0, acc0);
             if (more) {
                 // the next tile's first items, requested in front of this tile's flush atomics
                 next_a = uni(next_a);
@@ -1534,17 +1541,14 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
                     fetch_b_id(ti + 1, dy, first_b, cur);
             }
             if (flush_x > 0) {
-                emit(interior ? sub : mirror_i32(b0[2] + sub, hg.in_len[2]), rslot, acc0, roff0);
-                for (int xo = 0; xo < flush_x; xo += FL) {
-                    const int xi = xo + sub;
-                    const bool xin = xi < ext[2];
-                    const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
-                    for (int r0 = rslot + (xo == 0 ? FU * FR : 0); r0 < nrows; r0 += FU * FR) {
-                        int acc[FU], roff[FU];
-                        exchange(xi, xin, r0, acc, roff);
-                        emit(xs, r0, acc, roff);
-                    }
-                }
+                emit(0, 0, 0, acc0);
+                for (int xo = 0; xo < flush_x; xo += FL)
+                    for (int yo = 0; yo < by; yo += FR * FY)
+                        for (int z0 = (xo == 0 && yo == 0) ? FZ : 0; z0 < ext[0]; z0 += FZ) {
+                            int acc[FY][FZ];
+                            exchange(xo, yo, z0, acc);
+                            emit(xo, yo, z0, acc);
+                        }
             }
             ED_TICK(3);
             lds_barrier();               // B1: the cells are back at zero
@@ -1646,7 +1650,7 @@ hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_
 // K2 from records: LDS = parameters | sums | counters | two work lists | cells
 size_t hot_grad2_lds_bytes(int* box_cap, bool large)
 {
-    size_t cells = large ? 42 * 1024 : 30 * 1024;      // 3 / 4 workgroups per CU
+    size_t cells = large ? 44 * 1024 : 32 * 1024;      // 3 / 4 workgroups per CU
     if (const char* kb = ed_env("EDHIP_G2_CELLS_KB"))
         cells = (size_t)atoi(kb) * 1024;
     *box_cap = (int)(cells / 4);
