@@ -1464,14 +1464,15 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
             // counts and sums, this lane's first entries of its two lists (speculative: used only below the
             // counts) and the exchanges of the flush's first pass.
             // Flush: a lane owns a column of the box -- one (y, x) and every z -- so that a cell's address is the
-            // previous one plus a plane (LDS) / a slice of the volume (global): the row-walking form spent two
-            // divisions and two products per cell and a third of the wave's time (tools/g2_phases.py: the flush is
-            // bound by its instruction count).  8 y rows x 32 x per pass, FY passes of FZ planes per batch.
-            constexpr int FL = 32, FR = kBlock / FL, FY = 2, FZ = 8;
+            // previous one plus a plane (LDS) / a slice of the volume (global); the columns of the (y, x) plane are
+            // dealt to the 256 lanes in row-major order (one pass for the usual ~12 x 20 plane).  The row-walking
+            // form spent two divisions and two products per cell, left a third of the lanes idle and took a third
+            // of the wave's time (tools/g2_phases.py: the flush is bound by its instruction count).
+            constexpr int FZ = 16;
             const int ftf = fresh_tid();
-            const int xl = ftf & (FL - 1);
-            const int yl = ftf / FL;
             const int plane_cells = by * pitch;
+            const int ncol = flush_x > 0 ? by * ext[2] : 0;
+            const float inv_ex = 1.f / (float)ext[2];
             int next_a = 0, next_b = 0, first_a = 0, first_b = 0;
             float4 next_sum = make_float4(0.f, 0.f, 0.f, 0.f);
             const bool more = last_step && ti + 1 < ntile;
@@ -1482,54 +1483,47 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
                 first_a = list_a(ti + 1)[tid];
                 first_b = list_b(ti + 1)[tb];
             }
-            // cells (z0 .. z0 + FZ, yo + 8 p + yl, xo + xl), p < FY: read and reset in one LDS operation each
-            auto exchange = [&](int xo, int yo, int z0, int (&acc)[FY][FZ]) {
+            // cells (z0 .. z0 + FZ) of column c: read and reset in one LDS operation each
+            auto exchange = [&](int c, int z0, int (&acc)[FZ]) {
 #pragma unroll
-                for (int p = 0; p < FY; ++p) {
-                    const int yi = yo + FR * p + yl, xi = xo + xl;
+                for (int q = 0; q < FZ; ++q)
+                    acc[q] = 0;
+                if (c < ncol) {
+                    const int yi = (int)(((float)c + 0.5f) * inv_ex), xi = c - yi * ext[2];
+                    // (planes beyond the box: the last plane once more -- it reads the zero the first visit left)
+                    int* cp = box + yi * pitch + xi;
 #pragma unroll
                     for (int q = 0; q < FZ; ++q)
-                        acc[p][q] = 0;
-                    if (xi < ext[2] && yi < by) {
-                        // (planes beyond the box: the last plane once more -- it reads the zero the first visit left)
-                        int* cp = box + yi * pitch + xi;
-#pragma unroll
-                        for (int q = 0; q < FZ; ++q)
-                            acc[p][q] = __hip_atomic_exchange(cp + min(z0 + q, ext[0] - 1) * plane_cells, 0, __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                        acc[q] = __hip_atomic_exchange(cp + min(z0 + q, ext[0] - 1) * plane_cells, 0, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             };
             // one float atomic per touched source element.  A box that sticks out of the array holds the taps of
             // windows at the array's ends, which the reference mirror-maps (deform.c:791-813); the window starts
             // themselves lie inside the array, so one reflection is all a box index ever needs (`simple`, above).
             auto mirror1 = [](int i, int n) { return min(max(i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i), 0), n - 1); };
-            auto emit = [&](int xo, int yo, int z0, const int (&acc)[FY][FZ]) {
+            auto emit = [&](int c, int z0, const int (&acc)[FZ]) {
+                const int yi = (int)(((float)c + 0.5f) * inv_ex), xi = c - yi * ext[2];
+                if (interior) {
+                    float* col = dst + ((b0[0] + z0) * hg.vol_sz + (b0[1] + yi) * hg.vol_sy + b0[2] + xi);
 #pragma unroll
-                for (int p = 0; p < FY; ++p) {
-                    const int yi = yo + FR * p + yl, xi = xo + xl;
-                    if (interior) {
-                        float* col = dst + ((b0[0] + z0) * hg.vol_sz + (b0[1] + yi) * hg.vol_sy + b0[2] + xi);
+                    for (int q = 0; q < FZ; ++q) {
+                        if (acc[q] != 0)
+                            unsafeAtomicAdd(col + q * hg.vol_sz, (float)acc[q] * inv_scale);
+                    }
+                } else {
+                    float* col = dst + (mirror1(b0[1] + yi, hg.in_len[1]) * hg.vol_sy + mirror1(b0[2] + xi, hg.in_len[2]));
+                    int zv = b0[0] + z0;
+                    asm volatile("" : "+v"(zv));        // (vector arithmetic on purpose: scalar mirror maps of every plane cost 270 spilled SGPRs)
 #pragma unroll
-                        for (int q = 0; q < FZ; ++q) {
-                            if (acc[p][q] != 0)
-                                unsafeAtomicAdd(col + q * hg.vol_sz, (float)acc[p][q] * inv_scale);
-                        }
-                    } else {
-                        float* col = dst + (mirror1(b0[1] + yi, hg.in_len[1]) * hg.vol_sy + mirror1(b0[2] + xi, hg.in_len[2]));
-                        int zv = b0[0] + z0;
-                        asm volatile("" : "+v"(zv));        // (vector arithmetic on purpose: 24 scalar mirror maps cost 270 spilled SGPRs)
-#pragma unroll
-                        for (int q = 0; q < FZ; ++q) {
-                            if (acc[p][q] != 0)
-                                unsafeAtomicAdd(col + mirror1(zv + q, hg.in_len[0]) * hg.vol_sz, (float)acc[p][q] * inv_scale);
-                        }
+                    for (int q = 0; q < FZ; ++q) {
+                        if (acc[q] != 0)
+                            unsafeAtomicAdd(col + mirror1(zv + q, hg.in_len[0]) * hg.vol_sz, (float)acc[q] * inv_scale);
                     }
                 }
             };
-            int acc0[FY][FZ];
-            if (flush_x > 0)
-                exchange(0, 0, 0, acc0);
+            int acc0[FZ];
+            exchange(ftf, 0, acc0);
             if (more) {
                 // the next tile's first items, requested in front of this tile's flush atomics
                 next_a = uni(next_a);
@@ -1540,15 +1534,14 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
                 else if (tb < next_b)
                     fetch_b_id(ti + 1, dy, first_b, cur);
             }
-            if (flush_x > 0) {
-                emit(0, 0, 0, acc0);
-                for (int xo = 0; xo < flush_x; xo += FL)
-                    for (int yo = 0; yo < by; yo += FR * FY)
-                        for (int z0 = (xo == 0 && yo == 0) ? FZ : 0; z0 < ext[0]; z0 += FZ) {
-                            int acc[FY][FZ];
-                            exchange(xo, yo, z0, acc);
-                            emit(xo, yo, z0, acc);
-                        }
+            if (ncol > 0) {
+                emit(ftf, 0, acc0);
+                for (int c0 = 0; c0 < ncol; c0 += kBlock)
+                    for (int z0 = c0 == 0 ? FZ : 0; z0 < ext[0]; z0 += FZ) {
+                        int acc[FZ];
+                        exchange(c0 + ftf, z0, acc);
+                        emit(c0 + ftf, z0, acc);
+                    }
             }
             ED_TICK(3);
             lds_barrier();               // B1: the cells are back at zero
