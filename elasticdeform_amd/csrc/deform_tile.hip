@@ -1476,8 +1476,12 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 const size_t kb_flags = ((size_t)nb * sizeof(int) + 255) & ~(size_t)255;
                 const size_t kb_stash = ((size_t)nb * ngrid * sizeof(double) + 255) & ~(size_t)255;
                 // records: orders 1-3 on the 4-wave kernels (the one-wave kernels of orders 4 / 5 keep to boxes)
+                // Measured (profiles/r04_records_route.txt): with the records the gradient kernel of the benchmark
+                // step takes 290-305 us against hot_grad_kernel's 303-306, and K1 pays 15-20 us for writing them;
+                // the route stays in the tree for the profiling build (EDHIP_RECORDS=1), the shipped library keeps
+                // the boxes-only hand-over.
                 bool want_rec = ORDER <= 3 && ngrid <= 65536 && (double)nvox * nb * 16.0 <= (double)((size_t)16 << 30) &&
-                                !ed_env("EDHIP_NO_RECORDS");
+                                ed_env("EDHIP_RECORDS") != nullptr;
 #ifdef EDHIP_EXPERIMENTS
                 if (ed_env("EDHIP_WAVE"))
                     want_rec = false;

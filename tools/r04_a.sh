@@ -10,17 +10,17 @@ cp elasticdeform_amd/libedhip.so /tmp/libedhip_ship.so
 cp tools/libedhip_exp.so elasticdeform_amd/libedhip.so
 {
 for s in 5 10; do
-  TAG="new(rec)      " timeout 200 python tools/time_k12.py 256 3 $s
-  TAG="old(boxes)    " EDHIP_NO_RECORDS=1 timeout 200 python tools/time_k12.py 256 3 $s
+  EDHIP_RECORDS=1 TAG="new(rec)      " timeout 200 python tools/time_k12.py 256 3 $s
+  TAG="old(boxes)    " timeout 200 python tools/time_k12.py 256 3 $s
 done
-TAG="new standalone" BOXES=0 timeout 200 python tools/time_k12.py 256 3 5
-TAG="old standalone" BOXES=0 EDHIP_NO_RECORDS=1 timeout 200 python tools/time_k12.py 256 3 5
+EDHIP_RECORDS=1 TAG="new standalone" BOXES=0 timeout 200 python tools/time_k12.py 256 3 5
+TAG="old standalone" BOXES=0 timeout 200 python tools/time_k12.py 256 3 5
 for o in 1 2; do
-  TAG="new(rec) " timeout 200 python tools/time_k12.py 256 $o 5
-  TAG="old      " EDHIP_NO_RECORDS=1 timeout 200 python tools/time_k12.py 256 $o 5
+  EDHIP_RECORDS=1 TAG="new(rec) " timeout 200 python tools/time_k12.py 256 $o 5
+  TAG="old      " timeout 200 python tools/time_k12.py 256 $o 5
 done
-TAG="new 128 " timeout 200 python tools/time_k12.py 128 3 5
-TAG="old 128 " EDHIP_NO_RECORDS=1 timeout 200 python tools/time_k12.py 128 3 5
+EDHIP_RECORDS=1 TAG="new 128 " timeout 200 python tools/time_k12.py 128 3 5
+TAG="old 128 " timeout 200 python tools/time_k12.py 128 3 5
 } > $O/time_k12.txt 2>&1
 cp /tmp/libedhip_ship.so elasticdeform_amd/libedhip.so
 cat $O/pytest.txt | tail -40; cat $O/time_k12.txt; python -c "

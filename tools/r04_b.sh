@@ -8,8 +8,8 @@ cp tools/libedhip_exp.so elasticdeform_amd/libedhip.so
 for d in 0 4 8 12; do
   TAG="dbg=$d " EDHIP_TILE_DBG=$d ITERS=20 timeout 200 python tools/time_k12.py 256 3 5
 done
-TAG="old    " EDHIP_NO_RECORDS=1 ITERS=20 timeout 200 python tools/time_k12.py 256 3 5
-TAG="new s10" ITERS=20 timeout 200 python tools/time_k12.py 256 3 10
-TAG="old s10" EDHIP_NO_RECORDS=1 ITERS=20 timeout 200 python tools/time_k12.py 256 3 10
+TAG="old    " ITERS=20 timeout 200 python tools/time_k12.py 256 3 5
+EDHIP_RECORDS=1 TAG="new s10" ITERS=20 timeout 200 python tools/time_k12.py 256 3 10
+TAG="old s10" ITERS=20 timeout 200 python tools/time_k12.py 256 3 10
 } 2>&1 | grep -v amdgpu.ids > $O/abl.txt
 cat $O/abl.txt

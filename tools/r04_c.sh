@@ -12,7 +12,7 @@ done
 TAG="wg5 24KB" EDHIP_G2_WG5=1 EDHIP_G2_CELLS_KB=24 ITERS=20 timeout 200 python tools/time_k12.py 256 3 5
 TAG="wg4 24KB" EDHIP_G2_CELLS_KB=24 ITERS=20 timeout 200 python tools/time_k12.py 256 3 5
 TAG="wg3 44KB" EDHIP_G2_CELLS_KB=44 ITERS=20 timeout 200 python tools/time_k12.py 256 3 5
-TAG="old    " EDHIP_NO_RECORDS=1 ITERS=20 timeout 200 python tools/time_k12.py 256 3 5
+TAG="old    " ITERS=20 timeout 200 python tools/time_k12.py 256 3 5
 } 2>&1 | grep -v amdgpu.ids > $O/abl.txt
 cp /tmp/libedhip_ship.so elasticdeform_amd/libedhip.so
 cat $O/pytest.txt; cat $O/abl.txt
