@@ -344,6 +344,94 @@ __device__ __forceinline__ void hot_tile_coords(const HotGeom& hg, const HotPara
         box_reduce_to_lds(red, lane, lo, hi);
 }
 
+// self_serve: the tiles of a strip whose source box did not fit the LDS box, gathered straight from global
+// memory behind the strip loop -- a rare path (2 tiles of 32768 on the benchmark volume) that saves the call
+// the two launches of the spill levels.  Coordinates from the strip's tables in LDS with hot_coords, taps
+// mirror-mapped per axis (deform.c:791-813), accumulation x, y, z as chains of fused multiply-adds from zero:
+// the bits every other level gives.  Not inlined: called where nothing of the tile loop is live any more
+// (inlined into the loop an earlier form cost K1 its register allocation, profiles/r03_bench_misc.txt).
+template <int ORDER, bool AFFINE>
+__device__ __forceinline__ void hot_fwd_unfit(const HotGeom& hg, const HotStrip& sp, char* smem, unsigned unfit)
+{
+    constexpr int NT = ORDER + 1;
+    const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
+    const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kOffHot);
+    const int tid = threadIdx.x;
+    const int yy = (tid >> 3) & 7, xx = tid & 7, zq = tid >> 6;
+    const float* __restrict__ vol = hg.vol_r + sp.sample * hg.vol_bstride;
+    float* img = hg.img_w + sp.sample * hg.img_bstride;
+    const int oy = sp.ty * kT + yy;
+    for (int ti = 0; ti < sp.ntile; ++ti) {
+        if (!((unfit >> ti) & 1u))
+            continue;
+        const int ox = (sp.tx0 + ti) * kT + xx;
+        double tw[4];
+        int tib[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            tw[l] = tabx[ti * kT + xx].w[l];
+            tib[l] = tabx[ti * kT + xx].idx[l] * 8;
+        }
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            const int zi = zq + 4 * i;
+            const int oz = sp.tz * kT + zi;
+            if (oz >= hg.out_len[0] || oy >= hg.out_len[1] || ox >= hg.out_len[2])
+                continue;
+            const char* qrow = smem + kOffQ + (zi * kT + yy) * (32 * hg.ncpx);
+            const int b[3] = {oz + hg.off[0], oy + hg.off[1], ox + hg.off[2]};
+            double P[3] = {0.0, 0.0, 0.0};
+            if (AFFINE) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h)
+                    P[h] = fma(hp->affine[h * 4 + 2], (double)ox,
+                               fma(hp->affine[h * 4 + 0], (double)oz,
+                                   fma(hp->affine[h * 4 + 1], (double)oy, hp->affine[h * 4 + 3] + hp->offd[h])));
+            }
+            int st[3];
+            float fr[3];
+            const bool cst = hot_coords<ORDER, AFFINE>(hg, hp, qrow, tw, tib, b, P, st, fr);
+            int tap[3][NT];
+            float w[3][NT];
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                weights_from_frac<float, ORDER>(fr[h], w[h]);
+                const int stride = h == 0 ? hg.vol_sz : (h == 1 ? hg.vol_sy : 1);
+#pragma unroll
+                for (int l = 0; l < NT; ++l)
+                    tap[h][l] = mirror_i32(st[h] + l, hg.in_len[h]) * stride;
+            }
+            const int obase = oz * hg.img_sz + oy * hg.img_sy + ox;
+            for (long long ss = 0; ss < hg.nsteps; ++ss) {
+                long long vol_off = 0, img_off = 0;
+                if (hg.nstep)
+                    hot_step_offsets(hp, ss, vol_off, img_off);
+                float val = hg.cval;
+                if (!cst) {
+                    const float* src = vol + vol_off;
+                    float a0 = 0.f;
+#pragma unroll
+                    for (int l0 = 0; l0 < NT; ++l0) {
+                        float a1 = 0.f;
+#pragma unroll
+                        for (int l1 = 0; l1 < NT; ++l1) {
+                            const float* p1 = src + (tap[0][l0] + tap[1][l1]);
+                            float a2 = 0.f;
+#pragma unroll
+                            for (int l2 = 0; l2 < NT; ++l2)
+                                a2 = fmaf(w[2][l2], p1[tap[2][l2]], a2);
+                            a1 = fmaf(w[1][l1], a2, a1);
+                        }
+                        a0 = fmaf(w[0][l0], a1, a0);
+                    }
+                    val = a0;
+                }
+                __builtin_nontemporal_store(val, img + (img_off + obase));
+            }
+        }
+    }
+}
+
 // ABL: compile-time ablation switches for profiling (0 in production; EDHIP_HOT_ABL selects one of
 // the instantiated values for order 3): 2 skip the gather, 4 skip the coordinates, 8 skip the
 // bounding-box reduction (analytic box), 32 skip staging, 64 skip the output store
@@ -426,6 +514,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
     int start[NV][3];
     float frac[NV][3];
     bool valid[NV], constant[NV];
+    unsigned unfit = 0;       // self_serve: tiles of this strip whose box did not fit
     if (PIPE)
         hot_tile_coords<ORDER, AFFINE, ABL, NV>(hg, hp, tabx, sred, qrow, oz, oy, sp.tx0 * kT, xx, lane, vzy, Pzy,
                                             start, frac, valid, constant);
@@ -485,7 +574,9 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         const bool staged = any && fits;
         if (!REC_ONLY && any && hg.hint && tid == 0 && !(pitch > 0 && nrows * pitch <= hg.small_cap))
             atomicAdd(hg.hint, 1);         // spill feedback: would not fit the standard box
-        if (!REC_ONLY && any && !fits && tid == 0) {    // hand the whole tile to the general kernels
+        if (!REC_ONLY && any && !fits && hg.self_serve)
+            unfit |= 1u << ti;                 // served below, behind the strip loop
+        else if (!REC_ONLY && any && !fits && tid == 0) {    // hand the whole tile to the general kernels
             const int slot = atomicAdd(&hg.spill[0], 1);
             hg.spill[1 + slot] = sp.sample * hg.ntiles +
                                  (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + sp.tx0 + ti;
@@ -631,6 +722,8 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
             }
         }
     }
+    if (!REC_ONLY && unfit)
+        hot_fwd_unfit<ORDER, AFFINE>(hg, sp, smem, unfit);
 }
 
 // ================================================================================================
@@ -848,13 +941,20 @@ ED_UNROLL(ED_K2_U1)
         const int nbox = nrows * pitch;
         if (hg.hint && tid == 0 && (pitch == 0 || nbox > hg.small_cap))
             atomicAdd(hg.hint, TX / kT);   // spill feedback, in 8-wide tiles
+        // self_serve: a tile that does not fit keeps an EMPTY box -- every live voxel then fails the window test
+        // below and scatters its taps straight to global memory (the path of a stale handed-over box)
+        bool direct_tile = false;
         if (pitch == 0 || nbox > hg.box_cap) {
-            if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < hg.tiles[2]) {
-                const int slot = atomicAdd(&hg.spill[0], 1);
-                hg.spill[1 + slot] = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] +
-                                     sp.tx0 + ti * (TX / kT) + tid;
+            if (hg.self_serve) {
+                direct_tile = true;
+            } else {
+                if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < hg.tiles[2]) {
+                    const int slot = atomicAdd(&hg.spill[0], 1);
+                    hg.spill[1 + slot] = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] +
+                                         sp.tx0 + ti * (TX / kT) + tid;
+                }
+                continue;
             }
-            continue;
         }
         const bool interior = b0[0] >= 0 && b0[0] + ext[0] <= hg.in_len[0] && b0[1] >= 0 &&
                               b0[1] + ext[1] <= hg.in_len[1] && b0[2] >= 0 && b0[2] + ext[2] <= hg.in_len[2];
@@ -906,8 +1006,8 @@ ED_UNROLL(ED_K2_U2)
                 weights_from_frac<float, ORDER>(fr[2], w2);
                 const int rz = st[0] - b0[0], ry = st[1] - b0[1], rx = st[2] - b0[2];
                 // boxes handed over by the forward call are a hint: a window outside goes the direct way
-                const bool outside = given && (rz < 0 || rz + ORDER >= ext[0] || ry < 0 || ry + ORDER >= ext[1] ||
-                                               rx < 0 || rx + ORDER >= ext[2]);
+                const bool outside = direct_tile || (given && (rz < 0 || rz + ORDER >= ext[0] || ry < 0 || ry + ORDER >= ext[1] ||
+                                                               rx < 0 || rx + ORDER >= ext[2]));
                 // (A contribution is resolved to wmax * sum|dY| / 2^31 of its TILE.  Sending voxels far
                 // below the tile's scale down the float path as well was measured and dropped: with a
                 // threshold of 2^-20 of the tile's sum 0.05 % of the voxels of a uniform-random dY take
@@ -974,7 +1074,7 @@ ED_UNROLL(ED_K2_U2)
                 const int sub = tid & (FL - 1);                // FU rows are issued before the first atomic
                 const int rslot = tid / FL;
                 const float inv_by = 1.f / (float)by;
-                const int nr = (hg.dbg & 64) ? 0 : nrows;
+                const int nr = ((hg.dbg & 64) || direct_tile) ? 0 : nrows;
                 for (int xo = 0; xo < ext[2]; xo += FL) {
                     const int xi = xo + sub;
                     const bool xin = xi < ext[2];

@@ -1281,6 +1281,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // calls of this geometry on this stream reported decides between the standard and the large boxes
     SpillHint* sh = nullptr;
     bool large_boxes = false;
+    // self-serve: the recent calls of this geometry left at most a handful of tiles to the spill list -- level 1
+    // then takes such tiles itself (straight from / to global memory) and the two spill launches are not made
+    bool self_serve = false;
     if constexpr (std::is_same<T, float>::value && ORDER >= 1) {
         sh = ed_env("EDHIP_NO_SPILL_HINT") ? nullptr : spill_hint(stream);
         if (sh) {
@@ -1296,6 +1299,11 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 ((unsigned long long)g.has_affine << 24) | ((unsigned long long)nb << 32));
             sh->absorb();
             large_boxes = sh->fraction(key) > 0.10f;
+            self_serve = sh->known(key) && sh->fraction(key) * (float)(ntiles * nb) <= 64.f;
+#ifdef EDHIP_EXPERIMENTS
+            if (const char* ss = ed_env("EDHIP_SELF_SERVE"))
+                self_serve = atoi(ss) != 0;
+#endif
             tg.hint_host = sh->dev;
             tg.hint_seq = sh->begin_call(key, (unsigned)(ntiles * nb));
         }
@@ -1403,6 +1411,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     }
     // ---- level 1: strips, small boxes, highest occupancy ------------------------------------------
     bool hot_done = false;
+    bool served_all = false;        // level 1 ran in self-serve form: no spill list to work off
     HotGeom hg;
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)(((nstrips * nb + 7) / 8) * 8);
@@ -1442,6 +1451,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 hg.mode = tg.mode;
                 hg.has_affine = tg.has_affine;
                 hg.dbg = tg.dbg;
+                hg.self_serve = (self_serve && ORDER <= 3) ? 1 : 0;      // (orders 4 / 5: the one-wave kernels, which spill as before)
                 hg.cval = (float)ve.cval;
                 hg.nstep = ve.nstep;
                 hg.nsteps = ve.nsteps;
@@ -1557,6 +1567,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     // samples whose records the forward call made from these very grid values -- (2) the
                     // gradient kernel that reads records and boxes
                     HotGeom rg = hg;
+                    rg.self_serve = 0;
                     int fcap = 0, foff = 0;
                     const size_t flds = hot_lds_bytes(false, tg.ncpx, &fcap, &foff, false);
                     rg.box_cap = fcap;
@@ -1567,6 +1578,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     hipError_t he = flds ? launch_hot_records(rg, ORDER, nblk, flds, stream) : hipErrorNotSupported;
                     if (he == hipSuccess) {
                         HotGeom gg = hg;
+                        gg.self_serve = 0;
                         gg.rec_valid = nullptr;
                         int gcap = 0, scap = 0;
                         (void)hot_grad2_lds_bytes(&scap, false);
@@ -1605,6 +1617,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
 #endif
                 if (hlds && !hot_done && (wave_mode & (GRAD ? 2 : 1))) {
                     HotGeom wg = hg;
+                    wg.self_serve = 0;
                     wg.strip_tiles = 4;
 #ifdef EDHIP_EXPERIMENTS
                     if (const char* st = ed_env("EDHIP_WAVE_STRIP"))
@@ -1655,6 +1668,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     const hipError_t he = launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
                     if (he == hipSuccess) {
                         hot_done = true;
+                        served_all = hg.self_serve != 0;
                         if (!GRAD && hg.boxes && key)
                             *key = cur;
                     } else if (he != hipErrorNotSupported)
@@ -1715,6 +1729,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     const size_t lds2 = t2.off_ov + box2;
     const unsigned n2 = (unsigned)(ntiles * nb < wgs2 ? ntiles * nb : wgs2);
     const bool skip_l2 = ed_env("EDHIP_SKIP_L2") != nullptr;      // debugging aid
+    if (served_all)
+        return e;               // level 1 has served every tile
     if (e == hipSuccess && !skip_l2) {
         if (GRAD)
             hipLaunchKernelGGL((deform_tile3_grad_kernel<T, (ORDER < 1 ? 2 : ORDER), 8>), dim3(n2),

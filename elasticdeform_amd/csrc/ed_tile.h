@@ -401,6 +401,11 @@ struct HotGeom {
     // rec_valid[sample] != 0 (device memory, written by the tables kernel of a gradient call): the
     // records in the buffer were made from these very displacement values -- a rec_only launch
     // leaves that sample alone.
+    // self_serve: a geometry whose recent calls left (almost) no tile to the spill list (spill feedback,
+    // ed_workspace.h) is launched without the level-2 / level-3 kernels behind it -- two launches that cost the
+    // benchmark step 36 us for 2 tiles of 32768 -- and level 1 serves a tile whose box does not fit itself,
+    // straight from / to global memory
+    int self_serve;
     float4* rec;
     long long rec_bstride;
     int rec_only;
