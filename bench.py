@@ -21,6 +21,19 @@ SURVEY.md section 8e) => weak scaling.
 5^3 grid each (512 volumes over 8 GPUs), forward + gradient through the single-launch batch kernels
 (deform_grid_batch / deform_grid_gradient_batch); same metric, same JSON line.
 
+`--workload cfg4` is BASELINE cfg4 (multi-input [3 x 256^3 float32 image order 3 mirror, 256^3 int32 labels
+order 0 nearest], axis, crop 64^3, 3x4 affine = rotate 10 deg + zoom 1.1 about the crop centre): forward +
+gradient per step, value = output voxels (4 x 64^3) per second; `crop_window` reports the forward / gradient
+call with the crop-aware prefilter window as the library chooses, forced on and forced off.
+
+`--collective` (with `--workload cfg5`, N > 1) is the other leg of SURVEY.md 8(e): the whole batch lives on
+rank 0, the grids are broadcast, the volumes go out and the results come back point to point
+(distributed.deform_batch_sharded(scatter_from=0, gather_to=0)); its own JSON line, `config.parallelism` says so.
+
+`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) and relays
+rank 0's JSON line.
+
 Extra objects on the JSON line:
   roofline      the DOMINANT kernel of the timed step = the kernel with the largest per-step GPU
                 time.  The level-1 launches of K1 (forward gather) and K2 (gradient scatter) are
@@ -33,6 +46,9 @@ Extra objects on the JSON line:
   north_star_kernel   the same numbers for K1, the kernel BASELINE.json's 50 % target is quoted on;
                 `frac_read_only` prices it on the READ bytes alone (4 B/voxel), the literal
                 "HBM-read roofline" of north_star.
+  fresh_grid    the step as an augmentation loop runs it: a NEW displacement tensor every step (sigma 5 and
+                sigma 10), so that whatever the library keeps from call to call (tile boxes, spill feedback,
+                the repeat-call lane) is measured as that pattern uses it; cfg2, rank 0, N = 1 only.
   stress        SURVEY.md 8(d) "report both": the same step at sigma = 10 (the README example's
                 aggressiveness: displacement gradient ~1.25, many tiles take the spill levels), a few
                 timed steps after the headline region; cfg2, rank 0, N = 1 only.
@@ -61,7 +77,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--side", type=int, default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2")
+    ap.add_argument("--workload", choices=("cfg2", "cfg4", "cfg5"), default="cfg2")
+    ap.add_argument("--collective", action="store_true",
+                    help="cfg5, N > 1: the batch lives on rank 0 (broadcast grids, point-to-point scatter / gather)")
     ap.add_argument("--batch", type=int, default=64, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help=argparse.SUPPRESS)      # profile collection: headline kernels only
@@ -126,8 +144,161 @@ def cpu_baseline(side=128):
     }
 
 
+def relaunch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks of one node (one process per GPU,
+    127.0.0.1 rendezvous) with the same arguments and relay their output; returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cfg4_main(args):
+    """BASELINE cfg4 on one GPU: multi-input + axis + crop + affine, forward + gradient per step."""
+    import importlib
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases as C
+    import elasticdeform_amd as ed
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    n = args.side or N_SIDE
+    (img, lab), disp, kw = C.cfg4_inputs(n)
+    dev = torch.device("cuda", 0)
+    Xs = [torch.from_numpy(img).to(dev), torch.from_numpy(lab).to(dev)]
+    dd = torch.from_numpy(disp).to(dev)
+    outs = ed.deform_grid(Xs, dd, **kw)
+    dYs = [torch.rand(outs[0].shape, device=dev, dtype=torch.float32), torch.ones_like(outs[1])]
+    xshape = [tuple(img.shape), tuple(lab.shape)]
+
+    def fwd():
+        return ed.deform_grid(Xs, dd, **kw)
+
+    def bwd():
+        return ed.deform_grid_gradient(dYs, dd, X_shape=xshape, **kw)
+
+    def timed(fn, iters=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return ts[len(ts) // 2]
+
+    for _ in range(args.warmup):
+        fwd()
+        bwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd()
+        bwd()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    window = {"auto": {"deform_grid_ms": round(timed(fwd), 4), "deform_grid_gradient_ms": round(timed(bwd), 4)}}
+    saved = (dgm.CROP_WINDOW_MIN_SAVING, dgm.CROP_WINDOW_MAX_FRACTION)
+    try:
+        dgm.CROP_WINDOW_MIN_SAVING, dgm.CROP_WINDOW_MAX_FRACTION = 0, 1.0
+        window["forced_on"] = {"deform_grid_ms": round(timed(fwd), 4), "deform_grid_gradient_ms": round(timed(bwd), 4)}
+        dgm.CROP_WINDOW_MIN_SAVING = 1 << 62
+        window["forced_off"] = {"deform_grid_ms": round(timed(fwd), 4), "deform_grid_gradient_ms": round(timed(bwd), 4)}
+    finally:
+        dgm.CROP_WINDOW_MIN_SAVING, dgm.CROP_WINDOW_MAX_FRACTION = saved
+    vox = float(sum(int(np.prod(o.shape)) for o in outs))
+    ms = elapsed / args.steps * 1e3
+    # algorithmic bytes of the step when every input is filtered whole (the reference's pipeline,
+    # deform_grid.py:155-164, 277-286): the three float32 channels through 3 forward + 3 transposed passes
+    filt_bytes = 2.0 * 24.0 * float(img.size)
+    res = {"metric": "Mvoxels/s fwd+grad, cfg4 multi-input crop 64^3", "value": round(vox * args.steps / elapsed / 1e6, 2),
+           "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "cfg4: [3x%d^3 float32 image order 3 mirror, %d^3 int32 labels order 0 nearest], "
+                                  "axis [(1,2,3),(0,1,2)], crop %d^3, affine rotate 10 deg + zoom 1.1, 5x5x5 grid sigma 5, "
+                                  "prefilter on, deform_grid + deform_grid_gradient per step" % (n, n, n // 4),
+                      "parallelism": "1 GPU"},
+           "roofline": {"bound": "hbm", "achieved": round(filt_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(filt_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                        "kernel": "whole step against the prefilter's algorithmic bytes when every channel is filtered whole "
+                                  "(K3 / K4: 24 B per input voxel each); the deform kernels touch 4 x 64^3 voxels",
+                        "algorithmic_bytes_per_step": int(filt_bytes)},
+           "crop_window": window,
+           "output_voxels_per_step": int(vox)}
+    print(json.dumps(res), flush=True)
+
+
+def collective_main(args, rank, world, dev, distributed):
+    """SURVEY.md 8(e), second leg: the whole cfg5 batch lives on rank 0; per step the grids are broadcast, the
+    volumes scattered and the results gathered point to point (forward, then the same for the gradient)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from elasticdeform_amd import distributed as edd
+    n = args.side or 128
+    B = args.batch * world                 # the batch of all ranks, resident on rank 0
+    sigma = 5.0 * n / 256
+    X = dY = disp = None
+    if rank == 0:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(2)
+        X = torch.rand((B, n, n, n), device=dev, dtype=torch.float32, generator=gen)
+        dY = torch.rand((B, n, n, n), device=dev, dtype=torch.float32, generator=gen)
+        disp = torch.from_numpy(np.random.default_rng(22).standard_normal((B, 3, 5, 5, 5)) * sigma).to(dev)
+    kw = dict(order=3, mode="mirror")
+
+    def step():
+        edd.deform_batch_sharded(X, disp, scatter_from=0, gather_to=0, device=dev, **kw)
+        edd.deform_batch_sharded(dY, disp, gradient=True, scatter_from=0, gather_to=0, device=dev, **kw)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        vox = float(B) * float(n) ** 3
+        moved = 4.0 * vox * 4.0 * (world - 1) / max(world, 1)       # X out, Y back, dY out, dX back: float32, off-rank shards only
+        print(json.dumps({
+            "metric": "Mvoxels/s fwd+grad, batch of 128^3 fp32 order=3, batch resident on rank 0",
+            "value": round(vox * args.steps / elapsed / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg5, collective leg: %d volumes of %d^3 float32 on rank 0, one 5x5x5 grid each, order 3, "
+                                   "mirror, prefilter on, forward + gradient per step" % (B, n),
+                       "parallelism": "grids broadcast; volumes scattered from and results gathered to rank 0 point to point "
+                                      "(backend %s); %d volumes computed per rank" % (dist.get_backend() if distributed else "none",
+                                                                                      args.batch)},
+            "bytes_moved_per_step": int(moved),
+            "link_GBps": round(moved / (elapsed / args.steps) / 1e9, 2)}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -153,6 +324,17 @@ def main():
     dgm = importlib.import_module("elasticdeform_amd.deform_grid")
     from elasticdeform_amd import _lib
 
+    if args.workload == "cfg4":
+        if rank == 0:
+            cfg4_main(args)
+        if distributed:
+            dist.destroy_process_group()
+        return
+    if args.collective:
+        collective_main(args, rank, world, dev, distributed)
+        if distributed:
+            dist.destroy_process_group()
+        return
     cfg5 = args.workload == "cfg5"
     n = args.side or (128 if cfg5 else N_SIDE)
     B = args.batch if cfg5 else 1
@@ -359,6 +541,30 @@ def main():
                   "unit": "Mvoxels/s", "vs_headline_ms": round(ms10 / (elapsed / args.steps * 1e3), 3),
                   "deform_grid_ms": round(f10, 4), "deform_grid_gradient_ms": round(g10, 4)}
 
+    fresh = None
+    if rank == 0 and world == 1 and not cfg5 and not args.no_stress:
+        # the step as an augmentation loop runs it: a new displacement tensor every step
+        fresh = {}
+        for sg in (5.0, 10.0):
+            ns = max(10, args.steps)
+            rng = np.random.default_rng(2200 + int(sg))
+            grids = [torch.from_numpy(rng.standard_normal((3, 5, 5, 5)) * (sg * n / 256)).to(dev) for _ in range(ns + 3)]
+            for g in grids[:3]:
+                fwd(X, g, **kw)
+                bwd(dY, g, **kw)
+            torch.cuda.synchronize()
+            t0f = time.perf_counter()
+            for g in grids[3:]:
+                fwd(X, g, **kw)
+                bwd(dY, g, **kw)
+            torch.cuda.synchronize()
+            msf = (time.perf_counter() - t0f) / ns * 1e3
+            fresh["sigma_%g" % sg] = {"steps": ns, "ms_per_step": round(msf, 4), "value": round(vox / (msf * 1e-3) / 1e6, 2),
+                                      "unit": "Mvoxels/s"}
+        fresh["workload"] = ("cfg2 with a NEW 5x5x5 displacement tensor every step (deform_grid + deform_grid_gradient on "
+                             "the same new tensor), sigma 5 and sigma 10")
+        fresh["vs_headline_ms"] = round(fresh["sigma_5"]["ms_per_step"] / ms_per_step, 3)
+
     if rank == 0:
         if cfg5:
             workload = ("cfg5 shard: %d volumes of %d^3 float32 per GPU, one 5x5x5 grid (sigma %.3g) each, "
@@ -396,6 +602,8 @@ def main():
         }
         if stress is not None:
             res["stress"] = stress
+        if fresh is not None:
+            res["fresh_grid"] = fresh
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

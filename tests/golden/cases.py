@@ -265,6 +265,17 @@ def big_cases():
             cases.append(dict(name="cfg2_%s_s%g" % (tag, sigma), make=make, grad=False,
                               pick=None, big=True))
 
+    # the benchmark's own geometry, forward AND gradient at 256^3 (the headline kernel's
+    # gradient had no element-wise reference at its size): outputs / gradients stored on a sub-grid
+    for sigma in (5.0, 10.0):
+        def make2(sigma=sigma):
+            return cfg2_inputs(sigma)
+        # (cpu_oracle: tests/test_oracle.py restates one of the two at full size -- 80 s of CPU each)
+        cases.append(dict(name="cfg2_grad_s%g" % sigma, make=make2, grad=True, big=True, cpu_oracle=sigma == 5.0,
+                          dY=lambda: np.random.default_rng(10).random((256, 256, 256), dtype=np.float32),
+                          pick=lambda: ((slice(3, None, 8), slice(5, None, 8), slice(None, None, 4)),),
+                          gpick=lambda: ((slice(1, None, 8), slice(6, None, 8), slice(2, None, 4)),)))
+
     def make3():
         X, disp, kw, _ = cfg3_inputs()
         return X, disp, kw

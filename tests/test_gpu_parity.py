@@ -171,6 +171,13 @@ def test_baseline_configs_vs_golden(case, golden):
     if case["grad"]:
         dY = C.seeded_dY(case, out)
         grad = ed.deform_grid_gradient(dY, disp, X_shape=C.x_shapes(X), **kw)
+        if case["name"].startswith("cfg2_grad"):
+            # the headline geometry (256^3, order 3, mirror): the gradient against the reference's own,
+            # flat 1e-5 of the gradient's scale (BASELINE.json north_star) -- no fp64 oracle pass at this size
+            for g, w in zip(_pick(case, _aslist(grad), grad=True), golden.outputs(case, "grad")):
+                assert g.dtype == w.dtype == np.float32 and g.shape == w.shape
+                np.testing.assert_allclose(g, w, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(w).max())))
+            return
         truth = _grad_truth(dY, disp, X, kw, case)      # a few seconds of CPU at 128^3
         for g, w, t in zip(_pick(case, _aslist(grad), grad=True), golden.outputs(case, "grad"), truth):
             if w.dtype == np.float32:
