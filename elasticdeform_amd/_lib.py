@@ -46,7 +46,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libedhip.so
 # every symbol include/edhip.h declares
 EXPORTS = ('edhip_version', 'edhip_status_string', 'edhip_device_count', 'edhip_deform',
            'edhip_deform_batch', 'edhip_deform_batch_strided', 'edhip_source_box', 'edhip_spline_filter1d',
-           'edhip_spline_filter_axes', 'edhip_release_scratch', 'edhip_profile_dominant',
+           'edhip_spline_filter_axes', 'edhip_source_window', 'edhip_spline_filter_axes_window',
+           'edhip_release_scratch', 'edhip_profile_dominant',
            'edhip_profile_last_us')
 
 
@@ -123,6 +124,18 @@ def load():
             ctypes.POINTER(EdhipArray), ctypes.POINTER(EdhipArray), ctypes.c_int,
             ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
             ctypes.c_char_p, ctypes.c_size_t]
+        L.edhip_source_window.restype = ctypes.c_int
+        L.edhip_source_window.argtypes = [
+            ctypes.POINTER(EdhipArray), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+            ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_char_p, ctypes.c_size_t]
+        L.edhip_spline_filter_axes_window.restype = ctypes.c_int
+        L.edhip_spline_filter_axes_window.argtypes = [
+            ctypes.POINTER(EdhipArray), ctypes.POINTER(EdhipArray), ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+            ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         _lib = L
     return _lib
 
@@ -270,6 +283,47 @@ def source_box(disp_desc, in_len, out_len, output_offset, inverse_affine, flags,
                                 ctypes.c_void_p(stream), box.ctypes.data_as(p64), buf, 256)
     raise_for_status(status, buf)
     return box
+
+
+def source_window(disp_desc, in_len, out_len, output_offset, inverse_affine, shape, axis, order, mode,
+                  margin, align, minlen, flags, stream, window_ptr):
+    """edhip_source_window: the filter window of one input, written to DEVICE memory at `window_ptr`
+    (2 * len(shape) int32).  No synchronisation.  Returns the status (0, or EDHIP_ERR_UNSUPPORTED)."""
+    L = load()
+    in_len = numpy.ascontiguousarray(in_len, dtype=numpy.int64)
+    out_len = numpy.ascontiguousarray(out_len, dtype=numpy.int64)
+    shape = numpy.ascontiguousarray(shape, dtype=numpy.int64)
+    naxis = len(in_len)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    off = aff = None
+    if output_offset is not None:
+        off_arr = numpy.ascontiguousarray(output_offset, dtype=numpy.int64)
+        off = off_arr.ctypes.data_as(p64)
+    if inverse_affine is not None:
+        aff_arr = numpy.ascontiguousarray(inverse_affine, dtype=numpy.float64)
+        aff = aff_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    buf = _buf()
+    status = L.edhip_source_window(ctypes.byref(disp_desc), in_len.ctypes.data_as(p64),
+                                   out_len.ctypes.data_as(p64), off, naxis, aff, len(shape),
+                                   shape.ctypes.data_as(p64), (ctypes.c_int32 * naxis)(*[int(a) for a in axis]),
+                                   int(order), int(mode), int(margin), int(align), int(minlen), int(flags),
+                                   ctypes.c_void_p(stream), ctypes.c_void_p(window_ptr), buf, 256)
+    if status and status != ERR_UNSUPPORTED:
+        raise_for_status(status, buf)
+    return status
+
+
+def spline_filter_axes_window(in_desc, out_desc, axes, order, transpose, window_ptr, flags, stream):
+    """edhip_spline_filter_axes_window; returns the status (0, or EDHIP_ERR_UNSUPPORTED with nothing launched)"""
+    L = load()
+    n = len(axes)
+    buf = _buf()
+    status = L.edhip_spline_filter_axes_window(ctypes.byref(in_desc), ctypes.byref(out_desc), n,
+                                               (ctypes.c_int32 * n)(*axes), int(order), int(bool(transpose)),
+                                               ctypes.c_void_p(window_ptr), int(flags), stream, buf, 256)
+    if status and status != ERR_UNSUPPORTED:
+        raise_for_status(status, buf)
+    return status
 
 
 def spline_filter1d(in_desc, out_desc, axis, order, transpose, flags, stream):

@@ -458,8 +458,9 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
 // the exact box (a few samples wider for the grids elastic deformation uses).
 constexpr int kHullCap = 4096;          // doubles per refinement buffer
 
-__global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, int* box)
+__global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, int* box, const SourceWindow sw)
 {
+    // one workgroup per component (= per source axis): 52 us for the three of a 3-D grid in one workgroup
     __shared__ double smin[kMaxAxes][4], smax[kMaxAxes][4];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int naxis = g.naxis;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
         if (ok && t <= (double)kHullCap)
             levels = L;
     }
-    for (int h = 0; h < naxis; ++h) {
+    for (int h = blockIdx.x; h < naxis; h += gridDim.x) {
         double mn = 1e300, mx = -1e300;
         if (levels >= 0) {
             int n[4] = {1, 1, 1, 1};
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
         }
     }
     __syncthreads();
-    if (tid < naxis) {
+    if (tid < naxis && (tid % (int)gridDim.x) == (int)blockIdx.x) {
         const int h = tid;
         double mn = smin[h][0], mx = smax[h][0];
         for (int w = 1; w < 4; ++w) {
@@ -631,17 +632,69 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
         double lo = blo + (double)g.off[h] + mn, hi = bhi + (double)g.off[h] + mx;
         lo = !(lo == lo) ? -1e9 : (lo < -1e9 ? -1e9 : (lo > 1e9 ? 1e9 : lo));
         hi = !(hi == hi) ? 1e9 : (hi < -1e9 ? -1e9 : (hi > 1e9 ? 1e9 : hi));
-        box[2 * h] = (int)floor(lo) - 1;        // (one sample for the rounding of the sums above)
-        box[2 * h + 1] = (int)ceil(hi) + 1;
+        const int blo_i = (int)floor(lo) - 1;   // (one sample for the rounding of the sums above)
+        const int bhi_i = (int)ceil(hi) + 1;
+        box[2 * h] = blo_i;
+        box[2 * h + 1] = bhi_i;
+        if (sw.out) {
+            // The filter window of this source axis, left on the device (edhip_source_window): the tap window
+            // of deform.c:783-813 around the coordinate range, the boundary map's say where the range leaves
+            // the array ('nearest' / 'constant' clip it, the folding modes take the whole axis), the filter's
+            // decay margin, rows of the last axis on vector boundaries, at least `minlen` samples.
+            const int n = sw.shape[sw.axis[h]];
+            int wl = blo_i - sw.order / 2 - 1, wh = bhi_i + sw.order - sw.order / 2 + 1;      // inclusive
+            if (wl < 0 || wh > n - 1) {
+                if (sw.mode == EDHIP_MODE_NEAREST || sw.mode == EDHIP_MODE_CONSTANT) {
+                    const bool cl = wl < 0, ch = wh > n - 1;
+                    wl = wl < 0 ? 0 : (wl > n - 1 ? n - 1 : wl);
+                    wh = wh > n - 1 ? n - 1 : (wh < 0 ? 0 : wh);
+                    // windows that stick out are mirror-indexed (deform.c:795-813): up to `order` samples inward
+                    if (cl)
+                        wh = wh > (sw.order < n - 1 ? sw.order : n - 1) ? wh : (sw.order < n - 1 ? sw.order : n - 1);
+                    if (ch)
+                        wl = wl < (n - 1 - sw.order > 0 ? n - 1 - sw.order : 0) ? wl : (n - 1 - sw.order > 0 ? n - 1 - sw.order : 0);
+                } else {
+                    wl = 0;
+                    wh = n - 1;
+                }
+            }
+            int w0 = wl - sw.margin, w1 = wh + 1 + sw.margin;
+            w0 = w0 < 0 ? 0 : w0;
+            w1 = w1 > n ? n : w1;
+            if (w1 - w0 < sw.minlen) {
+                w0 = w0 < n - sw.minlen ? w0 : n - sw.minlen;
+                w0 = w0 < 0 ? 0 : w0;
+                w1 = w0 + sw.minlen < n ? w0 + sw.minlen : n;
+            }
+            if (sw.axis[h] == sw.ndim - 1 && sw.align > 1) {
+                w0 -= w0 % sw.align;
+                w1 = (w1 + sw.align - 1) / sw.align * sw.align;
+                w1 = w1 > n ? n : w1;
+            }
+            sw.out[2 * sw.axis[h]] = w0;
+            sw.out[2 * sw.axis[h] + 1] = w1;
+        }
+    }
+    if (sw.out && blockIdx.x == 0 && tid < sw.ndim) {
+        bool deformed = false;
+        for (int k = 0; k < naxis; ++k)
+            deformed = deformed || sw.axis[k] == tid;
+        if (!deformed) {
+            sw.out[2 * tid] = 0;
+            sw.out[2 * tid + 1] = sw.shape[tid];
+        }
     }
 }
 
-hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream, bool conservative)
+hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream, bool conservative, const SourceWindow* sw)
 {
-    if (conservative && g.nvox > 0) {
-        hipLaunchKernelGGL(source_box_hull_kernel, dim3(1), dim3(256), 0, stream, g, box);
+    if ((conservative || sw) && g.nvox > 0) {
+        const SourceWindow none{};
+        hipLaunchKernelGGL(source_box_hull_kernel, dim3((unsigned)g.naxis), dim3(256), 0, stream, g, box, sw ? *sw : none);
         return hipGetLastError();
     }
+    if (sw)
+        return hipErrorNotSupported;
     hipLaunchKernelGGL(source_box_init_kernel, dim3(1), dim3(64), 0, stream, box, g.naxis);
     if (g.nvox <= 0)
         return hipGetLastError();

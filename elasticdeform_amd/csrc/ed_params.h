@@ -55,7 +55,18 @@ hipError_t launch_deform_exact_list(const GridGeom& g, const IOView& v, const in
 // edhip_source_box: box[2h] = floor(min), box[2h+1] = ceil(max) of the raw (unmapped) source
 // coordinate along axis h over every output voxel; `box` = 2 * naxis device ints
 // conservative: the convex hull of the control coefficients (a superset of the exact box, O(grid points))
-hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream, bool conservative = false);
+// sw (conservative only): also leave the FILTER window of one input on the device -- 2 * ndim ints (w0, w1) in
+// the input's dimension order: the box widened by the tap window, the boundary mode's clipping, the filter's
+// decay margin; last-axis rows on `align`-element boundaries; at least `minlen` samples along a deformed axis
+struct SourceWindow {
+    int32_t* out;                 // device, 2 * ndim ints (nullptr: none)
+    int ndim;
+    int shape[EDHIP_MAX_DIMS];
+    int axis[kMaxAxes];           // array dimension of deformed axis h
+    int order, mode, margin, align, minlen;
+};
+hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream, bool conservative = false,
+                             const SourceWindow* sw = nullptr);
 
 // fast path: returns hipErrorNotSupported (without launching) when the case is outside its
 // envelope so that the caller can route it to the exact kernels instead.
@@ -135,8 +146,11 @@ constexpr size_t kWorkspaceGridBytes = 64 * 1024;
 
 // fast path (orders 2/3, float32/float64, lines >= 64 samples, no scratch); hipErrorNotSupported
 // (nothing launched) when the case is outside its envelope
+// window: 2 ints (w0, w1) per array dimension in DEVICE memory (edhip_source_window) -- only the samples inside
+// are read and written; hipErrorNotSupported (nothing launched) when the whole-line tile kernels cannot take it
 hipError_t launch_spline_filter_fast(const FilterParams& p, int order, int ndim, int axis,
                                      const int64_t* shape, const int64_t* in_stride_bytes,
-                                     const int64_t* out_stride_bytes, hipStream_t stream);
+                                     const int64_t* out_stride_bytes, hipStream_t stream,
+                                     const int* window = nullptr, bool dry = false);
 
 }  // namespace ed

@@ -586,8 +586,11 @@ int edhip_source_box(const edhip_array* displacement, const int64_t* in_len, con
     return EDHIP_OK;
 }
 
-int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, int axis, int order,
-                          int transpose, uint32_t flags, void* hip_stream, char* err, size_t errlen)
+// one filter pass; window: device-side window (only the whole-line tile kernels take one: EDHIP_ERR_UNSUPPORTED
+// otherwise, nothing launched); dry: the checks of a windowed pass without its launch
+static int filter1d_impl(const edhip_array* input, const edhip_array* output, int axis, int order,
+                         int transpose, uint32_t flags, void* hip_stream, const int32_t* window, bool dry,
+                         char* err, size_t errlen)
 {
     using namespace ed;
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -681,13 +684,15 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
     if (want_fast && p.npoles >= 1) {
         const hipError_t e = launch_spline_filter_fast(p, order, input->ndim, axis, input->shape,
                                                        input->stride_bytes, output->stride_bytes,
-                                                       stream);
+                                                       stream, window, dry);
         if (e == hipSuccess)
             return EDHIP_OK;
         if (e != hipErrorNotSupported)
             return hip_fail(err, errlen, e, "spline filter launch");
         (void)hipGetLastError();
     }
+    if (window || dry)
+        return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "windowed prefilter: outside the whole-line tile kernels");
 
     const bool need_ws = p.npoles > 0 && p.len >= 2;
     if (need_ws) {
@@ -715,6 +720,98 @@ int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, i
         if (e != hipSuccess)
             return hip_fail(err, errlen, e, "spline filter launch");
     }
+    return EDHIP_OK;
+}
+
+int edhip_spline_filter1d(const edhip_array* input, const edhip_array* output, int axis, int order,
+                          int transpose, uint32_t flags, void* hip_stream, char* err, size_t errlen)
+{
+    return filter1d_impl(input, output, axis, order, transpose, flags, hip_stream, nullptr, false, err, errlen);
+}
+
+int edhip_spline_filter_axes_window(const edhip_array* input, const edhip_array* output, int naxes,
+                                    const int32_t* axes, int order, int transpose, const int32_t* window,
+                                    uint32_t flags, void* hip_stream, char* err, size_t errlen)
+{
+    if (err && errlen)
+        err[0] = 0;
+    if (naxes < 0 || (naxes > 0 && !axes) || !window)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis list / window");
+    ed::StreamGuard guard((hipStream_t)hip_stream);
+    // every pass must be one the tile kernels take, BEFORE the first one is launched
+    for (int i = 0; i < naxes; ++i) {
+        const int st = filter1d_impl(i == 0 ? input : output, output, axes[i], order, transpose, flags, hip_stream,
+                                     window, true, err, errlen);
+        if (st != EDHIP_OK)
+            return st;
+    }
+    for (int i = 0; i < naxes; ++i) {
+        const int st = filter1d_impl(i == 0 ? input : output, output, axes[i], order, transpose, flags, hip_stream,
+                                     window, false, err, errlen);
+        if (st != EDHIP_OK)
+            return st;
+    }
+    return EDHIP_OK;
+}
+
+int edhip_source_window(const edhip_array* displacement, const int64_t* in_len, const int64_t* out_len,
+                        const int64_t* output_offset, int naxis, const double* affine, int ndim,
+                        const int64_t* shape, const int32_t* axis, int order, int mode, int margin, int align,
+                        int minlen, uint32_t flags, void* hip_stream, int32_t* window, char* err, size_t errlen)
+{
+    using namespace ed;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    StreamGuard guard(stream);
+    if (err && errlen)
+        err[0] = 0;
+    if (!in_len || !out_len || !window || !shape || !axis || naxis < 1 || ndim < naxis || ndim > EDHIP_MAX_DIMS)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis list");
+    if (naxis > 4)
+        return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "edhip_source_window: up to 4 deformed axes");
+    if (!displacement || displacement->ndim != naxis + 1 || displacement->shape[0] != naxis)
+        return fail(err, errlen, EDHIP_ERR_INVALID, "invalid displacement shape");
+    if (!dtype_ok(displacement->dtype))
+        return fail(err, errlen, EDHIP_ERR_DTYPE, "data type not supported");
+    int64_t points = naxis;
+    for (int k = 0; k <= naxis; ++k) {
+        if (displacement->shape[k] <= 0)
+            return fail(err, errlen, EDHIP_ERR_INVALID, "invalid displacement shape");
+        if (k > 0)
+            points *= displacement->shape[k];
+    }
+    if (points > 7680)
+        return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "edhip_source_window: control grids are limited to 7680 values");
+    SourceWindow sw{};
+    sw.out = window;
+    sw.ndim = ndim;
+    for (int d = 0; d < ndim; ++d) {
+        if (shape[d] <= 0 || shape[d] > 0x3fffffff)
+            return fail(err, errlen, EDHIP_ERR_INVALID, "invalid shape");
+        sw.shape[d] = (int)shape[d];
+    }
+    for (int k = 0; k < naxis; ++k) {
+        if (axis[k] < 0 || axis[k] >= ndim || shape[axis[k]] != in_len[k])
+            return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis list");
+        sw.axis[k] = axis[k];
+    }
+    sw.order = order;
+    sw.mode = mode;
+    sw.margin = margin < 0 ? 0 : margin;
+    sw.align = align < 1 ? 1 : align;
+    sw.minlen = minlen < 1 ? 1 : minlen;
+    GridGeom g;
+    const int st = make_geometry(displacement, in_len, out_len, output_offset, naxis, affine, flags,
+                                 stream, g, err, errlen);
+    if (st != EDHIP_OK)
+        return st;
+    hipError_t e = hipSuccess;
+    char* ws = (char*)workspace_reserve(stream, deform_tile_workspace_bytes(g), &e);
+    if (!ws)
+        return hip_fail(err, errlen, e, "scratch allocation");
+    int* dbox = (int*)(ws + kWorkspaceGridBytes - 64);
+    e = launch_source_box(g, dbox, stream, true, &sw);
+    if (e != hipSuccess)
+        return hip_fail(err, errlen, e, "source window launch");
     return EDHIP_OK;
 }
 

@@ -61,6 +61,12 @@ struct FastFilter {
     int nseg;                // segments per line
     int transpose;
     double z, h0;
+    // device-side window (crop-aware prefilter): 2 ints (w0, w1) per array dimension, or nullptr; the array
+    // dimension of the filtered axis and of every outer entry
+    const int* win;
+    int win_axis;
+    int win_outer[EDHIP_MAX_DIMS];
+    int dry;                 // 1: every check, no launch (can the whole-line tile kernels take this pass?)
 };
 
 __device__ __forceinline__ void line_offsets(const FastFilter& p, int64_t line, int64_t& in_off,
@@ -260,7 +266,48 @@ struct LineTile {
     int transpose;
     unsigned long long* trace;   // profiling only (EDHIP_FILTER_TRACE): phase timestamps of workgroup 0
     double z, h0;
+    // device-side window (edhip_spline_filter_axes_window): (w0, w1) per array dimension in device memory; the
+    // array dimension of the filtered axis, of the column axis (strided) and of every outer entry.  The host
+    // sizes tile and grid for the whole array; the kernel shrinks its geometry to the window when it starts.
+    const int* win;
+    int win_axis, win_col;
+    int win_outer[EDHIP_MAX_DIMS];
 };
+
+// the tile kernels' geometry restricted to the window the source-box kernel left on the device: lines outside
+// it are not touched, lines inside are filtered as lines of the window's length (its ends are the filter's
+// boundaries; the decay margin around the box makes that invisible inside the box)
+template <typename T, int C>
+__device__ __forceinline__ void apply_window(LineTile& p)
+{
+    if (!p.win)
+        return;
+    const int a0 = p.win[2 * p.win_axis], a1 = p.win[2 * p.win_axis + 1];
+    int64_t in_off = (int64_t)a0 * p.in_axis_stride, out_off = (int64_t)a0 * p.out_axis_stride;
+    p.n = a1 - a0;
+    p.nb = (p.n + kB - 1) / kB;
+    int64_t groups = 1;
+    for (int d = 0; d < p.nouter; ++d) {
+        const int o0 = p.win[2 * p.win_outer[d]], o1 = p.win[2 * p.win_outer[d] + 1];
+        in_off += (int64_t)o0 * p.in_outer_stride[d];
+        out_off += (int64_t)o0 * p.out_outer_stride[d];
+        p.outer_len[d] = o1 - o0;
+        groups *= o1 - o0;
+    }
+    if (C > 0) {      // strided: the column axis has unit stride
+        const int c0 = p.win[2 * p.win_col], c1 = p.win[2 * p.win_col + 1];
+        in_off += c0;
+        out_off += c0;
+        p.ncol = c1 - c0;
+        p.col_tiles = (p.ncol + C - 1) / C;
+        p.ntiles = groups * p.col_tiles;
+    } else {
+        p.nlines = groups;
+        p.ntiles = (groups + p.rows - 1) / p.rows;
+    }
+    p.in += in_off * (int64_t)sizeof(T);
+    p.out += out_off * (int64_t)sizeof(T);
+}
 
 // (32-bit decomposition: a 64-bit integer division costs ~1 us on this machine, and the persistent
 // kernels do one or two per tile; the host only takes this path for fewer than 2^31 lines)
@@ -377,8 +424,10 @@ __device__ __forceinline__ void lds_barrier()
 // Persistent workgroups; with VEC the next tile's rows are already in flight (in registers) while
 // the current tile is filtered and stored.
 template <typename T, int C, bool VEC>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_strided_kernel(const LineTile p)
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_strided_kernel(const LineTile pk)
 {
+    LineTile p = pk;
+    apply_window<T, C>(p);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* tile = reinterpret_cast<T*>(smem) + kK * C;     // [kK | n32 | kK][C]: sample j at row j
     typedef typename VecOf<T>::type V;
@@ -527,8 +576,10 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
 
 // ---- contiguous axis -------------------------------------------------------------------------------
 template <typename T, bool VEC>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_contig_kernel(const LineTile p)
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_contig_kernel(const LineTile pk)
 {
+    LineTile p = pk;
+    apply_window<T, 0>(p);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename VecOf<T>::type V;
     typedef typename std::conditional<VEC, V, T>::type W;
@@ -805,6 +856,8 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
     p.transpose = f.transpose;
     p.z = f.z;
     p.h0 = f.h0;
+    p.win = f.win;
+    p.win_axis = f.win_axis;
     // persistent grid: two workgroups per CU for float32 (LDS and registers are budgeted for exactly
     // that), one for float64 (its fp64 state does not fit 256 registers next to the prefetch)
     int dev = 0, ncu = 256;
@@ -838,12 +891,15 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
             p.outer_len[d] = f.outer_len[d];
             p.in_outer_stride[d] = f.in_outer_stride[d];
             p.out_outer_stride[d] = f.out_outer_stride[d];
+            p.win_outer[d] = f.win_outer[d];
         }
         const size_t lds = 1024 + (size_t)R * p.pitch * sizeof(T);
         p.ntiles = (f.nlines + R - 1) / R;
         const int64_t nblk = p.ntiles < resident ? p.ntiles : resident;
         if (lds > kTileLdsBudget)
             return hipErrorNotSupported;
+        if (f.dry)
+            return hipSuccess;
         if (vec) {
             const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, true>, kTileLdsBudget);
             if (attr != hipSuccess)
@@ -893,10 +949,12 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
         return hipErrorNotSupported;
     p.ncol = (int)f.outer_len[cax];
     p.col_tiles = (p.ncol + C - 1) / C;
+    p.win_col = f.win_outer[cax];
     int64_t groups = 1;
     for (int d = 0; d < f.nouter; ++d) {
         if (d == cax)
             continue;
+        p.win_outer[p.nouter] = f.win_outer[d];
         p.outer_len[p.nouter] = f.outer_len[d];
         p.in_outer_stride[p.nouter] = f.in_outer_stride[d];
         p.out_outer_stride[p.nouter] = f.out_outer_stride[d];
@@ -908,6 +966,8 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
     const bool vec = aligned16 && p.ncol % VN == 0 && strides_vec(cax) &&
                      f.in_axis_stride % VN == 0 && f.out_axis_stride % VN == 0;
     const size_t lds = tile_rows * C * sizeof(T);
+    if (f.dry)
+        return hipSuccess;
 #define EDHIP_TILE_STRIDED(CC, VV)                                                                   \
     do {                                                                                             \
         const hipError_t attr =                                                                      \
@@ -937,9 +997,12 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
 // host entry: returns hipErrorNotSupported when the case is outside the fast envelope
 hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim, int axis,
                                      const int64_t* shape, const int64_t* in_stride_bytes,
-                                     const int64_t* out_stride_bytes, hipStream_t stream)
+                                     const int64_t* out_stride_bytes, hipStream_t stream, const int* window, bool dry)
 {
     if (order < 2 || order > 5)
+        return hipErrorNotSupported;
+    // a device-side window is served by the whole-line tile kernels only (one pole: orders 2 / 3)
+    if (window && (order >= 4 || ed_env("EDHIP_NO_LINE_TILES")))
         return hipErrorNotSupported;
     if (fp.in_dtype != fp.out_dtype || (fp.in_dtype != EDHIP_F32 && fp.in_dtype != EDHIP_F64))
         return hipErrorNotSupported;
@@ -1014,9 +1077,13 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
         p.outer_len[p.nouter] = shape[d];
         p.in_outer_stride[p.nouter] = in_stride_bytes[d] / esz;
         p.out_outer_stride[p.nouter] = out_stride_bytes[d] / esz;
+        p.win_outer[p.nouter] = d;
         p.nlines *= shape[d];
         p.nouter++;
     }
+    p.win = window;
+    p.win_axis = axis;
+    p.dry = dry ? 1 : 0;
     if (p.nlines <= 0)
         return hipSuccess;
     p.transpose = fp.transpose;
@@ -1043,10 +1110,12 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
     if (!ed_env("EDHIP_NO_LINE_TILES")) {
         const hipError_t e = fp.in_dtype == EDHIP_F32 ? launch_line_tiles<float>(p, stream)
                                                       : launch_line_tiles<double>(p, stream);
-        if (e != hipErrorNotSupported)
+        if (e != hipErrorNotSupported || window)
             return e;
         (void)hipGetLastError();
     }
+    if (window)
+        return hipErrorNotSupported;
     {
         // block-recompute kernels: lane <-> line (UNIT: the filtered axis itself is contiguous)
         const int64_t threads = p.nlines * p.nseg;

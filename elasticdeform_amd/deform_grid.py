@@ -258,83 +258,68 @@ def _filter_axes(x, axes, order, transpose, device, overwrite=False, stream=None
     return src
 
 
-# Crop-aware prefilter: engaged when it saves at least this many voxels per filter pass (summed
-# over the inputs).  Finding the window costs a stream synchronisation (edhip_source_box hands the
-# box to the host), which exposes ~0.25 ms of host-side launch latency: about what filtering
-# 48M float32 voxels along three axes costs on an MI355X.
-CROP_WINDOW_MIN_SAVING = 48e6
-# ... and only when the output box plus the filter margins is at most this fraction of the input: beyond it
-# the window's passes + the read-back's synchronisation cost more than they save (512^3 float32 order 3,
-# window / whole volume: crop 128^3 forward 272 / 722 us, crop 256^3 735 / 885 us, crop 320^3 1161 / 1061 us;
-# profiles/r03_bench_misc.txt)
-CROP_WINDOW_MAX_FRACTION = 0.30
+# Crop-aware prefilter: with a crop only a box of each input is ever read, so only that
+# box plus the filter's decay margin is filtered.  The window never leaves the device: edhip_source_window
+# computes it from the control grid (one small launch, no read-back), the filter passes and the transposed
+# passes of the gradient restrict themselves to it (edhip_spline_filter_axes_window), K1 / K2 work on full-size
+# buffers whose samples outside the window are never touched.  The host only decides WHETHER to try, from what
+# it knows without the device: the output box plus the margins, as a fraction of the input.
+# (Until round 4 the box was read back to the host: the synchronisation exposed the launch latency of every
+# kernel behind it, and BASELINE cfg4 -- 3 x 256^3 cropped to 64^3 -- never got a window.)
+CROP_WINDOW_MIN_SAVING = 4e6         # voxels per filter pass, summed over the inputs (below: not worth a launch)
+CROP_WINDOW_MAX_FRACTION = 0.50      # (output box + margins) / input, upper bound known to the host
+# decay margin (samples) after which a cut in a line is invisible in the data's own precision: |pole|^m below
+# 1e-9 for float32 volumes (their filter runs in float32), below 1e-18 for float64
+_WINDOW_MARGIN = {'float32': {2: 12, 3: 16}, 'float64': {2: 24, 3: 32}}
+_WINDOW_MIN_LINE = 64                # the whole-line tile kernels' shortest line
 
 
-def _crop_windows(plan, shapes, dtypes, disp_desc, dflag, crop, prefilter, device):
-    """Crop-aware prefilter: per input, the window (start, stop) along
-    every deformed axis that has to be filtered, or None for 'the whole array'.  Only for floating
-    point volumes outside 'exact' arithmetic: the window's coefficients equal the whole-volume
-    ones to below fp64 rounding, not bit for bit."""
-    n = len(shapes)
+def _crop_windows(plan, xs, disp_desc, dflag, crop, prefilter, device, stream):
+    """Per input: a device tensor holding its filter window (2 ints per dimension, edhip_source_window), or
+    None for 'filter the whole array'.  Floating-point volumes of orders 2 / 3 outside 'exact' arithmetic: the
+    window's coefficients equal the whole-volume ones to below the data's rounding, not bit for bit."""
+    n = len(xs)
     wins = [None] * n
     if crop is None or not prefilter or (_flags & _lib.FLAG_EXACT):
         return wins
-    todo = [i for i in range(n) if plan.order[i] > 1 and dtypes[i] in ('float32', 'float64')]
+    todo = [i for i in range(n) if int(plan.order[i]) in _WINDOW_MARGIN.get(_dtype_name(xs[i]), {})]
     if not todo:
         return wins
     if disp_desc.ndim < 2 or disp_desc.ndim > 5 or numpy.prod(list(disp_desc.shape)[:disp_desc.ndim]) > 7680:
-        return wins                 # edhip_source_box: control grid in LDS, up to 4 deformed axes
+        return wins                 # (control grid in LDS, up to 4 deformed axes)
     ax0 = plan.axis[0]
-    in_len = [int(shapes[0][a]) for a in ax0]
+    in_len = [int(xs[0].shape[a]) for a in ax0]
     out_len = [int(plan.output_shapes[0][a]) for a in ax0]
 
     def volume(i, lens):            # voxels of input i when its deformed axes have extents `lens`
-        v = float(numpy.prod([int(d) for d in shapes[i]], dtype=numpy.float64))
+        v = float(numpy.prod([int(d) for d in xs[i].shape], dtype=numpy.float64))
         for a, l in zip(plan.axis[i], lens):
-            v *= float(l) / float(shapes[i][a])
+            v *= float(l) / float(xs[i].shape[a])
         return v
-    # upper bound of the saving: no window is smaller than the output box plus the filter margins
-    def at_least(i):
-        m = _host.PREFILTER_MARGIN.get(int(plan.order[i]), 64)
-        return [min(n_in, n_out + 2 * m) for n_in, n_out in zip(in_len, out_len)]
-    if sum(volume(i, in_len) - volume(i, at_least(i)) for i in todo) < CROP_WINDOW_MIN_SAVING:
+
+    def at_least(i):                # no window is smaller than the output box plus margins and taps
+        m = _WINDOW_MARGIN[_dtype_name(xs[i])][int(plan.order[i])]
+        return [min(n_in, max(n_out + 2 * m + int(plan.order[i]) + 3, _WINDOW_MIN_LINE))
+                for n_in, n_out in zip(in_len, out_len)]
+    full = sum(volume(i, in_len) for i in todo)
+    least = sum(volume(i, at_least(i)) for i in todo)
+    if full - least < CROP_WINDOW_MIN_SAVING or least > CROP_WINDOW_MAX_FRACTION * full:
         return wins
-    if sum(volume(i, at_least(i)) for i in todo) > CROP_WINDOW_MAX_FRACTION * sum(volume(i, in_len) for i in todo):
-        return wins
-    # (the box of the control coefficients' convex hull after two levels of subdivision: microseconds on the
-    # device and within ~20 % of the exact range, where the exact scan of every output voxel took 0.9 ms for a
-    # 256^3 output -- more than the window saved)
-    cbox = _lib.source_box(disp_desc, in_len, out_len, plan.output_offset, plan.inverse_affine,
-                           _flags | dflag | _lib.FLAG_FAST, _stream(device))
-    saving = 0.0
+    torch = _torch()
     for i in todo:
-        box = _host.source_box(plan, i, shapes[i], cbox)
-        # the float32 tile kernel stages whole padded rows (up to 49 samples past a window start)
-        wins[i] = _host.prefilter_window(box, shapes[i], plan.axis[i], plan.order[i], slack_last=52)
-        if wins[i] is not None:
-            saving += volume(i, in_len) - volume(i, [w1 - w0 for w0, w1 in wins[i]])
-    if saving < CROP_WINDOW_MIN_SAVING:
-        return [None] * n
+        x = xs[i]
+        if not x.is_contiguous() or any(int(x.shape[a]) < _WINDOW_MIN_LINE for a in plan.axis[i]):
+            continue
+        name = _dtype_name(x)
+        vn = 4 if name == 'float32' else 2
+        win = torch.empty(2 * x.dim(), dtype=torch.int32, device=device)
+        st = _lib.source_window(disp_desc, in_len, out_len, plan.output_offset, plan.inverse_affine,
+                                tuple(int(v) for v in x.shape), plan.axis[i], int(plan.order[i]), int(plan.mode[i]),
+                                _WINDOW_MARGIN[name][int(plan.order[i])], vn if int(x.shape[-1]) % vn == 0 else 1,
+                                _WINDOW_MIN_LINE, _flags | dflag | _lib.FLAG_FAST, stream, win.data_ptr())
+        if st == 0:
+            wins[i] = win
     return wins
-
-
-def _window_view(x, axes, win):
-    sl = [slice(None)] * x.dim()
-    for a, (w0, w1) in zip(axes, win):
-        sl[a] = slice(w0, w1)
-    return x[tuple(sl)]
-
-
-def _windowed_desc(sub, full_shape, axes, win):
-    """Descriptor of the full-size array whose samples inside the window live in `sub` (a tensor
-    of the window's shape): same strides, base pointer moved back by the window's start.  The
-    kernels only ever touch samples inside the window (source_box is conservative)."""
-    es = sub.element_size()
-    ptr = sub.data_ptr()
-    for a, (w0, _) in zip(axes, win):
-        ptr -= w0 * sub.stride(a) * es
-    return _lib.describe(ptr, _dtype_name(sub), tuple(int(v) for v in full_shape),
-                         tuple(st * es for st in sub.stride()))
 
 
 def _prefilter_displacement(displacement, device):
@@ -472,20 +457,22 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
         # deformed axes (deform_grid.py:155-164): the whole array, or -- with a crop -- only the
         # window of it that the cropped output can reach
         df, dflag = _prefilter_displacement(dd, device)
-        wins = _crop_windows(plan, [tuple(x.shape) for x in Xd], [_dtype_name(x) for x in Xd],
-                             _desc(df), dflag, crop, prefilter, device)
+        wins = _crop_windows(plan, Xd, _desc(df), dflag, crop, prefilter, device, stream)
         Xf, in_descs = [], []
         for i, x in enumerate(Xd):
+            xf = None
             if not (prefilter and plan.order[i] > 1):
                 xf = x
-                in_descs.append(_desc(x))
-            elif wins[i] is None:
+            elif wins[i] is not None:
+                # a full-size buffer of which only the window is written -- and read: the kernels' taps stay
+                # inside the source box, the box inside the window
+                xf = torch.empty_like(x)
+                if _lib.spline_filter_axes_window(_desc(x), _desc(xf), list(plan.axis[i]), int(plan.order[i]), False,
+                                                  wins[i].data_ptr(), _flags, stream) != 0:
+                    xf = None           # (outside the tile kernels' envelope: nothing was launched)
+            if xf is None:
                 xf = _filter_axes(x, plan.axis[i], int(plan.order[i]), False, device, stream=stream)
-                in_descs.append(_desc(xf))
-            else:
-                xf = _filter_axes(_window_view(x, plan.axis[i], wins[i]), plan.axis[i],
-                                  int(plan.order[i]), False, device)
-                in_descs.append(_windowed_desc(xf, x.shape, plan.axis[i], wins[i]))
+            in_descs.append(_desc(xf))
             Xf.append(xf)                  # keeps the buffers alive until the launch is enqueued
 
         # every output element is written by the kernel (value or cval), so no zero fill is needed
@@ -571,19 +558,18 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         # With a crop the scatter only touched a box of dX: the transposed filter runs on that box
         # plus its decay margin and the result replaces the box (the rest stays exactly zero, where
         # the whole-volume filter would leave values below 1e-18 of the gradient's scale).
-        wins = _crop_windows(plan, [tuple(x.shape) for x in dXs], [_dtype_name(x) for x in dXs],
-                             _desc(df), dflag, crop, prefilter, device)
+        wins = _crop_windows(plan, dXs, _desc(df), dflag, crop, prefilter, device, stream)
         dXf = []
         for i, x in enumerate(dXs):
             if not (prefilter and plan.order[i] > 1):
                 dXf.append(x)
-            elif wins[i] is None:
+            elif wins[i] is not None and _lib.spline_filter_axes_window(
+                    _desc(x), _desc(x), list(plan.axis[i]), int(plan.order[i]), True, wins[i].data_ptr(), _flags,
+                    stream) == 0:
+                dXf.append(x)           # in place, inside the window; the rest of dX stays exactly zero
+            else:
                 dXf.append(_filter_axes(x, plan.axis[i], int(plan.order[i]), True, device, overwrite=True,
                                         stream=stream))
-            else:
-                view = _window_view(x, plan.axis[i], wins[i])
-                view.copy_(_filter_axes(view, plan.axis[i], int(plan.order[i]), True, device))
-                dXf.append(x)
         dXf = [_narrow(x, dy) if w is not None else x for x, dy, w in zip(dXf, dY_dev, wide)]
         res = [_from_device(x, dy) for x, dy in zip(dXf, dYs)]
         if sig is not None:

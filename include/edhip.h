@@ -316,6 +316,35 @@ int edhip_spline_filter_axes(const edhip_array* input, const edhip_array* output
                              uint32_t flags, void* hip_stream,
                              char* err, size_t errlen);
 
+/*
+ * Crop-aware prefilter with the window kept ON THE DEVICE (no read-back, no stream synchronisation).
+ * The reference prefilters every input whole before it deforms it (deform_grid.py:155-164) and runs the
+ * transposed filter over the whole gradient afterwards (:277-286); with a crop only a box of the input is
+ * ever read.  edhip_source_window computes, for ONE input of an edhip_deform call with these displacement /
+ * crop / affine arguments, the index window [w0, w1) along each of the input's deformed axes outside which no
+ * tap of the output can fall -- the range of the source coordinate (a superset: convex hull of the subdivided
+ * control coefficients), the tap window of deform.c:783-813, the boundary mode's clipping or folding
+ * (deform.c:47-128: 'nearest' / 'constant' clip, the folding modes keep the whole axis), `margin` samples of
+ * filter decay on either side -- and writes 2 * ndim int32 (w0, w1) in the input's dimension order into
+ * `window` (DEVICE memory; non-deformed dimensions get (0, shape[d])).  Rows of the last dimension start and
+ * end on multiples of `align` elements; a deformed axis keeps at least `minlen` samples.
+ * edhip_spline_filter_axes_window is edhip_spline_filter_axes restricted to that window: samples outside it
+ * are neither read nor written, lines are filtered as lines of the window's length.  Whole-line tile kernels
+ * only (float32 / float64, orders 2 / 3, lines of 64 .. 576 samples): EDHIP_ERR_UNSUPPORTED, with nothing
+ * launched, when a pass is outside that envelope -- filter the whole array then.
+ */
+int edhip_source_window(const edhip_array* displacement, const int64_t* in_len, const int64_t* out_len,
+                        const int64_t* output_offset /* naxis or NULL */, int naxis,
+                        const double* inv_affine /* naxis*(naxis+1) or NULL */,
+                        int ndim, const int64_t* shape /* ndim: the input's extents */,
+                        const int32_t* axis /* naxis: the input's deformed dimensions */, int order, int mode,
+                        int margin, int align, int minlen, uint32_t flags, void* hip_stream,
+                        int32_t* window /* device, 2 * ndim */, char* err, size_t errlen);
+int edhip_spline_filter_axes_window(const edhip_array* input, const edhip_array* output, int naxes,
+                                    const int32_t* axes, int order, int transpose,
+                                    const int32_t* window /* device, 2 * ndim */, uint32_t flags,
+                                    void* hip_stream, char* err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

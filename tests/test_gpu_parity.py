@@ -511,6 +511,36 @@ def test_crop_aware_prefilter_matches_whole_volume(mode, dtype):
         dgm.CROP_WINDOW_MAX_FRACTION = fraction
 
 
+def test_cfg4_engages_the_crop_window_by_default(monkeypatch):
+    """BASELINE cfg4 (3 x 256^3 cropped to 64^3) with the library's own thresholds: the windowed filter passes
+    run (the window never engaged on the configuration it was specified for), forward and
+    gradient, and nothing waits for the device in between (no edhip_source_box read-back)."""
+    import importlib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    from elasticdeform_amd import _lib
+    calls = {"window": 0, "box": 0}
+    real_w, real_b = _lib.spline_filter_axes_window, _lib.source_box
+
+    def spy_w(*a, **k):
+        st = real_w(*a, **k)
+        calls["window"] += st == 0
+        return st
+
+    def spy_b(*a, **k):
+        calls["box"] += 1
+        return real_b(*a, **k)
+    monkeypatch.setattr(_lib, "spline_filter_axes_window", spy_w)
+    monkeypatch.setattr(_lib, "source_box", spy_b)
+    (img, lab), disp, kw = C.cfg4_inputs()
+    Xs = [torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()]
+    dd = torch.from_numpy(disp).cuda()
+    outs = ed.deform_grid(Xs, dd, **kw)
+    assert calls["window"] == 1 and calls["box"] == 0
+    dYs = [torch.ones_like(outs[0]), torch.ones_like(outs[1])]
+    ed.deform_grid_gradient(dYs, dd, X_shape=[tuple(img.shape), tuple(lab.shape)], **kw)
+    assert calls["window"] == 2 and calls["box"] == 0
+
+
 def test_source_box_kernel_vs_oracle_coordinates():
     """edhip_source_box against a numpy evaluation of the raw source coordinates (the cubic
     B-spline displacement through SciPy's map_coordinates on the prefiltered grid)."""
