@@ -274,49 +274,93 @@ struct LineTile {
     int win_outer[EDHIP_MAX_DIMS];
 };
 
-// the tile kernels' geometry restricted to the window the source-box kernel left on the device: lines outside
-// it are not touched, lines inside are filtered as lines of the window's length (its ends are the filter's
-// boundaries; the decay margin around the box makes that invisible inside the box)
-template <typename T, int C>
-__device__ __forceinline__ void apply_window(LineTile& p)
+// The tile kernels' geometry, in registers: the host's (whole array) or -- with a device-side window -- the
+// window's: lines outside it are not touched, lines inside are filtered as lines of the window's length (its
+// ends are the filter's boundaries; the decay margin around the source box makes that invisible inside the
+// box).  Scalars read through readfirstlane and a fixed-size length array with static indices: a mutable copy
+// of LineTile went to scratch memory and made every pass 2.5x slower, window or not.
+constexpr int kWinOuter = 4;      // outer axes a windowed pass may have (arrays of up to 5 dimensions)
+struct TileGeo {
+    int n, nb, ncol, col_tiles;
+    int64_t ntiles, nlines;
+    int64_t in_off, out_off;      // elements: the window's origin
+    uint32_t olen[kWinOuter];
+};
+
+template <int C>
+__device__ __forceinline__ TileGeo tile_geometry(const LineTile& p)
 {
+    TileGeo g;
+    g.n = p.n;
+    g.nb = p.nb;
+    g.ncol = p.ncol;
+    g.col_tiles = p.col_tiles;
+    g.ntiles = p.ntiles;
+    g.nlines = p.nlines;
+    g.in_off = g.out_off = 0;
+#pragma unroll
+    for (int d = 0; d < kWinOuter; ++d)
+        g.olen[d] = d < p.nouter ? (uint32_t)p.outer_len[d] : 1u;
     if (!p.win)
-        return;
-    const int a0 = p.win[2 * p.win_axis], a1 = p.win[2 * p.win_axis + 1];
-    int64_t in_off = (int64_t)a0 * p.in_axis_stride, out_off = (int64_t)a0 * p.out_axis_stride;
-    p.n = a1 - a0;
-    p.nb = (p.n + kB - 1) / kB;
+        return g;
+    auto w = [&](int dim, int k) { return __builtin_amdgcn_readfirstlane(p.win[2 * dim + k]); };
+    const int a0 = w(p.win_axis, 0), a1 = w(p.win_axis, 1);
+    g.in_off = (int64_t)a0 * p.in_axis_stride;
+    g.out_off = (int64_t)a0 * p.out_axis_stride;
+    g.n = a1 - a0;
+    g.nb = (g.n + kB - 1) / kB;
     int64_t groups = 1;
-    for (int d = 0; d < p.nouter; ++d) {
-        const int o0 = p.win[2 * p.win_outer[d]], o1 = p.win[2 * p.win_outer[d] + 1];
-        in_off += (int64_t)o0 * p.in_outer_stride[d];
-        out_off += (int64_t)o0 * p.out_outer_stride[d];
-        p.outer_len[d] = o1 - o0;
-        groups *= o1 - o0;
+#pragma unroll
+    for (int d = 0; d < kWinOuter; ++d) {
+        if (d < p.nouter) {
+            const int o0 = w(p.win_outer[d], 0), o1 = w(p.win_outer[d], 1);
+            g.in_off += (int64_t)o0 * p.in_outer_stride[d];
+            g.out_off += (int64_t)o0 * p.out_outer_stride[d];
+            g.olen[d] = (uint32_t)(o1 - o0);
+            groups *= o1 - o0;
+        }
     }
     if (C > 0) {      // strided: the column axis has unit stride
-        const int c0 = p.win[2 * p.win_col], c1 = p.win[2 * p.win_col + 1];
-        in_off += c0;
-        out_off += c0;
-        p.ncol = c1 - c0;
-        p.col_tiles = (p.ncol + C - 1) / C;
-        p.ntiles = groups * p.col_tiles;
+        const int c0 = w(p.win_col, 0), c1 = w(p.win_col, 1);
+        g.in_off += c0;
+        g.out_off += c0;
+        g.ncol = c1 - c0;
+        g.col_tiles = (g.ncol + C - 1) / C;
+        g.ntiles = groups * g.col_tiles;
     } else {
-        p.nlines = groups;
-        p.ntiles = (groups + p.rows - 1) / p.rows;
+        g.nlines = groups;
+        g.ntiles = (groups + p.rows - 1) / p.rows;
     }
-    p.in += in_off * (int64_t)sizeof(T);
-    p.out += out_off * (int64_t)sizeof(T);
+    return g;
 }
 
 // (32-bit decomposition: a 64-bit integer division costs ~1 us on this machine, and the persistent
 // kernels do one or two per tile; the host only takes this path for fewer than 2^31 lines)
-__device__ __forceinline__ void tile_offsets(const LineTile& p, int64_t idx, int64_t& in_off,
+__device__ __forceinline__ void tile_offsets(const LineTile& p, const TileGeo& g, int64_t idx, int64_t& in_off,
                                              int64_t& out_off)
 {
     in_off = 0;
     out_off = 0;
     uint32_t r = (uint32_t)idx;
+    if (p.win) {
+        // (windowed pass: at most kWinOuter outer axes, lengths in registers)
+#pragma unroll
+        for (int d = kWinOuter - 1; d > 0; --d) {
+            if (d < p.nouter) {
+                const uint32_t len = g.olen[d];
+                const uint32_t q = r / len;
+                const uint32_t c = r - q * len;
+                in_off += (int64_t)c * p.in_outer_stride[d];
+                out_off += (int64_t)c * p.out_outer_stride[d];
+                r = q;
+            }
+        }
+        if (p.nouter > 0) {
+            in_off += (int64_t)r * p.in_outer_stride[0];
+            out_off += (int64_t)r * p.out_outer_stride[0];
+        }
+        return;
+    }
     for (int d = p.nouter - 1; d > 0; --d) {
         const uint32_t len = (uint32_t)p.outer_len[d];
         const uint32_t q = r / len;
@@ -424,10 +468,9 @@ __device__ __forceinline__ void lds_barrier()
 // Persistent workgroups; with VEC the next tile's rows are already in flight (in registers) while
 // the current tile is filtered and stored.
 template <typename T, int C, bool VEC>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_strided_kernel(const LineTile pk)
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_strided_kernel(const LineTile p)
 {
-    LineTile p = pk;
-    apply_window<T, C>(p);
+    const TileGeo geo = tile_geometry<C>(p);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* tile = reinterpret_cast<T*>(smem) + kK * C;     // [kK | n32 | kK][C]: sample j at row j
     typedef typename VecOf<T>::type V;
@@ -436,13 +479,13 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
     constexpr int RP = kBlock / CH;                    // rows per pass of the vector loads
     constexpr int NPF = VEC ? (C * (int)sizeof(T) == 256 ? 16 : 18) : 1;   // loads per thread per tile
     const int tid = threadIdx.x;
-    const int n = p.n;
+    const int n = geo.n;
     const int ch = tid % CH, r0 = tid / CH;
     const bool tr = p.transpose != 0;
     typedef typename TileArith<T>::type A;
     const A z = (A)p.z, h0 = (A)p.h0;
-    const T* in_base = reinterpret_cast<const T*>(p.in);
-    T* out_base = reinterpret_cast<T*>(p.out);
+    const T* in_base = reinterpret_cast<const T*>(p.in) + geo.in_off;
+    T* out_base = reinterpret_cast<T*>(p.out) + geo.out_off;
 
     struct Where {
         int64_t in_off, out_off;
@@ -450,10 +493,10 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
     };
     auto locate = [&](int64_t t) {
         Where w;
-        const uint32_t grp = (uint32_t)t / (uint32_t)p.col_tiles;
-        const int col0 = (int)((uint32_t)t - grp * (uint32_t)p.col_tiles) * C;
-        w.ncols = p.ncol - col0 < C ? p.ncol - col0 : C;
-        tile_offsets(p, grp, w.in_off, w.out_off);
+        const uint32_t grp = (uint32_t)t / (uint32_t)geo.col_tiles;
+        const int col0 = (int)((uint32_t)t - grp * (uint32_t)geo.col_tiles) * C;
+        w.ncols = geo.ncol - col0 < C ? geo.ncol - col0 : C;
+        tile_offsets(p, geo, grp, w.in_off, w.out_off);
         w.in_off += col0;
         w.out_off += col0;
         return w;
@@ -471,7 +514,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
     };
 
     int64_t t = blockIdx.x;
-    if (t >= p.ntiles)
+    if (t >= geo.ntiles)
         return;
     Where cur = locate(t);
     if (VEC)
@@ -507,7 +550,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
         lds_barrier();
         // halo rows: samples -kK .. -1 and n .. n32 + kK - 1, mirrored (forward) or zero (transpose)
         {
-            const int nh = kK + (p.nb * kB - n) + kK;
+            const int nh = kK + (geo.nb * kB - n) + kK;
             const int cc = tid % C;
             for (int h0_ = tid / C; h0_ < nh; h0_ += 8 * (kBlock / C)) {
                 T x[8];
@@ -528,7 +571,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
             }
         }
         const int64_t next = t + gridDim.x;
-        const bool has_next = next < p.ntiles;
+        const bool has_next = next < geo.ntiles;
         Where nxt = cur;
         if (has_next) {
             nxt = locate(next);
@@ -540,7 +583,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
         const int c = tid % C;
         const T* col = tile + c;
         T* dst = out_base + cur.out_off;
-        for (int blk = tid / C; blk < p.nb; blk += kBlock / C) {
+        for (int blk = tid / C; blk < geo.nb; blk += kBlock / C) {
             const int b = blk * kB;
             A o[kB];
             block_from_reader([&](int j) { return (A)col[j * C]; }, b, z, h0, o);
@@ -576,10 +619,9 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
 
 // ---- contiguous axis -------------------------------------------------------------------------------
 template <typename T, bool VEC>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_contig_kernel(const LineTile pk)
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_contig_kernel(const LineTile p)
 {
-    LineTile p = pk;
-    apply_window<T, 0>(p);
+    const TileGeo geo = tile_geometry<0>(p);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename VecOf<T>::type V;
     typedef typename std::conditional<VEC, V, T>::type W;
@@ -589,13 +631,13 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
     int64_t* row_off = reinterpret_cast<int64_t*>(smem);          // [parity][in / out][32]
     T* tile = reinterpret_cast<T*>(smem + 1024);                  // [R][pitch], sample j at [kK + j]
     const int tid = threadIdx.x;
-    const int n = p.n, R = p.rows, pitch = p.pitch;
-    const int n32 = p.nb * kB;
+    const int n = geo.n, R = p.rows, pitch = p.pitch;
+    const int n32 = geo.nb * kB;
     const bool tr = p.transpose != 0;
     typedef typename TileArith<T>::type A;
     const A z = (A)p.z, h0 = (A)p.h0;
-    const T* in_base = reinterpret_cast<const T*>(p.in);
-    T* out_base = reinterpret_cast<T*>(p.out);
+    const T* in_base = reinterpret_cast<const T*>(p.in) + geo.in_off;
+    T* out_base = reinterpret_cast<T*>(p.out) + geo.out_off;
     const int nc = n / VN;                 // n % VN == 0 (host)
     const int total = R * nc;
     const float inv_nc = 1.0f / (float)nc;
@@ -603,9 +645,9 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
     auto setup_rows = [&](int64_t t, int par) {
         if (tid < R) {
             const int64_t line0 = t * R;
-            const int nl = (int)(p.nlines - line0 < R ? p.nlines - line0 : R);
+            const int nl = (int)(geo.nlines - line0 < R ? geo.nlines - line0 : R);
             int64_t a, b;
-            tile_offsets(p, line0 + (tid < nl ? tid : nl - 1), a, b);
+            tile_offsets(p, geo, line0 + (tid < nl ? tid : nl - 1), a, b);
             row_off[par * 64 + tid] = a;
             row_off[par * 64 + 32 + tid] = b;
         }
@@ -622,7 +664,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
     };
 
     int64_t t = blockIdx.x;
-    if (t >= p.ntiles)
+    if (t >= geo.ntiles)
         return;
     int tslot = 0;
     auto stamp = [&]() {
@@ -668,7 +710,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
             }
         }
         const int64_t next = t + gridDim.x;
-        const bool has_next = next < p.ntiles;
+        const bool has_next = next < geo.ntiles;
         if (has_next)
             setup_rows(next, par ^ 1);
         lds_barrier();
@@ -705,7 +747,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
 
         // one (line, block) item per thread
         const int r = tid % R, blk = tid / R;
-        const bool have = blk < p.nb;
+        const bool have = blk < geo.nb;
         A o[kB];
         const int b = blk * kB;
         if (have) {
@@ -791,7 +833,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
         stamp();
         {
             const int64_t line0 = t * R;
-            const int nl = (int)(p.nlines - line0 < R ? p.nlines - line0 : R);
+            const int nl = (int)(geo.nlines - line0 < R ? geo.nlines - line0 : R);
             constexpr int NST = 8192 / (kBlock * VN);
 #pragma unroll
             for (int u = 0; u < NST; ++u) {
@@ -876,6 +918,8 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
         return true;
     };
     const bool contig = f.in_axis_stride == 1 && f.out_axis_stride == 1 && f.nouter > 0;
+    if (f.win && f.nouter - (contig ? 0 : 1) > kWinOuter)
+        return hipErrorNotSupported;       // (windowed passes keep their outer lengths in registers)
     if (contig) {
         const bool vec = aligned16 && p.n % VN == 0 && strides_vec(-1);
         p.pitch = 2 * kK + p.nb * kB + (vec ? VN : 1);
