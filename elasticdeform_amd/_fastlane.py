@@ -39,16 +39,21 @@ def _init():
 
 
 def _hashable(v):
-    """order / mode / cval / axis: scalars as they are, (nested) lists and tuples as tagged tuples"""
-    if v is None or type(v) in (int, float, str, bool):
-        return v
-    return _host._freeze(v)
+    """order / mode / cval / axis: tagged by type like the general path's plan key (_host._freeze), so that
+    order=3, order=3.0 and order=True -- which the general path validates differently -- never share a lane"""
+    return None if v is None else _host._freeze(v)
+
+
+class _NoLane(Exception):
+    pass
 
 
 def _crop_key(crop):
     if crop is None:
         return None
-    return tuple((s.start, s.stop, s.step) if isinstance(s, slice) else ('?', id(s)) for s in crop)
+    if not all(isinstance(s, slice) for s in crop):
+        raise _NoLane()             # (the general path raises the reference's exception for it)
+    return tuple((s.start, s.stop, s.step) for s in crop)
 
 
 def signature(gradient, X, displacement, order, mode, cval, crop, prefilter, axis, X_shape, flags):
@@ -80,8 +85,24 @@ def signature(gradient, X, displacement, order, mode, cval, crop, prefilter, axi
         return (gradient, type(X) is list, tuple(sig), dev, displacement.shape, displacement.stride(),
                 displacement.dtype, _hashable(order), _hashable(mode), _hashable(cval), _crop_key(crop),
                 bool(prefilter), _hashable(axis), X_shape, flags)
-    except TypeError:
+    except (_NoLane, TypeError):
         return None
+
+
+def _like_desc(dgm, x, shape=None):
+    """Descriptor (data pointer 0) of what torch.empty_like(x) / torch.empty(shape, dtype=x.dtype) would be for
+    the dense tensors the lanes serve -- built from the layout, no allocation."""
+    es = x.element_size()
+    if shape is None:
+        if not x.is_contiguous():
+            return dgm._desc(_torch.empty_like(x))          # (preserved strides of a non-dense view: ask torch)
+        shape = x.shape
+    shape = tuple(int(v) for v in shape)
+    strides, st = [], es
+    for d in reversed(shape):
+        strides.append(st)
+        st *= d
+    return _lib.describe(0, dgm._dtype_name(x), shape, list(reversed(strides)))
 
 
 class _Filter(object):
@@ -99,9 +120,10 @@ class _Filter(object):
         self.chain = all(int(x.shape[d]) <= 256 for d in axes)
         self.overwrite = bool(overwrite and self.chain)
         self.src = dgm._desc(x)
-        like = _torch.empty_like(x)
-        self.b0 = self.src if self.overwrite else dgm._desc(like)
-        self.b1 = dgm._desc(like) if (self.n > 1 and not self.chain) else None
+        # (descriptors of tensors "like x" from its layout alone: only the data pointer changes per call; building
+        # them from scratch tensors cost up to three volume-sized allocations after the result was already computed)
+        self.b0 = self.src if self.overwrite else _like_desc(dgm, x)
+        self.b1 = _like_desc(dgm, x) if (self.n > 1 and not self.chain) else None
         self.steps = axes
 
     def run(self, L, x, flags, stream, ebuf):
@@ -163,10 +185,10 @@ class Lane(object):
             for i, x in enumerate(xs):
                 if prefilter and plan.order[i] > 1:
                     self.filters[i] = _Filter(dgm, x, plan.axis[i], plan.order[i], False, False)
-                    self.ins[i] = dgm._desc(torch.empty_like(x))
+                    self.ins[i] = _like_desc(dgm, x)
                 else:
                     self.ins[i] = dgm._desc(x)
-                self.outs[i] = dgm._desc(torch.empty(self.shapes[i], dtype=x.dtype, device=self.dev))
+                self.outs[i] = _like_desc(dgm, x, self.shapes[i])
         # upper bound of what the crop-aware prefilter could save (deform_grid._crop_windows): calls
         # that might engage it stay on the general path
         self.max_saving = 0.0

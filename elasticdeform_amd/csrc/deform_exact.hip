@@ -456,7 +456,7 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
 // is extremal at the box's corners.  One workgroup walks the control points -- O(grid) instead of the
 // O(voxels) of source_box_kernel (933 us for a 256^3 output): floor / ceil of that hull, a superset of
 // the exact box (a few samples wider for the grids elastic deformation uses).
-constexpr int kHullCap = 4096;          // doubles per refinement buffer
+constexpr int kHullCap = 4000;          // doubles per refinement buffer (two of them + the partial results: under 64 KiB of static LDS)
 
 __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, int* box, const SourceWindow sw)
 {

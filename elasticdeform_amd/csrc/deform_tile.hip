@@ -1308,6 +1308,11 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
             tg.hint_seq = sh->begin_call(key, (unsigned)(ntiles * nb));
         }
     }
+    // (a call without spill feedback -- integer volumes, order 0 -- must leave the counters of the float call in
+    // front of it alone: its tables kernel used to reset them unreported, and a multi-input call such as
+    // BASELINE cfg4 never learned that its geometry does not spill)
+    if (!sh)
+        tg.hint = nullptr;
     tg.keep_mode = 0;
     tg.keep_stash = nullptr;
     tg.keep_flags = nullptr;

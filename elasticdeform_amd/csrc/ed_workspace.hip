@@ -97,6 +97,7 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
         if (e == hipSuccess) {
             b.cap = bytes;
             b.transient = true;
+            (void)hipMemsetAsync(b.ptr, 0, (size_t)65536, stream);      // (spill-feedback words: see below)
             return b.ptr;
         }
         (void)hipGetLastError();
@@ -117,6 +118,9 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
         return nullptr;
     }
     b.cap = want;
+    // the head holds the spill-feedback words (count, sequence number) the next tables kernel reports to the
+    // host: leftover memory must not pass for a report (SpillHint::absorb matches small sequence numbers)
+    (void)hipMemsetAsync(b.ptr, 0, want < (size_t)65536 ? want : (size_t)65536, stream);
     return b.ptr;
 }
 

@@ -385,16 +385,27 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
             one.raw = (flags & EDHIP_FLAG_RAW_DISPLACEMENT) ? 1 : 0;
             // (several inputs share the geometry: the boxes are those of the last forward launch,
             // which is what a gradient call with the same inputs reads them for)
+            // The tile path clears the block inside its tables launch -- when its start is 16-byte aligned.  A
+            // block it cannot take is cleared HERE, in front of the scatter (it used to be cleared behind a
+            // launch that returned success with zero_done unset: the computed gradient was wiped).
+            hipError_t ce = hipSuccess;
             if (zero) {
-                one.zero_ptr = zero_ptr[i];
-                one.zero_bytes = zero_bytes[i];
+                if (((uintptr_t)zero_ptr[i] & 15) == 0) {
+                    one.zero_ptr = zero_ptr[i];
+                    one.zero_bytes = zero_bytes[i];
+                } else {
+                    ce = clear_now(i);
+                }
             }
-            e = launch_deform_tile(g, v, gradient != 0, stream, &one);
-            // (the tile path either cleared the block in its tables launch or has not touched it yet)
-            if (zero && !one.zero_done && (e == hipSuccess || e == hipErrorNotSupported)) {
-                const hipError_t ce = clear_now(i);
+            e = ce == hipSuccess ? launch_deform_tile(g, v, gradient != 0, stream, &one) : ce;
+            // (a tile path that declined the call -- or served it on a route without the tables' fill -- has
+            // not touched the block: cleared now, and whoever takes the call next finds it cleared)
+            // (zero_done unset behind an aligned block: the tables launch -- which precedes every scatter of the
+            // tile path -- was not made, so nothing has been added to the block yet)
+            if (zero && one.zero_ptr && !one.zero_done && (e == hipSuccess || e == hipErrorNotSupported)) {
+                const hipError_t c2 = clear_now(i);
                 if (e == hipSuccess)
-                    e = ce;
+                    e = c2;
             }
         }
         else

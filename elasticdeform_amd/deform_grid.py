@@ -359,7 +359,11 @@ def _lane_build(sig, gradient, xs, dd, plan, prefilter, X_shape, crop):
     if dd.ndim < 2 or dd.numel() > _lib.RAW_DISPLACEMENT_MAX_POINTS:
         _fastlane.remember(sig, False)
         return
-    _fastlane.remember(sig, _fastlane.Lane(_this, gradient, xs, dd, plan, prefilter, X_shape, _flags, crop))
+    try:
+        lane = _fastlane.Lane(_this, gradient, xs, dd, plan, prefilter, X_shape, _flags, crop)
+    except Exception:
+        lane = False        # (the result of this call is already computed: a lane that cannot be built is no lane)
+    _fastlane.remember(sig, lane)
 
 
 # Layouts whose deformed axes are not the innermost ones (channel-last volumes: X is (D, H, W, C) with

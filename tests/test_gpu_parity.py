@@ -1437,6 +1437,23 @@ def test_zero_gradient_flag_clears_dense_accumulators_on_every_route():
         _lib.deform(True, [dgm._desc(acc)], dgm._desc(d), None, [dgm._desc(dY)], [axes], [order], [3], [0.0], None,
                     _lib.FLAG_AUTO | _lib.FLAG_RAW_DISPLACEMENT, stream)
         assert float((acc - 2.0 - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), shape
+    # a dense accumulator whose first element is element-aligned but NOT 16-byte aligned (a sub-buffer handed
+    # through the C ABI): the tables launch cannot take the fill, so the block is cleared in front of the
+    # scatter -- it used to be cleared BEHIND it and the gradient came back all zeros
+    for dt, odd in ((np.float32, 1), (np.float32, 3), (np.float64, 1)):
+        shape = (40, 36, 44)
+        n = int(np.prod(shape))
+        dY = torch.from_numpy(rng.random(shape).astype(dt)).to(dev)
+        d = torch.from_numpy(rng.standard_normal((3, 3, 3, 3)) * 1.5).to(dev)
+        want = ed.deform_grid_gradient(dY, d, order=3, mode="mirror", prefilter=False)
+        pool = torch.full((n + 8,), float("nan"), dtype=dY.dtype, device=dev)
+        dX = pool[odd:odd + n].view(shape)
+        assert dX.data_ptr() % 16 != 0 and dX.is_contiguous()
+        _lib.deform(True, [dgm._desc(dX)], dgm._desc(d), None, [dgm._desc(dY)], [(0, 1, 2)], [3], [3], [0.0], None,
+                    _lib.FLAG_AUTO | _lib.FLAG_RAW_DISPLACEMENT | _lib.FLAG_ZERO_GRADIENT, stream)
+        assert float(want.abs().max()) > 0.1
+        assert float((dX - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), (dt, odd)
+        assert bool(torch.isnan(pool[:odd]).all()) and bool(torch.isnan(pool[odd + n:]).all())      # nothing outside the block
     # a strided (non-dense) accumulator is refused
     big = torch.zeros((40, 36, 88), dtype=torch.float32, device=dev)
     dY = torch.rand((40, 36, 44), device=dev)
