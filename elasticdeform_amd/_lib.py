@@ -17,6 +17,7 @@ MAX_AXES = 7
 
 FLAG_AUTO, FLAG_EXACT, FLAG_FAST = 0, 1, 2
 FLAG_RAW_DISPLACEMENT = 4      # edhip_deform prefilters the control grid itself (<= 4096 points)
+FLAG_GRID_STAYS = 64           # with RAW_DISPLACEMENT: the raw grid of the previous RAW call on the stream, unchanged
 ERR_UNSUPPORTED = 5             # EDHIP_ERR_UNSUPPORTED: legal, outside this build's limits (nothing was launched)
 FLAG_KEEP_BOXES = 8            # forward: leave the tiles' bounding boxes for the gradient call that follows
 FLAG_USE_BOXES = 16            # gradient: same displacement contents and geometry as that forward call

@@ -456,6 +456,19 @@ hipError_t launch_deform_exact(const GridGeom& g, const IOView& v, int gradient,
 // is extremal at the box's corners.  One workgroup walks the control points -- O(grid) instead of the
 // O(voxels) of source_box_kernel (933 us for a 256^3 output): floor / ceil of that hull, a superset of
 // the exact box (a few samples wider for the grids elastic deformation uses).
+// mirror index map of deform.c:668-686 in 32-bit arithmetic (control grids are small; a 64-bit modulo costs
+// about a microsecond here, and the level-0 load did one per axis and point)
+__device__ __forceinline__ int mirror_small(int i, int n)
+{
+    if (n <= 1)
+        return 0;
+    const int period = 2 * n - 2;
+    if (i < 0)
+        i = -i;
+    i %= period;
+    return i >= n ? period - i : i;
+}
+
 constexpr int kHullCap = 4000;          // doubles per refinement buffer (two of them + the partial results: under 64 KiB of static LDS)
 
 __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, int* box, const SourceWindow sw)
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
                 int64_t off = g.disp_stride[0] * h;
                 for (int k = naxis - 1; k >= 0; --k) {
                     const int q = r / n[k];
-                    off += mirror_index((int64_t)T[k] + (r - q * n[k]), g.ncp[k]) * g.disp_stride[k + 1];
+                    off += (int64_t)mirror_small((int)T[k] + (r - q * n[k]), (int)g.ncp[k]) * g.disp_stride[k + 1];
                     r = q;
                 }
                 sbuf[0][e] = load_as_double(g.disp + off, g.disp_dtype);

@@ -51,6 +51,17 @@ struct SpillHint {
 };
 SpillHint* spill_hint(hipStream_t stream);          // nullptr when pinned memory is not available
 
+// What the head of a stream's workspace holds: the filtered copy of which raw control grid
+// (EDHIP_FLAG_RAW_DISPLACEMENT), written where.  A call with EDHIP_FLAG_GRID_STAYS whose raw grid matches
+// the stamp -- and whose workspace has not moved -- skips the prefilter launch.  Callers hold the StreamGuard.
+struct GridStamp {
+    const void* raw = nullptr;
+    const void* ws = nullptr;
+    int dtype = 0, ndim = 0;
+    long long shape[9] = {}, stride[9] = {};
+};
+GridStamp* grid_stamp(hipStream_t stream);
+
 // Drains the devices that own scratch and frees every cached buffer.
 void workspace_release_all();
 

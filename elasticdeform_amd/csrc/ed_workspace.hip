@@ -162,6 +162,16 @@ void* keep_reserve(hipStream_t stream, size_t bytes, KeepKey** key, hipError_t* 
     return b.ptr;
 }
 
+GridStamp* grid_stamp(hipStream_t stream)
+{
+    static std::map<std::pair<int, hipStream_t>, GridStamp> stamps;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        dev = -1;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    return &stamps[std::make_pair(dev, stream)];      // (std::map: the address is stable)
+}
+
 SpillHint* spill_hint(hipStream_t stream)
 {
     int dev = 0;

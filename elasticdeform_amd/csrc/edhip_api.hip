@@ -106,9 +106,28 @@ int make_geometry(const edhip_array* displacement, const int64_t* in_len, const 
             g.disp_stride[k] = stride;
             stride *= gp.shape[k];
         }
-        e = launch_grid_prefilter(gp, stream);
-        if (e != hipSuccess)
-            return hip_fail(err, errlen, e, "grid prefilter launch");
+        // (EDHIP_FLAG_GRID_STAYS: the previous call's filtered copy of this very grid is still there)
+        GridStamp* stamp = grid_stamp(stream);
+        GridStamp now;
+        now.raw = displacement->data;
+        now.ws = ws;
+        now.dtype = displacement->dtype;
+        now.ndim = naxis + 1;
+        for (int k = 0; k <= naxis; ++k) {
+            now.shape[k] = displacement->shape[k];
+            now.stride[k] = displacement->stride_bytes[k];
+        }
+        const bool stays = (flags & EDHIP_FLAG_GRID_STAYS) && stamp->raw == now.raw && stamp->ws == now.ws &&
+                           stamp->dtype == now.dtype && stamp->ndim == now.ndim &&
+                           memcmp(stamp->shape, now.shape, sizeof(now.shape)) == 0 &&
+                           memcmp(stamp->stride, now.stride, sizeof(now.stride)) == 0;
+        if (!stays) {
+            *stamp = GridStamp();
+            e = launch_grid_prefilter(gp, stream);
+            if (e != hipSuccess)
+                return hip_fail(err, errlen, e, "grid prefilter launch");
+            *stamp = now;
+        }
         g.disp = (const char*)ws;
     }
     if (affine)

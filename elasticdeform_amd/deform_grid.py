@@ -274,7 +274,7 @@ _WINDOW_MARGIN = {'float32': {2: 12, 3: 16}, 'float64': {2: 24, 3: 32}}
 _WINDOW_MIN_LINE = 64                # the whole-line tile kernels' shortest line
 
 
-def _crop_windows(plan, xs, disp_desc, dflag, crop, prefilter, device, stream):
+def _crop_windows(plan, xs, disp_desc, dflag, crop, prefilter, device, stream, grid_stays=False):
     """Per input: a device tensor holding its filter window (2 ints per dimension, edhip_source_window), or
     None for 'filter the whole array'.  Floating-point volumes of orders 2 / 3 outside 'exact' arithmetic: the
     window's coefficients equal the whole-volume ones to below the data's rounding, not bit for bit."""
@@ -316,7 +316,10 @@ def _crop_windows(plan, xs, disp_desc, dflag, crop, prefilter, device, stream):
         st = _lib.source_window(disp_desc, in_len, out_len, plan.output_offset, plan.inverse_affine,
                                 tuple(int(v) for v in x.shape), plan.axis[i], int(plan.order[i]), int(plan.mode[i]),
                                 _WINDOW_MARGIN[name][int(plan.order[i])], vn if int(x.shape[-1]) % vn == 0 else 1,
-                                _WINDOW_MIN_LINE, _flags | dflag | _lib.FLAG_FAST, stream, win.data_ptr())
+                                _WINDOW_MIN_LINE,
+                                _flags | dflag | _lib.FLAG_FAST | (_lib.FLAG_GRID_STAYS if (grid_stays and dflag) else 0),
+                                stream, win.data_ptr())
+        grid_stays = True           # (the next input's window: same grid, just filtered)
         if st == 0:
             wins[i] = win
     return wins
@@ -484,6 +487,8 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
                 for shape, x in zip(plan.output_shapes, Xd)]
 
         bflag = _box_flag_forward(displacement, df, device, stream)
+        if dflag and any(w is not None for w in wins):
+            bflag |= _lib.FLAG_GRID_STAYS        # (edhip_source_window has just filtered this very grid on this stream)
         _lib.deform(False, in_descs, _desc(df), plan.output_offset,
                     [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
                     plan.inverse_affine, _flags | dflag | bflag, stream, prepared=_prepared(plan, len(Xd)))
@@ -562,7 +567,7 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         # With a crop the scatter only touched a box of dX: the transposed filter runs on that box
         # plus its decay margin and the result replaces the box (the rest stays exactly zero, where
         # the whole-volume filter would leave values below 1e-18 of the gradient's scale).
-        wins = _crop_windows(plan, dXs, _desc(df), dflag, crop, prefilter, device, stream)
+        wins = _crop_windows(plan, dXs, _desc(df), dflag, crop, prefilter, device, stream, grid_stays=True)
         dXf = []
         for i, x in enumerate(dXs):
             if not (prefilter and plan.order[i] > 1):

@@ -141,7 +141,12 @@ enum edhip_flags {
      * order); float32 volumes on the tile kernels get the fill from spare workgroups of the per-call tables
      * launch (it overlaps that kernel instead of being a bandwidth-bound launch of its own), every other
      * route a hipMemsetAsync.  Without the flag the accumulators are added to as they are. */
-    EDHIP_FLAG_ZERO_GRADIENT = 32
+    EDHIP_FLAG_ZERO_GRADIENT = 32,
+    /* with EDHIP_FLAG_RAW_DISPLACEMENT: the caller promises that the raw control grid is, byte for byte, the one
+     * of the previous RAW_DISPLACEMENT call on this stream (edhip_source_window followed by edhip_deform inside
+     * one deform_grid call): when the library finds that call's filtered copy still in the stream's workspace
+     * (same pointer, dtype, shape and strides, workspace not moved) it does not filter the grid again. */
+    EDHIP_FLAG_GRID_STAYS = 64
 };
 
 /* strided N-d array in device memory: the POD stand-in for PyArrayObject* */
