@@ -469,12 +469,12 @@ __device__ __forceinline__ int mirror_small(int i, int n)
     return i >= n ? period - i : i;
 }
 
-constexpr int kHullCap = 4000;          // doubles per refinement buffer (two of them + the partial results: under 64 KiB of static LDS)
+constexpr int kHullCap = 3900;          // doubles per refinement buffer (two of them + the partial results: under 64 KiB of static LDS)
 
-__global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, int* box, const SourceWindow sw)
+__global__ __launch_bounds__(1024) void source_box_hull_kernel(const GridGeom g, int* box, const SourceWindow sw)
 {
     // one workgroup per component (= per source axis): 52 us for the three of a 3-D grid in one workgroup
-    __shared__ double smin[kMaxAxes][4], smax[kMaxAxes][4];
+    __shared__ double smin[kMaxAxes][16], smax[kMaxAxes][16];       // (up to 16 waves: the passes are short and latency-bound)
     const int tid = threadIdx.x, wave = tid >> 6;
     const int naxis = g.naxis;
     // control-point index range per axis whose basis functions reach the output box
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
                 tot *= n[k];
             }
             int cur = 0;
-            for (int e = tid; e < tot; e += 256) {          // level 0: the mirror-extended coefficients
+            for (int e = tid; e < tot; e += (int)blockDim.x) {          // level 0: the mirror-extended coefficients
                 int r = e;
                 int64_t off = g.disp_stride[0] * h;
                 for (int k = naxis - 1; k >= 0; --k) {
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
                         tot_out *= k == ax ? nn : n[k];
                     const double* A = sbuf[cur];
                     double* B = sbuf[cur ^ 1];
-                    for (int e = tid; e < tot_out; e += 256) {
+                    for (int e = tid; e < tot_out; e += (int)blockDim.x) {
                         const int in_idx = e % inner;                    // axes after ax
                         const int r = e / inner;
                         const int m = ia + r % nn;                       // refined index along ax
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
                     tot = tot_out;
                 }
             }
-            for (int e = tid; e < tot; e += 256) {
+            for (int e = tid; e < tot; e += (int)blockDim.x) {
                 const double v = sbuf[cur][e];
                 if (v == v) {                   // NaN grid entries: no constraint (like the exact kernel)
                     mn = v < mn ? v : mn;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
             }
             __syncthreads();                    // the next component reuses the buffers
         } else
-        for (int64_t e = tid; e < total; e += 256) {
+        for (int64_t e = tid; e < total; e += (int)blockDim.x) {
             int64_t r = e, off = g.disp_stride[0] * h;
             for (int k = naxis - 1; k >= 0; --k) {
                 const int64_t q = r / n_i[k];
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void source_box_hull_kernel(const GridGeom g, 
     if (tid < naxis && (tid % (int)gridDim.x) == (int)blockIdx.x) {
         const int h = tid;
         double mn = smin[h][0], mx = smax[h][0];
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
             mn = smin[h][w] < mn ? smin[h][w] : mn;
             mx = smax[h][w] > mx ? smax[h][w] : mx;
         }
@@ -703,7 +703,7 @@ hipError_t launch_source_box(const GridGeom& g, int* box, hipStream_t stream, bo
 {
     if ((conservative || sw) && g.nvox > 0) {
         const SourceWindow none{};
-        hipLaunchKernelGGL(source_box_hull_kernel, dim3((unsigned)g.naxis), dim3(256), 0, stream, g, box, sw ? *sw : none);
+        hipLaunchKernelGGL(source_box_hull_kernel, dim3((unsigned)g.naxis), dim3(1024), 0, stream, g, box, sw ? *sw : none);
         return hipGetLastError();
     }
     if (sw)
