@@ -462,7 +462,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
     // (per-workgroup issue priorities (s_setprio) and a staggered start of the workgroups of a CU, to
     // push co-resident workgroups into complementary phases, were tried: no change)
     hot_prologue(hg, sp, smem, threadIdx.x, !QGLOBAL, NTH);
-    if (hg.dbg & 8192)
+    if (ED_DBG(hg.dbg, 8192))
         return;       // experiment: launch + prologue only
 
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
             hot_tile_coords<ORDER, AFFINE, ABL, NV>(hg, hp, tabx + ti * kT, red, qrow, oz, oy, (sp.tx0 + ti) * kT, xx,
                                                 lane, vzy, Pzy, start, frac, valid, constant);
         lds_atomics_done();
-        if (hg.dbg & 2048) __syncthreads(); else lds_barrier();   // B1: box known; every gather of the previous tile is done
+        if (ED_DBG(hg.dbg, 2048)) __syncthreads(); else lds_barrier();   // B1: box known; every gather of the previous tile is done
         int b0[3] = {red[0], red[1], red[2]};
         int ext[3] = {red[3] - red[0] + 1, red[4] - red[1] + 1, red[5] - red[2] + 1};
         bool any = red[3] >= red[0];
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
     for (int e = tid * 4; e < hg.box_cap; e += kBlock * 4)
         *reinterpret_cast<int4*>(smem + hg.off_box + e * 4) = make_int4(0, 0, 0, 0);
     hot_prologue(hg, sp, smem, tid);
-    if (hg.dbg & 8192)
+    if (ED_DBG(hg.dbg, 8192))
         return;       // experiment: launch + prologue only
     if (NGRP == 2 && grp == 1)
         __syncthreads();
@@ -932,7 +932,7 @@ ED_UNROLL(ED_K2_U1)
             continue;      // nothing to scatter (uniform)
         // 16 lanes of a row hit 16 consecutive cells; pitch 8 * odd keeps neighbouring rows apart
         int pitch = ext[2] <= 8 ? 8 : (ext[2] <= 24 ? 24 : (ext[2] <= 40 ? 40 : (ext[2] <= 56 ? 56 : 0)));
-        if (hg.dbg & 1024)      // experiment: row offsets of 16 banks (mod 32): 34 % fewer conflict
+        if (ED_DBG(hg.dbg, 1024))      // experiment: row offsets of 16 banks (mod 32): 34 % fewer conflict
             pitch = ext[2] <= 16 ? 16 : (ext[2] <= 48 ? 48 : 0);     // cycles, but the box doubles
         if (given && ((unsigned)ext[0] > 4096u || (unsigned)ext[1] > 4096u))
             pitch = 0;          // (a handed-over box is not trusted with the products below)
@@ -994,7 +994,7 @@ ED_UNROLL(ED_K2_U2)
 #pragma unroll
                 for (int k = 1; k < NV; ++k)
                     gv = i == k ? gval[k] : gv;
-                if (gv == 0.f || (hg.dbg & 128))
+                if (gv == 0.f || ED_DBG(hg.dbg, 128))
                     continue;
                 int st[3];
                 float fr[3];
@@ -1074,7 +1074,7 @@ ED_UNROLL(ED_K2_U2)
                 const int sub = tid & (FL - 1);                // FU rows are issued before the first atomic
                 const int rslot = tid / FL;
                 const float inv_by = 1.f / (float)by;
-                const int nr = ((hg.dbg & 64) || direct_tile) ? 0 : nrows;
+                const int nr = (ED_DBG(hg.dbg, 64) || direct_tile) ? 0 : nrows;
                 for (int xo = 0; xo < ext[2]; xo += FL) {
                     const int xi = xo + sub;
                     const bool xin = xi < ext[2];
@@ -1091,7 +1091,7 @@ ED_UNROLL(ED_K2_U2)
                         }
 #pragma unroll
                         for (int k = 0; k < FU; ++k) {
-                            if ((hg.dbg & 4096) ? acc[k] == 0x7ffffff1 : acc[k] != 0) {     // (4096: timing without the atomics)
+                            if (ED_DBG(hg.dbg, 4096) ? acc[k] == 0x7ffffff1 : acc[k] != 0) {     // (4096: timing without the atomics)
                                 const int r = r0 + k * FR;
                                 const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
                                 int rowoff;
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
 
         // ---- the NEXT tile's producer, in front of this tile's consumers ------------------------------
 #ifdef EDHIP_EXPERIMENTS
-        if (hg.dbgbuf && ti == 0)
+        if (ED_DBG_PTR(hg.dbgbuf) && ti == 0)
             tmark = __builtin_readcyclecounter();
 #endif
         int nbx_next = 0;
@@ -1446,8 +1446,8 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
             };
 #ifdef EDHIP_EXPERIMENTS
             // (profiling build, EDHIP_TILE_DBG: 4 no flush, 8 no consumers)
-            const int n_a_ = (!work || (hg.dbg & 8)) ? 0 : n_a, n_b_ = (!work || (hg.dbg & 8)) ? 0 : n_b;
-            const int flush_x = (!work || (hg.dbg & 4)) ? 0 : ext[2];
+            const int n_a_ = (!work || ED_DBG(hg.dbg, 8)) ? 0 : n_a, n_b_ = (!work || ED_DBG(hg.dbg, 8)) ? 0 : n_b;
+            const int flush_x = (!work || ED_DBG(hg.dbg, 4)) ? 0 : ext[2];
 #else
             const int n_a_ = work ? n_a : 0, n_b_ = work ? n_b : 0, flush_x = work ? ext[2] : 0;
 #endif
@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(kBlock, WGS) void hot_grad2_kernel(const HotGeom hg
         nbx_cur = nbx_next;
     }
 #ifdef EDHIP_EXPERIMENTS
-    if (hg.dbgbuf && lane == 0) {
+    if (ED_DBG_PTR(hg.dbgbuf) && lane == 0) {
         unsigned long long* d = hg.dbgbuf + ((size_t)blockIdx.x * 4 + wave) * 8;
         for (int q = 0; q < 5; ++q)
             d[q] = (unsigned long long)tacc[q];

@@ -803,7 +803,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 2 : 3) void deform_tile3_g
                     gv = sel ? gval[k] : gv;
                     act = sel ? active[k] : act;
                 }
-                if (!act || gv == (T)0 || (tg.dbg & 128))
+                if (!act || gv == (T)0 || ED_DBG(tg.dbg, 128))
                     continue;
                 T w0[NT], w1[NT], w2[NT];
                 weights_from_frac<T, ORDER>(f0, w0);
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 2 : 3) void deform_tile3_g
             // (only the ext[2] live cells of each padded row are visited)
             const float inv_ex = 1.0f / (float)ext[2];
             const int ncell = nrows * ext[2];
-            for (int e = tid; e < ((tg.dbg & 64) ? 0 : ncell); e += kBlock) {
+            for (int e = tid; e < (ED_DBG(tg.dbg, 64) ? 0 : ncell); e += kBlock) {
                 const int r = (int)(((float)e + 0.5f) * inv_ex), xi = e - r * ext[2];
                 const acc_t acc = box[r * pitch + xi];
                 if (acc != 0) {
@@ -1423,7 +1423,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         [[maybe_unused]] constexpr bool kBenchKernel = PAIR && ORDER == 3 && sizeof(T) == 4;
         if constexpr (std::is_same<T, float>::value && ORDER >= 1) {
             // float32, unit stride along x on both sides: the benchmark kernels of deform_hot.hip
-            if (tg.in_stride[2] == 1 && tg.out_stride[2] == 1 && !(tg.dbg & 512) && !ed_env("EDHIP_NO_HOT")) {
+            if (tg.in_stride[2] == 1 && tg.out_stride[2] == 1 && !ED_DBG(tg.dbg, 512) && !ed_env("EDHIP_NO_HOT")) {
                 memset(&hg, 0, sizeof(hg));
                 hg.vol_r = reinterpret_cast<const float*>(ve.in);
                 hg.vol_w = reinterpret_cast<float*>(const_cast<char*>(ve.in));

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64, OCC) void wave_fwd_kernel(const HotGeom hg, con
                 if (hg.nstep)
                     wave_step_offsets(hp, ss, vol_off, img_off);
 #ifdef EDHIP_EXPERIMENTS
-                if (!(hg.dbg & 2))             // ablation: no staging
+                if (!ED_DBG(hg.dbg, 2))             // ablation: no staging
 #endif
                 if (bl.any) {
                     // (the previous gather's reads have all returned: their values were stored)
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64, OCC) void wave_fwd_kernel(const HotGeom hg, con
                     const float* bp = box + (rz * ps + ry * pitch + (rx & ~1));
                     float val = 0.f;
 #ifdef EDHIP_EXPERIMENTS
-                    if (hg.dbg & 1)            // ablation: no gather
+                    if (ED_DBG(hg.dbg, 1))            // ablation: no gather
                         val = fr[0] + fr[1] + fr[2] + w0[1];
                     else
 #endif
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64, OCC) void wave_fwd_kernel(const HotGeom hg, con
                         // 128-byte line follows from this same wave within the strip
                         float* o = op + (k - 3);
 #ifdef EDHIP_EXPERIMENTS
-                        if ((hg.dbg & 8) && val != -12345.678f)         // ablation: no stores
+                        if (ED_DBG(hg.dbg, 8) && val != -12345.678f)         // ablation: no stores
                             continue;
 #endif
                         if (ox <= last) {
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64, OCC) void wave_fwd_kernel(const HotGeom hg, con
     }
     }
 #ifdef EDHIP_EXPERIMENTS
-    if (hg.dbgbuf && lane == 0) {
+    if (ED_DBG_PTR(hg.dbgbuf) && lane == 0) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(64, OCC) void wave_grad_kernel(const HotGeom hg, co
     int zz = 2 * (lane & 3) + ((lane >> 4) & 1);
     int yy = 2 * ((lane >> 2) & 3) + ((lane >> 5) & 1);
 #ifdef EDHIP_EXPERIMENTS
-    if (hg.dbg & 16) {          // experiment: lane = 8 z + y
+    if (ED_DBG(hg.dbg, 16)) {          // experiment: lane = 8 z + y
         zz = lane >> 3;
         yy = lane & 7;
     }

@@ -308,3 +308,14 @@ __device__ __forceinline__ double control_coordinate(int64_t ncp, int64_t o_plus
 }
 
 }  // namespace ed
+
+// Experiment switches of the kernels (EDHIP_TILE_DBG bits, timestamp buffers): live in the profiling build
+// (make EXPERIMENTS=1) only -- in the shipped library the tests below are the constant `false` and the code
+// behind them is not compiled in.
+#ifdef EDHIP_EXPERIMENTS
+#define ED_DBG(word, bits) (((word) & (bits)) != 0)
+#define ED_DBG_PTR(ptr) ((ptr) != nullptr)
+#else
+#define ED_DBG(word, bits) false
+#define ED_DBG_PTR(ptr) false
+#endif
