@@ -137,6 +137,10 @@ def cpu_baseline(side=128):
     vox = float(n) ** 3
     return {
         "value": round(vox / (t2 - t0) / 1e6, 4), "unit": "Mvoxels/s", "cores": 1, "kind": kind,
+        "note": ("the reference's own C path (oracle/_ref, built from /root/reference by `make -C oracle ref` / "
+                 "__graft_entry__.build())" if kind == "reference" else
+                 "oracle/_ref is not built in this tree (it is compiled from /root/reference, which a clean clone does "
+                 "not have): the C restatement oracle/ed_oracle.c was timed instead"),
         "sample": "%d^3 float32 forward+gradient, order 3, mirror, prefilter on, 5^3 grid "
                   "(same arguments as the GPU workload, 1/8 of its voxels)" % n,
         "fwd_s": round(t1 - t0, 3), "grad_s": round(t2 - t1, 3),
@@ -469,12 +473,21 @@ def main():
         except Exception:
             return None
 
+    # HBM bytes per launch from the PMC passes (profiles/hbm_traffic.json): reported only while the kernels'
+    # sources are the ones the passes were made on (hash of the files, written by tools/hbm_traffic.py)
     traffic_db = {}
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
+            import hashlib
             with open(tpath) as f:
                 traffic_db = json.load(f)
+            h = hashlib.sha256()
+            for fn in ("deform_hot.hip", "ed_tile.h", "ed_device.h"):
+                with open(os.path.join(ROOT, "elasticdeform_amd", "csrc", fn), "rb") as fh:
+                    h.update(fh.read())
+            if traffic_db.get("kernel_sources_sha16") != h.hexdigest()[:16]:
+                traffic_db = {}
         except Exception:
             traffic_db = {}
 

@@ -12,7 +12,23 @@ import glob
 import json
 import sys
 
+import hashlib
+import os
+
 root, commit = sys.argv[1], sys.argv[2]
+
+
+def kernel_sources_sha16():
+    """Hash of the sources the two measured kernels are built from: bench.py reports `traffic` only while it
+    matches the tree it runs in (a stamp that cannot go stale unnoticed)."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("deform_hot.hip", "ed_tile.h", "ed_device.h"):
+        with open(os.path.join(here, "elasticdeform_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -20,7 +36,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
             vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/time_k12.py (the bench workload: "
                "256^3 float32, order 3, mirror, sigma 5), mean per dispatch, KB -> bytes",
-       "algorithmic_bytes_per_launch": 134217728, "kernels": {}}
+       "algorithmic_bytes_per_launch": 134217728, "kernel_sources_sha16": kernel_sources_sha16(), "kernels": {}}
 for tag, key in (("K1", "hot_fwd_kernel<3, false, 0,"), ("K2", "hot_grad_kernel<3, false")):
     for name, c in vals.items():
         if key in name and c.get("FETCH_SIZE") and c.get("WRITE_SIZE"):
