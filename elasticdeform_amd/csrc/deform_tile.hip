@@ -1299,7 +1299,10 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 ((unsigned long long)g.has_affine << 24) | ((unsigned long long)nb << 32));
             sh->absorb();
             large_boxes = sh->fraction(key) > 0.10f;
-            self_serve = sh->known(key) && sh->fraction(key) * (float)(ntiles * nb) <= 64.f;
+            // (forward: a tile gathered straight from global memory costs its workgroup ~10 us; gradient: 64 global
+            // float atomics per voxel, ~50 us per tile -- 31 such tiles of a 128^3 volume took K2 from 56 to 141 us --
+            // so the gradient serves itself only where the geometry's recent calls left nothing at all)
+            self_serve = sh->known(key) && sh->fraction(key) * (float)(ntiles * nb) <= (GRAD ? 0.5f : 64.f);
 #ifdef EDHIP_EXPERIMENTS
             if (const char* ss = ed_env("EDHIP_SELF_SERVE"))
                 self_serve = atoi(ss) != 0;

@@ -266,7 +266,8 @@ def _filter_axes(x, axes, order, transpose, device, overwrite=False, stream=None
 # it knows without the device: the output box plus the margins, as a fraction of the input.
 # (Until round 4 the box was read back to the host: the synchronisation exposed the launch latency of every
 # kernel behind it, and BASELINE cfg4 -- 3 x 256^3 cropped to 64^3 -- never got a window.)
-CROP_WINDOW_MIN_SAVING = 4e6         # voxels per filter pass, summed over the inputs (below: not worth a launch)
+CROP_WINDOW_MIN_SAVING = 24e6        # voxels per filter pass, summed over the inputs: below, the window's own launches and
+                                     # host calls (~30 us) eat what it saves (a 256^3 float32 pass is 25 us; profiles/r04_time_crop_window.txt)
 CROP_WINDOW_MAX_FRACTION = 0.50      # (output box + margins) / input, upper bound known to the host
 # decay margin (samples) after which a cut in a line is invisible in the data's own precision: |pole|^m below
 # 1e-9 for float32 volumes (their filter runs in float32), below 1e-18 for float64
