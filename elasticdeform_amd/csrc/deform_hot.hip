@@ -791,7 +791,9 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
             gnext[i] = (vy && ox < hg.out_len[2] && oz0 + ZSTEP * i < hg.out_len[0])
                            ? dy[(oz0 + ZSTEP * i) * hg.img_sz + oy * hg.img_sy + ox] : 0.f;
     }
-    for (int ti = 0; ti < ntile; ++ti) {
+    // half: -1 = the whole TX-wide tile; 0 / 1 = an oversize tile taken again as its x-halves (below)
+    int half = -1, half_next = -1;
+    for (int ti = 0; ti < ntile; half = half_next, half_next = half == 0 ? 1 : -1, ti += half < 0 ? 1 : 0) {
         int* red = sred + (ti % 3) * 8;
         const int ox = sp.tx0 * kT + ti * TX + xx;
         const bool vx = ox < hg.out_len[2];
@@ -799,10 +801,17 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
         const int ostep = ZSTEP * hg.img_sz;
 
         float gpre[NV];
+        if (half >= 0) {
+            // (the tile's dY again: gnext already holds the next tile's)
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            gpre[i] = gnext[i];
-        if (ti + 1 < ntile) {
+            for (int i = 0; i < NV; ++i)
+                gpre[i] = (vy && vx && oz0 + ZSTEP * i < hg.out_len[0]) ? dy[ooff0 + i * ostep] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                gpre[i] = gnext[i];
+        }
+        if (half < 0 && ti + 1 < ntile) {
             const bool nvx = ox + TX < hg.out_len[2];
 #pragma unroll
             for (int i = 0; i < NV; ++i)
@@ -820,14 +829,22 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
                 gb0[h] = uni(bx[h]);
                 gbhi[h] = uni(bx[3 + h]);
             }
+            if (half < 0) {
 #pragma unroll
-            for (int k = 1; k < TX / kT; ++k) {
-                if (sp.tx0 + ti * (TX / kT) + k < hg.tiles[2]) {
+                for (int k = 1; k < TX / kT; ++k) {
+                    if (sp.tx0 + ti * (TX / kT) + k < hg.tiles[2]) {
 #pragma unroll
-                    for (int h = 0; h < 3; ++h) {
-                        gb0[h] = min(gb0[h], uni(bx[k * 8 + h]));
-                        gbhi[h] = max(gbhi[h], uni(bx[k * 8 + 3 + h]));
+                        for (int h = 0; h < 3; ++h) {
+                            gb0[h] = min(gb0[h], uni(bx[k * 8 + h]));
+                            gbhi[h] = max(gbhi[h], uni(bx[k * 8 + 3 + h]));
+                        }
                     }
+                }
+            } else if (half == 1) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    gb0[h] = uni(bx[8 + h]);
+                    gbhi[h] = uni(bx[8 + 3 + h]);
                 }
             }
         }
@@ -863,7 +880,8 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
                     P[h] = fma(hp->affine[h * 4 + 0], (double)oz, Pxy[h]);
             }
             const bool cst = hot_coords<ORDER, AFFINE>(hg, hp, qrow0 + i * qstep, tw, tib, b, P, start, frac);
-            return vy && vx && oz < hg.out_len[0] && !cst;     // constant voxels contribute nothing (:928)
+            // constant voxels contribute nothing (:928); in a half pass the other half's lanes sit out
+            return vy && vx && oz < hg.out_len[0] && !cst && (half < 0 || (xx >> 3) == half);
         };
         // With the forward call's boxes (EDHIP_FLAG_USE_BOXES) the box pass is skipped: this tile's box
         // is the union of the boxes of the 8-wide forward tiles it covers.
@@ -939,19 +957,25 @@ ED_UNROLL(ED_K2_U1)
         const int by = ext[1];
         const int nrows = ext[0] * by;
         const int nbox = nrows * pitch;
-        if (hg.hint && tid == 0 && (pitch == 0 || nbox > hg.small_cap))
+        if (hg.hint && tid == 0 && half < 0 && (pitch == 0 || nbox > hg.small_cap))
             atomicAdd(hg.hint, TX / kT);   // spill feedback, in 8-wide tiles
         // self_serve: a tile that does not fit keeps an EMPTY box -- every live voxel then fails the window test
         // below and scatters its taps straight to global memory (the path of a stale handed-over box)
         bool direct_tile = false;
         if (pitch == 0 || nbox > hg.box_cap) {
+            if (TX == 16 && given && half < 0 && sp.tx0 + ti * 2 + 1 < hg.tiles[2]) {
+                // taken again as its two x-halves, each with the box of the forward tile it is (8 lanes of every
+                // 16 sit out a pass): what the forward kernel could hold, 6144 cells can
+                half_next = 0;
+                continue;
+            }
             if (hg.self_serve) {
                 direct_tile = true;
             } else {
-                if (tid < TX / kT && sp.tx0 + ti * (TX / kT) + tid < hg.tiles[2]) {
+                const int t8 = sp.tx0 + ti * (TX / kT) + (half >= 0 ? half : tid);
+                if (tid < (half >= 0 ? 1 : TX / kT) && t8 < hg.tiles[2]) {
                     const int slot = atomicAdd(&hg.spill[0], 1);
-                    hg.spill[1 + slot] = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] +
-                                         sp.tx0 + ti * (TX / kT) + tid;
+                    hg.spill[1 + slot] = sp.sample * hg.ntiles + (sp.tz * hg.tiles[1] + sp.ty) * hg.tiles[2] + t8;
                 }
                 continue;
             }

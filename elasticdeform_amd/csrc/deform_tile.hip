@@ -1283,29 +1283,40 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     bool large_boxes = false;
     // self-serve: the recent calls of this geometry left at most a handful of tiles to the spill list -- level 1
     // then takes such tiles itself (straight from / to global memory) and the two spill launches are not made
-    bool self_serve = false;
+    bool self_serve = false, self_serve_boxes = false;
     if constexpr (std::is_same<T, float>::value && ORDER >= 1) {
         sh = ed_env("EDHIP_NO_SPILL_HINT") ? nullptr : spill_hint(stream);
         if (sh) {
-            unsigned long long key = 1469598103934665603ull;
-            auto mix = [&](unsigned long long x) { key = (key ^ x) * 1099511628211ull; };
-            for (int k = 0; k < 3; ++k) {
-                mix((unsigned long long)g.in_len[k]);
-                mix((unsigned long long)g.out_len[k]);
-                mix((unsigned long long)g.off[k]);
-                mix((unsigned long long)g.ncp[k]);
-            }
-            mix((unsigned long long)ORDER | ((unsigned long long)GRAD << 8) | ((unsigned long long)v.mode << 16) |
-                ((unsigned long long)g.has_affine << 24) | ((unsigned long long)nb << 32));
+            auto geometry_key = [&](bool grad) {
+                unsigned long long key = 1469598103934665603ull;
+                auto mix = [&](unsigned long long x) { key = (key ^ x) * 1099511628211ull; };
+                for (int k = 0; k < 3; ++k) {
+                    mix((unsigned long long)g.in_len[k]);
+                    mix((unsigned long long)g.out_len[k]);
+                    mix((unsigned long long)g.off[k]);
+                    mix((unsigned long long)g.ncp[k]);
+                }
+                mix((unsigned long long)ORDER | ((unsigned long long)grad << 8) | ((unsigned long long)v.mode << 16) |
+                    ((unsigned long long)g.has_affine << 24) | ((unsigned long long)nb << 32));
+                return key;
+            };
+            const unsigned long long key = geometry_key(GRAD);
             sh->absorb();
             large_boxes = sh->fraction(key) > 0.10f;
-            // (forward: a tile gathered straight from global memory costs its workgroup ~10 us; gradient: 64 global
-            // float atomics per voxel, ~50 us per tile -- 31 such tiles of a 128^3 volume took K2 from 56 to 141 us --
-            // so the gradient serves itself only where the geometry's recent calls left nothing at all)
+            // Forward: a tile gathered straight from global memory costs its workgroup ~10 us, so a handful may stay.
+            // Gradient: 64 global float atomics per voxel, ~50 us per 16-wide tile (31 such tiles of a 128^3 volume
+            // took K2 from 56 to 141 us).  A gradient call WITH the forward call's boxes takes its oversize tiles as
+            // x-halves, and what is left is what the forward call could not hold either: it serves itself when the
+            // FORWARD calls of the geometry left at most a few tiles (decided below, where the boxes are known to be
+            // there); without the boxes only where its own recent calls left nothing at all.
             self_serve = sh->known(key) && sh->fraction(key) * (float)(ntiles * nb) <= (GRAD ? 0.5f : 64.f);
+            if (GRAD) {
+                const unsigned long long fkey = geometry_key(false);
+                self_serve_boxes = sh->known(fkey) && sh->fraction(fkey) * (float)(ntiles * nb) <= 8.f;
+            }
 #ifdef EDHIP_EXPERIMENTS
             if (const char* ss = ed_env("EDHIP_SELF_SERVE"))
-                self_serve = atoi(ss) != 0;
+                self_serve = self_serve_boxes = atoi(ss) != 0;
 #endif
             tg.hint_host = sh->dev;
             tg.hint_seq = sh->begin_call(key, (unsigned)(ntiles * nb));
@@ -1566,6 +1577,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                             // hand-over's bookkeeping costs more than it saves: 190 -> 196, 242 -> 252 us)
                             hg.boxes = kb;
                             hg.use_boxes = 1;
+                            if (self_serve_boxes && ORDER <= 3)
+                                hg.self_serve = 1;
                         }
                     }
                 }
