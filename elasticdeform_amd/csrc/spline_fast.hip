@@ -264,6 +264,7 @@ struct LineTile {
     int pitch;                   // contiguous: tile row pitch in elements
     int64_t ntiles;
     int transpose;
+    int fold;                    // transpose: folded tail terms kept (fold_tails)
     unsigned long long* trace;   // profiling only (EDHIP_FILTER_TRACE): phase timestamps of workgroup 0
     double z, h0;
     // device-side window (edhip_spline_filter_axes_window): (w0, w1) per array dimension in device memory; the
@@ -376,11 +377,25 @@ __device__ __forceinline__ void tile_offsets(const LineTile& p, const TileGeo& g
 }
 
 // transpose: fold the two tails of the zero-extended result back into block b (see header).
-// A = arithmetic type of the tile kernels (see TileArith).
+// A = arithmetic type of the tile kernels (see TileArith).  kfold: the folded terms z^m s are dropped from
+// m = kfold on (|z|^kfold is below the rounding of A: kK in double, LineTile::fold in float).  When the line
+// ends with this block (lengths that are a multiple of the block) s[n-1] is the block's own last output -- above
+// n-1 the extension is zero, so the anti-causal sum there is x[n-1] itself and o = h0 (yc + x - x) -- and every
+// index is static; other lengths recompute it with s_last_fn.  (The fold used to run in two of a line's eight
+// blocks, each with a 32-step recursion of its own, and the waves that got those blocks held the tile back.)
 template <typename A, typename SLast>
-__device__ __forceinline__ void fold_tails(A (&o)[kB], int b, int n, A z, A h0, SLast s_last_fn)
+__device__ __forceinline__ void fold_tails(A (&o)[kB], int b, int n, A z, A h0, int kfold, SLast s_last_fn)
 {
-    if (b + kB > n - 1 - kK) {
+    if (n == b + kB) {
+        const A s_last = o[kB - 1];
+        A zp = z;
+#pragma unroll
+        for (int m = 1; m < kB; ++m) {
+            if (m < kfold && m < n - 1)
+                o[kB - 1 - m] += zp * s_last;
+            zp *= z;
+        }
+    } else if (b + kB > n - kfold) {
         const A s_last = h0 * s_last_fn();      // s[n-1] = h0 * sum_k z^k x[n-1-k]
         A zp = 1;              // z^(n-1-i), built upwards from i = n-1
         for (int i = n - 1; i > b + kB - 1; --i)
@@ -400,7 +415,7 @@ __device__ __forceinline__ void fold_tails(A (&o)[kB], int b, int n, A z, A h0, 
         A zp = z;
 #pragma unroll
         for (int k = 1; k < kB; ++k) {
-            if (k < n - 1)
+            if (k < n - 1 && k < kfold)
                 o[k] += zp * s0;
             zp *= z;
         }
@@ -588,7 +603,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
             A o[kB];
             block_from_reader([&](int j) { return (A)col[j * C]; }, b, z, h0, o);
             if (tr)
-                fold_tails(o, b, n, z, h0, [&]() {
+                fold_tails(o, b, n, z, h0, p.fold, [&]() {
                     A yc = 0;
 #pragma unroll 8
                     for (int k = kK - 1; k >= 0; --k)
@@ -792,7 +807,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
                 block_from_reader([&](int j) { return (A)row[j]; }, b, z, h0, o);
             }
             if (tr)
-                fold_tails(o, b, n, z, h0, [&]() {
+                fold_tails(o, b, n, z, h0, p.fold, [&]() {
                     A yc = 0;
                     if (VEC) {      // vector reads here too: scalar ones are 8-way bank conflicted
 #pragma unroll 4
@@ -898,6 +913,17 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
     p.transpose = f.transpose;
     p.z = f.z;
     p.h0 = f.h0;
+    {
+        // |z|^fold < 1e-10 in float32 arithmetic (order 3: 18 terms; the first pole of order 5: 28), kK in double
+        int fold = kK;
+        if (sizeof(T) == 4 && f.z != 0.0) {
+            const double az = f.z < 0 ? -f.z : f.z;
+            double zp = 1.0;
+            for (fold = 0; fold < kK && zp >= 1e-10; ++fold)
+                zp *= az;
+        }
+        p.fold = fold;
+    }
     p.win = f.win;
     p.win_axis = f.win_axis;
     // persistent grid: two workgroups per CU for float32 (LDS and registers are budgeted for exactly
