@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--workload", choices=("cfg2", "cfg4", "cfg5"), default="cfg2")
     ap.add_argument("--collective", action="store_true",
                     help="cfg5, N > 1: the batch lives on rank 0 (broadcast grids, point-to-point scatter / gather)")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f16"), default="f32",
+                    help="cfg2 with 16-bit float STORAGE (float32 arithmetic; the reduced-precision opt-in): its own line")
     ap.add_argument("--batch", type=int, default=64, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help=argparse.SUPPRESS)      # profile collection: headline kernels only
@@ -241,6 +243,68 @@ def cfg4_main(args):
     print(json.dumps(res), flush=True)
 
 
+def storage16_main(args):
+    """cfg2 with the volume, the result, dY and dX stored as 16-bit floats (opt-in extension; the reference rejects
+    float16, deform.c:742-747).  Arithmetic stays float32: the first prefilter pass widens, K1's store narrows, K2's
+    load of dY widens, the last transposed prefilter pass narrows.  Timed next to the cast route (widen / narrow with
+    torch casts around the float32 pipeline), which is what the opt-in did until round 4."""
+    import importlib
+    import numpy as np
+    import torch
+    import elasticdeform_amd as ed
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    n = args.side or N_SIDE
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1)
+    X = torch.from_numpy(rng.random((n, n, n), dtype=np.float32)).to(dev).to(tdt)
+    dY = torch.from_numpy(rng.random((n, n, n), dtype=np.float32)).to(dev).to(tdt)
+    disp = torch.from_numpy(np.random.default_rng(22).standard_normal((3, 5, 5, 5)) * (5.0 * n / 256)).to(dev)
+    kw = dict(order=3, mode="mirror")
+    ed.set_reduced_precision(True)
+
+    def step():
+        ed.deform_grid(X, disp, **kw)
+        ed.deform_grid_gradient(dY, disp, **kw)
+
+    def run():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps * 1e3
+
+    ms = run()
+    real = dgm._direct16
+    try:
+        dgm._direct16 = lambda *a, **k: False
+        ms_cast = run()
+    finally:
+        dgm._direct16 = real
+    vox = float(n) ** 3
+    # bytes the step moves by design, per voxel: K3 (2 + 4) + 8 + 8, K1 4 + 2, K2 2 + 4, K4 8 + 8 + (4 + 2)
+    direct_b, cast_b = 56.0, 64.0 + 4 * 6.0
+    res = {"metric": "Mvoxels/s fwd+grad, 256^3 order=3, 16-bit storage", "value": round(vox / (ms * 1e-3) / 1e6, 2),
+           "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 arithmetic, %s storage" % args.dtype, "data": "synthetic",
+           "config": {"workload": "cfg2 with %s volumes: 3D %dx%dx%d, 5x5x5 grid sigma 5, order 3, mode mirror, prefilter on, "
+                                  "deform_grid + deform_grid_gradient per step (set_reduced_precision(True))"
+                                  % (args.dtype, n, n, n), "parallelism": "1 GPU"},
+           "roofline": {"bound": "hbm", "achieved": round(direct_b * vox / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(direct_b * vox / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                        "kernel": "whole step against the bytes it moves by design: 56 B/voxel (float32 intermediates "
+                                  "between the filter passes; the cast route moves 88)",
+                        "algorithmic_bytes_per_step": direct_b * vox},
+           "cast_route": {"ms_per_step": round(ms_cast, 4), "bytes_per_voxel": cast_b,
+                          "note": "the same step with torch casts around the float32 pipeline"},
+           "cpu_baseline": None}
+    print(json.dumps(res))
+
+
 def collective_main(args, rank, world, dev, distributed):
     """SURVEY.md 8(e), second leg: the whole cfg5 batch lives on rank 0; per step the grids are broadcast, the
     volumes scattered and the results gathered point to point (forward, then the same for the gradient)."""
@@ -328,6 +392,10 @@ def main():
     dgm = importlib.import_module("elasticdeform_amd.deform_grid")
     from elasticdeform_amd import _lib
 
+    if args.dtype != "f32":
+        if args.workload != "cfg2" or args.gpus != 1:
+            raise SystemExit("--dtype bf16 / f16: the cfg2 workload on one GPU")
+        return storage16_main(args)
     if args.workload == "cfg4":
         if rank == 0:
             cfg4_main(args)

@@ -18,6 +18,7 @@ MAX_AXES = 7
 FLAG_AUTO, FLAG_EXACT, FLAG_FAST = 0, 1, 2
 FLAG_RAW_DISPLACEMENT = 4      # edhip_deform prefilters the control grid itself (<= 4096 points)
 FLAG_GRID_STAYS = 64           # with RAW_DISPLACEMENT: the raw grid of the previous RAW call on the stream, unchanged
+FLAG_SCRATCH_INPUT = 128       # edhip_spline_filter_axes: in place on the input, the last pass input -> output
 ERR_UNSUPPORTED = 5             # EDHIP_ERR_UNSUPPORTED: legal, outside this build's limits (nothing was launched)
 FLAG_KEEP_BOXES = 8            # forward: leave the tiles' bounding boxes for the gradient call that follows
 FLAG_USE_BOXES = 16            # gradient: same displacement contents and geometry as that forward call
@@ -200,10 +201,11 @@ def _buf():
 
 
 def deform(gradient, in_descs, disp_desc, output_offset, out_descs, axis, orders, modes, cvals,
-           inverse_affine, flags, stream, prepared=None):
+           inverse_affine, flags, stream, prepared=None, may_decline=False):
     """edhip_deform -- argument for argument `_deform_grid.deform_grid(_grad)` of the reference
     (_deform_grid.c:108-118) with descriptors in place of arrays, plus flags and the HIP stream.
-    `prepared`: a DeformArgs built earlier from the same parameter arrays."""
+    `prepared`: a DeformArgs built earlier from the same parameter arrays.  `may_decline`: return
+    EDHIP_ERR_UNSUPPORTED (nothing launched) instead of raising; otherwise returns 0."""
     L = load()
     n = len(in_descs)
     a = prepared if prepared is not None else DeformArgs(n, axis, orders, modes, cvals, output_offset,
@@ -213,8 +215,9 @@ def deform(gradient, in_descs, disp_desc, output_offset, out_descs, axis, orders
     buf = _buf()
     status = L.edhip_deform(1 if gradient else 0, n, ins, ctypes.byref(disp_desc), a.off, outs, a.naxis,
                             a.axis, a.orders, a.modes, a.cvals, a.aff, int(flags), stream, buf, 256)
-    if status:
+    if status and not (may_decline and status == ERR_UNSUPPORTED):
         raise_for_status(status, buf)
+    return status
 
 
 def deform_batch(gradient, in_descs, disp_descs, output_offset, out_descs, axis, order, mode, cval,
@@ -338,16 +341,18 @@ def spline_filter1d(in_desc, out_desc, axis, order, transpose, flags, stream):
         raise_for_status(status, buf)
 
 
-def spline_filter_axes(in_desc, out_desc, axes, order, transpose, flags, stream):
-    """edhip_spline_filter_axes: the whole chain (first pass in -> out, the rest in place) in one call"""
+def spline_filter_axes(in_desc, out_desc, axes, order, transpose, flags, stream, may_decline=False):
+    """edhip_spline_filter_axes: the whole chain (first pass in -> out, the rest in place) in one call.
+    `may_decline`: return EDHIP_ERR_UNSUPPORTED (nothing launched) instead of raising; otherwise returns 0."""
     L = load()
     n = len(axes)
     buf = _buf()
     status = L.edhip_spline_filter_axes(ctypes.byref(in_desc), ctypes.byref(out_desc), n,
                                         (ctypes.c_int32 * n)(*axes), int(order), int(bool(transpose)),
                                         int(flags), stream, buf, 256)
-    if status:
+    if status and not (may_decline and status == ERR_UNSUPPORTED):
         raise_for_status(status, buf)
+    return status
 
 
 def release_scratch():

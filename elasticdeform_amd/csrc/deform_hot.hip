@@ -90,6 +90,18 @@ __device__ __forceinline__ void box_reduce_to_lds(int* red, int lane, int (&lo)[
 }
 #undef ED_RED6
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// the output side of a call with 16-bit float storage (HotGeom::io16; element offsets count 16-bit elements)
+__device__ __forceinline__ void store_out(float* img, long long off, float val, int io16)
+{
+    if (io16)
+        __builtin_nontemporal_store((unsigned short)narrow16(val, io16), reinterpret_cast<unsigned short*>(img) + off);
+    else
+        __builtin_nontemporal_store(val, img + off);
+}
+__device__ __forceinline__ float load_dy(const float* dy, long long off, int io16)
+{
+    return io16 ? widen16(reinterpret_cast<const unsigned short*>(dy)[off], io16) : dy[off];
+}
 __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 // (int)floor(x + 0.5) in one instruction; __float2int_rn is v_rndne_f32 + v_cvt_i32_f32 (64 more VALU
 // instructions per voxel in the scatter).  Ties go up instead of to even: exact halves of a
@@ -351,7 +363,7 @@ __device__ __forceinline__ void hot_tile_coords(const HotGeom& hg, const HotPara
 // the bits every other level gives.  Not inlined: called where nothing of the tile loop is live any more
 // (inlined into the loop an earlier form cost K1 its register allocation, profiles/r03_bench_misc.txt).
 template <int ORDER, bool AFFINE>
-__device__ __forceinline__ void hot_fwd_unfit(const HotGeom& hg, const HotStrip& sp, char* smem, unsigned unfit)
+__device__ __forceinline__ void hot_fwd_unfit(const HotGeom& hg, const HotStrip& sp, char* smem, unsigned unfit, int io16)
 {
     constexpr int NT = ORDER + 1;
     const AxTab* tabx = reinterpret_cast<const AxTab*>(smem + kOffTabX);
@@ -426,7 +438,7 @@ __device__ __forceinline__ void hot_fwd_unfit(const HotGeom& hg, const HotStrip&
                     }
                     val = a0;
                 }
-                __builtin_nontemporal_store(val, img + (img_off + obase));
+                store_out(img, img_off + obase, val, io16);
             }
         }
     }
@@ -439,9 +451,12 @@ __device__ __forceinline__ void hot_fwd_unfit(const HotGeom& hg, const HotStrip&
 // Tile loop, software-pipelined: once the box of tile t is known its staging copies are issued as
 // asynchronous LDS-DMA, and the coordinates + bounding box of tile t + 1 are computed while they are
 // in flight; the gather of tile t follows the barrier that retires the copies.
-template <int ORDER, bool AFFINE, int ABL = 0, int NTH = kBlock, int WAVES = ((ABL & 2048) ? 5 : 4), bool REC_ONLY = false>
+// IO16: the output is stored as 16-bit floats (HotGeom::io16 says which); instantiated for orders 1-3 only
+template <int ORDER, bool AFFINE, int ABL = 0, int NTH = kBlock, int WAVES = ((ABL & 2048) ? 5 : 4), bool REC_ONLY = false,
+          bool IO16 = false>
 __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
 {
+    const int io16 = IO16 ? hg.io16 : 0;
     // NTH = 256: two voxels per lane (z = wave, wave + 4); NTH = 512: one voxel per lane, eight waves
     constexpr int NV = 512 / NTH;
     constexpr int NW = NTH / 64;
@@ -683,10 +698,12 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
                 const int plane = by * pitch;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    if (!valid[i])
+                    if (!IO16 && !valid[i])
                         continue;
-                    float val;
-                    if (constant[i]) {
+                    float val = 0.f;
+                    if (IO16 && !valid[i]) {
+                        ;
+                    } else if (constant[i]) {
                         val = hg.cval;
                     } else if (ABL & 2) {
                         val = frac[i][0] + frac[i][1] + frac[i][2] + (float)start[i][0] + (float)start[i][1] + (float)start[i][2];
@@ -704,8 +721,14 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
                                           : hot_gather<ORDER, 48>(bp, plane, w0, w1, w2);
                     }
                     // streaming store (a tile writes 32-byte row segments; see deform_tile.hip)
-                    if (!(ABL & 64) || val == -12345.678f)
-                        __builtin_nontemporal_store(val, img + (img_off + obase[i] + ti * kT));
+                    if constexpr (IO16) {
+                        // (cached 2-byte stores: a tile writes 16-byte row segments, half a 32-byte sector -- streamed
+                        // past the L2 they cost K1 17 us on the 256^3 benchmark; pairing x-neighbours' lanes into
+                        // 32-bit stores cost 12 spilled registers and more: 254 us against 248)
+                        if (valid[i])
+                            reinterpret_cast<unsigned short*>(img)[img_off + obase[i] + ti * kT] = (unsigned short)narrow16(val, io16);
+                    } else if (!(ABL & 64) || val == -12345.678f)
+                        store_out(img, img_off + obase[i] + ti * kT, val, io16);
                 }
             }
         }
@@ -723,7 +746,7 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
         }
     }
     if (!REC_ONLY && unfit)
-        hot_fwd_unfit<ORDER, AFFINE>(hg, sp, smem, unfit);
+        hot_fwd_unfit<ORDER, AFFINE>(hg, sp, smem, unfit, io16);
 }
 
 // ================================================================================================
@@ -731,9 +754,11 @@ __global__ __launch_bounds__(NTH, WAVES) void hot_fwd_kernel(const HotGeom hg)
 // into fixed-point LDS cells with integer atomics and flushed with one float atomic per touched
 // source element (see deform_tile.hip for the scale's no-overflow bound).
 // ================================================================================================
-template <int ORDER, bool AFFINE, int GRAD_WAVES, int TX, int NGRP = 1>
+// IO16: dY is stored as 16-bit floats (HotGeom::io16 says which); instantiated for orders 1-3 only
+template <int ORDER, bool AFFINE, int GRAD_WAVES, int TX, int NGRP = 1, bool IO16 = false>
 __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(const HotGeom hg)
 {
+    const int io16 = IO16 ? hg.io16 : 0;
     constexpr int NT = ORDER + 1;
     constexpr int NV = TX / 4, ZSTEP = 8 / NV;       // TX 16: 4 voxels per lane; TX 8: 2
     extern __shared__ __attribute__((aligned(16))) char smem0[];
@@ -782,14 +807,21 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
     const bool vy = oy < hg.out_len[1];
 
     // dY of a tile's first step is loaded one tile ahead: with the forward call's boxes there is no
-    // box pass left to hide its HBM round trip under
+    // box pass left to hide its HBM round trip under.  (IO16: the 16 raw bits travel in the register and are widened
+    // where the value is used -- a conversion at the load would wait for it right there.)
+    auto load_raw = [&](long long off) -> float {
+        if constexpr (IO16)
+            return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(dy)[off]);
+        else
+            return dy[off];
+    };
     float gnext[NV];
     {
         const int ox = sp.tx0 * kT + xx;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             gnext[i] = (vy && ox < hg.out_len[2] && oz0 + ZSTEP * i < hg.out_len[0])
-                           ? dy[(oz0 + ZSTEP * i) * hg.img_sz + oy * hg.img_sy + ox] : 0.f;
+                           ? load_raw((oz0 + ZSTEP * i) * hg.img_sz + oy * hg.img_sy + ox) : 0.f;
     }
     // half: -1 = the whole TX-wide tile; 0 / 1 = an oversize tile taken again as its x-halves (below)
     int half = -1, half_next = -1;
@@ -805,7 +837,7 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
             // (the tile's dY again: gnext already holds the next tile's)
 #pragma unroll
             for (int i = 0; i < NV; ++i)
-                gpre[i] = (vy && vx && oz0 + ZSTEP * i < hg.out_len[0]) ? dy[ooff0 + i * ostep] : 0.f;
+                gpre[i] = (vy && vx && oz0 + ZSTEP * i < hg.out_len[0]) ? load_raw(ooff0 + i * ostep) : 0.f;
         } else {
 #pragma unroll
             for (int i = 0; i < NV; ++i)
@@ -815,7 +847,7 @@ __global__ __launch_bounds__(kBlock * NGRP, GRAD_WAVES) void hot_grad_kernel(con
             const bool nvx = ox + TX < hg.out_len[2];
 #pragma unroll
             for (int i = 0; i < NV; ++i)
-                gnext[i] = (vy && nvx && oz0 + ZSTEP * i < hg.out_len[0]) ? dy[ooff0 + TX + i * ostep] : 0.f;
+                gnext[i] = (vy && nvx && oz0 + ZSTEP * i < hg.out_len[0]) ? load_raw(ooff0 + TX + i * ostep) : 0.f;
         }
         // the forward call's boxes (EDHIP_FLAG_USE_BOXES): requested here, ahead of the barrier
         const bool given = hg.use_boxes != 0;
@@ -907,7 +939,7 @@ ED_UNROLL(ED_K2_U1)
             float gm = 0.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                gval[i] = gpre[i];
+                gval[i] = IO16 ? widen16(__float_as_uint(gpre[i]), io16) : gpre[i];
                 // inf / NaN gradients have no fixed-point scale: left out of the sum, scattered with
                 // float atomics below
                 gm += (__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(gval[i]);
@@ -995,7 +1027,7 @@ ED_UNROLL(ED_K2_U1)
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     const bool inb = vy && vx && oz0 + ZSTEP * i < hg.out_len[0];
-                    gval[i] = inb ? dy[img_off + ooff0 + i * ostep] : 0.f;
+                    gval[i] = inb ? load_dy(dy, img_off + ooff0 + i * ostep, io16) : 0.f;
                     gm += (__float_as_int(gval[i]) & 0x7f800000) == 0x7f800000 ? 0.f : fabsf(gval[i]);
                 }
                 gm = wave_sum(gm);
@@ -1709,11 +1741,31 @@ hipError_t launch_order(const HotGeom& hg, bool gradient, unsigned nblk, size_t 
             return hipGetLastError();
         }
 #endif
+        if (hg.io16) {
+            if constexpr (ORDER <= 3) {
+                if (hg.has_affine)
+                    hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 4, 16, 1, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+                else
+                    hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4, 16, 1, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+                return hipGetLastError();
+            }
+            return hipErrorNotSupported;
+        }
         if (hg.has_affine)
             hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
         else
             hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
     } else {
+        if (hg.io16) {
+            if constexpr (ORDER <= 3) {
+                if (hg.has_affine)
+                    hipLaunchKernelGGL((hot_fwd_kernel<ORDER, true, 0, kBlock, 4, false, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+                else
+                    hipLaunchKernelGGL((hot_fwd_kernel<ORDER, false, 0, kBlock, 4, false, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
+                return hipGetLastError();
+            }
+            return hipErrorNotSupported;
+        }
 #ifdef EDHIP_EXPERIMENTS
         // profiling builds of the forward kernel (see hot_fwd_kernel's ABL switches)
         if (!hg.has_affine && ORDER == 3 && ed_env("EDHIP_HOT_ABL")) {
@@ -1753,6 +1805,11 @@ hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(kBlock), lds, stream, hg);
         return hipGetLastError();
     };
+#ifndef EDHIP_EXPERIMENTS
+    (void)go;
+    (void)order;
+    return hipErrorNotSupported;      // (the records route is measured in the profiling build only, deform_tile.hip)
+#else
     switch (order * 2 + (hg.has_affine ? 1 : 0)) {
     case 2: return go(hot_fwd_kernel<1, false, 0, kBlock, 4, true>);
     case 3: return go(hot_fwd_kernel<1, true, 0, kBlock, 4, true>);
@@ -1762,6 +1819,7 @@ hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_
     case 7: return go(hot_fwd_kernel<3, true, 0, kBlock, 4, true>);
     default: return hipErrorNotSupported;
     }
+#endif
 }
 
 // K2 from records: LDS = parameters | sums | counters | two work lists | cells
@@ -1782,6 +1840,9 @@ hipError_t launch_hot_grad2(const HotGeom& hg, int order, unsigned nblk, size_t 
         return hipGetLastError();
     }
 #endif
+#ifndef EDHIP_EXPERIMENTS
+    return hipErrorNotSupported;      // (profiling build only, like the records it reads)
+#else
     switch (order) {
     case 1: hipLaunchKernelGGL((hot_grad2_kernel<1, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
     case 2: hipLaunchKernelGGL((hot_grad2_kernel<2, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg); break;
@@ -1789,6 +1850,7 @@ hipError_t launch_hot_grad2(const HotGeom& hg, int order, unsigned nblk, size_t 
     default: return hipErrorNotSupported;
     }
     return hipGetLastError();
+#endif
 }
 
 // LDS: x table | reduction slots | wave sums | parameters | 64 Q rows | box.  Returns 0 when the

@@ -1208,6 +1208,14 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // launch still has a few workgroups per CU (even lengths for the gradient: its kernel walks 16-wide
     // tiles; the forward kernels go down to one tile per workgroup -- a tile is a serial chain of
     // coordinates, box reduction, staging and gather, ~8 us, and a 32^3 volume has 64 of them)
+    if (v.out16) {
+        // 16-bit output side: the level-1 kernels of deform_hot.hip (orders 1-3) in self-serve form, or nothing
+        if constexpr (!(std::is_same<T, float>::value && ORDER >= 1 && ORDER <= 3))
+            return hipErrorNotSupported;
+        if (nb != 1 || tg.in_stride[2] != 1 || tg.out_stride[2] != 1 || ed_env("EDHIP_NO_HOT") || ed_env("EDHIP_WAVE") ||
+            ed_env("EDHIP_RECORDS"))
+            return hipErrorNotSupported;
+    }
     tg.strip_tiles = kStrip;
     while (tg.strip_tiles > (GRAD ? 2 : 1) &&
            (int64_t)nb * tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles) < 1024)
@@ -1471,6 +1479,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 hg.has_affine = tg.has_affine;
                 hg.dbg = tg.dbg;
                 hg.self_serve = (self_serve && ORDER <= 3) ? 1 : 0;      // (orders 4 / 5: the one-wave kernels, which spill as before)
+                hg.io16 = v.out16;
+                if (v.out16)
+                    hg.self_serve = 1;          // (the spill levels do not know about 16-bit storage)
                 hg.cval = (float)ve.cval;
                 hg.nstep = ve.nstep;
                 hg.nsteps = ve.nsteps;
@@ -1491,6 +1502,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box, false);
                     hg.hint = sh ? tg.hint : nullptr;
                 }
+                if (v.out16 && !hlds)
+                    return hipErrorNotSupported;        // (nothing has been launched yet)
                 hg.lds_grp = (int)((hlds + 15) & ~(size_t)15);
                 // EDHIP_FLAG_KEEP_BOXES / USE_BOXES: the forward kernel's tile boxes -- and, orders 1-3, its
                 // per-voxel coordinate records -- live in a buffer of their own (nothing else writes it) under
@@ -1692,7 +1705,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         served_all = hg.self_serve != 0;
                         if (!GRAD && hg.boxes && key)
                             *key = cur;
-                    } else if (he != hipErrorNotSupported)
+                    } else if (he != hipErrorNotSupported || v.out16)
                         e = he;
                 }
 

@@ -309,6 +309,25 @@ __device__ __forceinline__ double control_coordinate(int64_t ncp, int64_t o_plus
 
 }  // namespace ed
 
+// 16-bit float storage next to float32 arithmetic (EDHIP_F16 / EDHIP_BF16 on one side of a float32 pass):
+// kind 1 = IEEE half, 2 = bfloat16; widening is exact, narrowing rounds to nearest even (what a torch cast does)
+__device__ __forceinline__ float widen16(unsigned bits, int kind)
+{
+    return kind == 2 ? __uint_as_float(bits << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)bits);
+}
+__device__ __forceinline__ unsigned narrow16(float x, int kind)
+{
+    if (kind == 2) {
+        unsigned u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u)
+            return (u >> 16) | 0x40u;                 // NaN stays NaN (quiet)
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    }
+    return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x);
+}
+
+
 // Experiment switches of the kernels (EDHIP_TILE_DBG bits, timestamp buffers): live in the profiling build
 // (make EXPERIMENTS=1) only -- in the shipped library the tests below are the constant `false` and the code
 // behind them is not compiled in.

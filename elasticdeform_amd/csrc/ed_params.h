@@ -42,6 +42,11 @@ struct IOView {
     int64_t step_len[kMaxSteps];
     int64_t in_step_stride[kMaxSteps];
     int64_t out_step_stride[kMaxSteps];
+    // 16-bit float storage on the OUTPUT side of a float32 call (forward: the result is narrowed at the store;
+    // gradient: dY is widened at the load): 1 half, 2 bfloat16.  out_dtype then reads EDHIP_F32 and every output
+    // stride is twice its byte value, so that "stride / sizeof(float)" counts 16-bit elements.  Only the level-1
+    // kernels of deform_hot.hip know about it (launch_tile declines every other route).
+    int out16;
 };
 
 // launchers (defined in the .hip files, called from edhip_api.cpp); all enqueue on `stream` and

@@ -406,6 +406,7 @@ struct HotGeom {
     // benchmark step 36 us for 2 tiles of 32768 -- and level 1 serves a tile whose box does not fit itself,
     // straight from / to global memory
     int self_serve;
+    int io16;                     // IOView::out16: the output side (img_r / img_w) holds 16-bit floats
     float4* rec;
     long long rec_bstride;
     int rec_only;

@@ -357,12 +357,27 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         const edhip_array& in = inputs[i];
         const edhip_array& out = outputs[i];
         IOView v;
+        // float32 volume, 16-bit float on the output side (forward: narrowed at the store; gradient: dY widened at
+        // the load), asked for with EDHIP_FLAG_FAST: the level-1 tile kernels take it, or nobody (EDHIP_ERR_UNSUPPORTED,
+        // nothing launched; without the flag the exact kernels take the pair like any other).  The view pretends float32 with doubled output strides (IOView::out16).
+        const int out16 = ((flags & EDHIP_FLAG_FAST) && !(flags & EDHIP_FLAG_EXACT) && in.dtype == EDHIP_F32)
+                              ? (out.dtype == EDHIP_F16 ? 1 : (out.dtype == EDHIP_BF16 ? 2 : 0)) : 0;
         {
-            const int st = make_view(in, out, naxis, axis + i * naxis, orders[i], modes[i], cvals[i], v, err,
-                                     errlen);
+            edhip_array out32 = out;
+            if (out16) {
+                out32.dtype = EDHIP_F32;
+                for (int d = 0; d < out.ndim; ++d)
+                    out32.stride_bytes[d] = out.stride_bytes[d] * 2;
+            }
+            const int st = make_view(in, out16 ? out32 : out, naxis, axis + i * naxis, orders[i], modes[i], cvals[i], v,
+                                     err, errlen);
             if (st != EDHIP_OK)
                 return st;
+            v.out16 = out16;
         }
+        if (out16 && (v.nsteps <= 0 || ((uintptr_t)out.data & 3) || !deform_fast_supported(g, v, gradient) ||
+                      !deform_tile_supported(g, v, gradient != 0)))
+            return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "16-bit output next to a float32 volume: outside the tile kernels");
         if (v.nsteps <= 0) {
             if (zero && clear_now(i) != hipSuccess)
                 return fail(err, errlen, EDHIP_ERR_DEVICE, "clearing the gradient arrays failed");
@@ -417,6 +432,10 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
                 }
             }
             e = ce == hipSuccess ? launch_deform_tile(g, v, gradient != 0, stream, &one) : ce;
+            if (out16 && e == hipErrorNotSupported) {
+                (void)hipGetLastError();
+                return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "16-bit output next to a float32 volume: outside the level-1 tile kernels");
+            }
             // (a tile path that declined the call -- or served it on a route without the tables' fill -- has
             // not touched the block: cleared now, and whoever takes the call next finds it cleared)
             // (zero_done unset behind an aligned block: the tables launch -- which precedes every scatter of the
@@ -709,8 +728,10 @@ static int filter1d_impl(const edhip_array* input, const edhip_array* output, in
 
     // fast path for float32 / float64 unless the caller asks for the exact one; same operator, no
     // scratch, ~1e-16 relative to the sequential recursion (see spline_fast.hip)
+    // (16-bit float storage on one side of a float32 pass: the whole-line tile kernels widen / narrow it on the way)
+    const bool half_in = (input->dtype == EDHIP_F16 || input->dtype == EDHIP_BF16) && output->dtype == EDHIP_F32;
     const bool want_fast = !(flags & EDHIP_FLAG_EXACT) &&
-                           (input->dtype == EDHIP_F32 || input->dtype == EDHIP_F64);
+                           (input->dtype == EDHIP_F32 || input->dtype == EDHIP_F64 || half_in);
     if (want_fast && p.npoles >= 1) {
         const hipError_t e = launch_spline_filter_fast(p, order, input->ndim, axis, input->shape,
                                                        input->stride_bytes, output->stride_bytes,
@@ -723,6 +744,11 @@ static int filter1d_impl(const edhip_array* input, const edhip_array* output, in
     }
     if (window || dry)
         return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "windowed prefilter: outside the whole-line tile kernels");
+    // a float32 pass with 16-bit float storage on one side, asked for with EDHIP_FLAG_FAST: the tile kernels or nobody
+    // (without the flag the exact kernel takes the pair like any other)
+    const bool half_out = input->dtype == EDHIP_F32 && (output->dtype == EDHIP_F16 || output->dtype == EDHIP_BF16);
+    if ((half_in || half_out) && (flags & EDHIP_FLAG_FAST) && !(flags & EDHIP_FLAG_EXACT))
+        return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "16-bit storage next to a float32 pass: outside the whole-line tile kernels");
 
     const bool need_ws = p.npoles > 0 && p.len >= 2;
     if (need_ws) {
@@ -854,10 +880,22 @@ int edhip_spline_filter_axes(const edhip_array* input, const edhip_array* output
     if (naxes < 0 || (naxes > 0 && !axes))
         return fail(err, errlen, EDHIP_ERR_INVALID, "invalid axis list");
     ed::StreamGuard guard((hipStream_t)hip_stream);
+    const bool scratch_in = (flags & EDHIP_FLAG_SCRATCH_INPUT) && naxes > 1;
+    if (naxes > 0 && input && output && input->dtype != output->dtype && (flags & EDHIP_FLAG_FAST) &&
+        !(flags & EDHIP_FLAG_EXACT)) {
+        // the one pass that converts (first of a widening chain, last of a narrowing one): can the tile kernels take
+        // it?  Decided before anything is launched.
+        const int i = (flags & EDHIP_FLAG_SCRATCH_INPUT) ? naxes - 1 : 0;
+        const int st = filter1d_impl(input, output, axes[i], order, transpose, flags, hip_stream, nullptr, true, err, errlen);
+        if (st != EDHIP_OK)
+            return st;
+    }
     for (int i = 0; i < naxes; ++i) {
-        // the reference's loop (deform_grid.py:157-162, :279-284): input -> output, then in place
-        const int st = edhip_spline_filter1d(i == 0 ? input : output, output, axes[i], order, transpose, flags,
-                                             hip_stream, err, errlen);
+        // the reference's loop (deform_grid.py:157-162, :279-284): input -> output, then in place;
+        // EDHIP_FLAG_SCRATCH_INPUT: in place on the input, the last pass input -> output
+        const edhip_array* src = scratch_in ? input : (i == 0 ? input : output);
+        const edhip_array* dst = scratch_in ? (i == naxes - 1 ? output : input) : output;
+        const int st = edhip_spline_filter1d(src, dst, axes[i], order, transpose, flags, hip_stream, err, errlen);
         if (st != EDHIP_OK)
             return st;
     }

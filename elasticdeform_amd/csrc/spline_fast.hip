@@ -67,6 +67,7 @@ struct FastFilter {
     int win_axis;
     int win_outer[EDHIP_MAX_DIMS];
     int dry;                 // 1: every check, no launch (can the whole-line tile kernels take this pass?)
+    int in16, out16;         // 16-bit float storage on one side of a float32 pass (1 half, 2 bfloat16; ed_device.h)
 };
 
 __device__ __forceinline__ void line_offsets(const FastFilter& p, int64_t line, int64_t& in_off,
@@ -265,6 +266,7 @@ struct LineTile {
     int64_t ntiles;
     int transpose;
     int fold;                    // transpose: folded tail terms kept (fold_tails)
+    int in16, out16;             // see FastFilter
     unsigned long long* trace;   // profiling only (EDHIP_FILTER_TRACE): phase timestamps of workgroup 0
     double z, h0;
     // device-side window (edhip_spline_filter_axes_window): (w0, w1) per array dimension in device memory; the
@@ -482,9 +484,11 @@ __device__ __forceinline__ void lds_barrier()
 // ---- strided axis ----------------------------------------------------------------------------------
 // Persistent workgroups; with VEC the next tile's rows are already in flight (in registers) while
 // the current tile is filtered and stored.
-template <typename T, int C, bool VEC>
+// IN16: the input is stored as 16-bit floats (p.in16) and widened on its way into the tile (VEC only)
+template <typename T, int C, bool VEC, bool IN16 = false>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_strided_kernel(const LineTile p)
 {
+    static_assert(!IN16 || (VEC && sizeof(T) == 4), "16-bit input: float32 arithmetic, vector loads");
     const TileGeo geo = tile_geometry<C>(p);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* tile = reinterpret_cast<T*>(smem) + kK * C;     // [kK | n32 | kK][C]: sample j at row j
@@ -499,7 +503,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
     const bool tr = p.transpose != 0;
     typedef typename TileArith<T>::type A;
     const A z = (A)p.z, h0 = (A)p.h0;
-    const T* in_base = reinterpret_cast<const T*>(p.in) + geo.in_off;
+    const T* in_base = reinterpret_cast<const T*>(p.in) + (IN16 ? 0 : geo.in_off);
+    const unsigned short* in16_base = reinterpret_cast<const unsigned short*>(p.in) + geo.in_off;
     T* out_base = reinterpret_cast<T*>(p.out) + geo.out_off;
 
     struct Where {
@@ -516,15 +521,25 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
         w.out_off += col0;
         return w;
     };
-    V v[NPF];
+    typedef typename std::conditional<IN16, uint2, V>::type VL;     // what a thread keeps in flight per row
+    VL v[NPF];
     // (unconditional loads from clamped addresses: a predicated load sits in its own basic block
     // and the compiler then drains vmcnt before each one, serialising the whole prefetch)
     auto issue = [&](const Where& w) {
-        const T* src = in_base + w.in_off + (ch * VN < w.ncols ? ch * VN : 0);   // ncols % VN == 0 (host)
+        if constexpr (IN16) {
+            const unsigned short* src = in16_base + w.in_off + (ch * VN < w.ncols ? ch * VN : 0);
 #pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            const int r = u * RP + r0;
-            v[u] = *reinterpret_cast<const V*>(src + (int64_t)(r < n ? r : n - 1) * p.in_axis_stride);
+            for (int u = 0; u < NPF; ++u) {
+                const int r = u * RP + r0;
+                v[u] = *reinterpret_cast<const uint2*>(src + (int64_t)(r < n ? r : n - 1) * p.in_axis_stride);
+            }
+        } else {
+            const T* src = in_base + w.in_off + (ch * VN < w.ncols ? ch * VN : 0);   // ncols % VN == 0 (host)
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int r = u * RP + r0;
+                v[u] = *reinterpret_cast<const V*>(src + (int64_t)(r < n ? r : n - 1) * p.in_axis_stride);
+            }
         }
     };
 
@@ -539,8 +554,18 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
                 const int r = u * RP + r0;
-                if (r < n)
-                    *reinterpret_cast<V*>(tile + r * C + ch * VN) = v[u];
+                if constexpr (IN16) {
+                    V x;
+                    x[0] = widen16(v[u].x & 0xffffu, p.in16);
+                    x[1] = widen16(v[u].x >> 16, p.in16);
+                    x[2] = widen16(v[u].y & 0xffffu, p.in16);
+                    x[3] = widen16(v[u].y >> 16, p.in16);
+                    if (r < n)
+                        *reinterpret_cast<V*>(tile + r * C + ch * VN) = x;
+                } else {
+                    if (r < n)
+                        *reinterpret_cast<V*>(tile + r * C + ch * VN) = v[u];
+                }
             }
         } else {
             constexpr int RS = kBlock / C;
@@ -633,9 +658,11 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
 }
 
 // ---- contiguous axis -------------------------------------------------------------------------------
-template <typename T, bool VEC>
+// OUT16: the output is stored as 16-bit floats (p.out16), narrowed on its way out of the tile (VEC only)
+template <typename T, bool VEC, bool OUT16 = false>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile_contig_kernel(const LineTile p)
 {
+    static_assert(!OUT16 || (VEC && sizeof(T) == 4), "16-bit output: float32 arithmetic, vector stores");
     const TileGeo geo = tile_geometry<0>(p);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename VecOf<T>::type V;
@@ -856,8 +883,17 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void prefilter_tile
                 const int ic = idx < total ? idx : total - 1;
                 const int rr = (int)(((float)ic + 0.5f) * inv_nc), ch = ic - rr * nc;
                 const W x = *reinterpret_cast<const W*>(tile + rr * pitch + kK + ch * VN);
-                if (idx < total && rr < nl)
-                    *reinterpret_cast<W*>(out_base + row_off[par * 64 + 32 + rr] + ch * VN) = x;
+                if constexpr (OUT16) {
+                    uint2 pk;
+                    pk.x = narrow16(x[0], p.out16) | (narrow16(x[1], p.out16) << 16);
+                    pk.y = narrow16(x[2], p.out16) | (narrow16(x[3], p.out16) << 16);
+                    if (idx < total && rr < nl)
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + geo.out_off +
+                                                  row_off[par * 64 + 32 + rr] + ch * VN) = pk;
+                } else {
+                    if (idx < total && rr < nl)
+                        *reinterpret_cast<W*>(out_base + row_off[par * 64 + 32 + rr] + ch * VN) = x;
+                }
             }
         }
         if (!has_next)
@@ -926,6 +962,8 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
     }
     p.win = f.win;
     p.win_axis = f.win_axis;
+    p.in16 = f.in16;
+    p.out16 = f.out16;
     // persistent grid: two workgroups per CU for float32 (LDS and registers are budgeted for exactly
     // that), one for float64 (its fp64 state does not fit 256 registers next to the prefetch)
     int dev = 0, ncu = 256;
@@ -937,6 +975,7 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
         wgs_per_cu = atoi(w) > 0 ? atoi(w) : wgs_per_cu;
     const int64_t resident = (int64_t)ncu * wgs_per_cu;
     const bool aligned16 = ((uintptr_t)f.in % 16 == 0) && ((uintptr_t)f.out % 16 == 0);
+    [[maybe_unused]] const bool mixed = f.in16 || f.out16;      // served by one kernel each (float32 only), or not at all
     auto strides_vec = [&](int skip) {
         for (int d = 0; d < f.nouter; ++d)
             if (d != skip && (f.in_outer_stride[d] % VN || f.out_outer_stride[d] % VN))
@@ -968,8 +1007,20 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
         const int64_t nblk = p.ntiles < resident ? p.ntiles : resident;
         if (lds > kTileLdsBudget)
             return hipErrorNotSupported;
+        if (mixed && (f.in16 || !vec || sizeof(T) != 4))
+            return hipErrorNotSupported;      // (16-bit storage: the strided kernel reads it, this one writes it)
         if (f.dry)
             return hipSuccess;
+        if constexpr (sizeof(T) == 4) {
+            if (f.out16) {
+                const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, true, true>, kTileLdsBudget);
+                if (attr != hipSuccess)
+                    return hipErrorNotSupported;
+                hipLaunchKernelGGL((prefilter_tile_contig_kernel<T, true, true>), dim3((unsigned)nblk), dim3(kBlock),
+                                   lds, stream, p);
+                return hipGetLastError();
+            }
+        }
         if (vec) {
             const hipError_t attr = allow_large_lds(prefilter_tile_contig_kernel<T, true>, kTileLdsBudget);
             if (attr != hipSuccess)
@@ -1036,8 +1087,20 @@ hipError_t launch_line_tiles(const FastFilter& f, hipStream_t stream)
     const bool vec = aligned16 && p.ncol % VN == 0 && strides_vec(cax) &&
                      f.in_axis_stride % VN == 0 && f.out_axis_stride % VN == 0;
     const size_t lds = tile_rows * C * sizeof(T);
+    if (mixed && (f.out16 || !vec || C != CW || sizeof(T) != 4))
+        return hipErrorNotSupported;
     if (f.dry)
         return hipSuccess;
+    if constexpr (sizeof(T) == 4) {
+        if (f.in16) {
+            const hipError_t attr = allow_large_lds(prefilter_tile_strided_kernel<T, CW, true, true>, kTileLdsBudget);
+            if (attr != hipSuccess)
+                return hipErrorNotSupported;
+            hipLaunchKernelGGL((prefilter_tile_strided_kernel<T, CW, true, true>), dim3((unsigned)nblk), dim3(kBlock),
+                               lds, stream, p);
+            return hipGetLastError();
+        }
+    }
 #define EDHIP_TILE_STRIDED(CC, VV)                                                                   \
     do {                                                                                             \
         const hipError_t attr =                                                                      \
@@ -1074,7 +1137,15 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
     // a device-side window is served by the whole-line tile kernels only (one pole: orders 2 / 3)
     if (window && (order >= 4 || ed_env("EDHIP_NO_LINE_TILES")))
         return hipErrorNotSupported;
-    if (fp.in_dtype != fp.out_dtype || (fp.in_dtype != EDHIP_F32 && fp.in_dtype != EDHIP_F64))
+    // 16-bit float storage on ONE side of a float32 pass (orders 2 / 3, whole-line tile kernels only): the first pass
+    // of a forward chain widens, the last pass of a chain narrows
+    auto kind16 = [](int dt) { return dt == EDHIP_F16 ? 1 : (dt == EDHIP_BF16 ? 2 : 0); };
+    const int in16 = fp.out_dtype == EDHIP_F32 ? kind16(fp.in_dtype) : 0;
+    const int out16 = fp.in_dtype == EDHIP_F32 ? kind16(fp.out_dtype) : 0;
+    const bool mixed = in16 || out16;
+    if (mixed && (order >= 4 || ed_env("EDHIP_NO_LINE_TILES")))
+        return hipErrorNotSupported;
+    if (!mixed && (fp.in_dtype != fp.out_dtype || (fp.in_dtype != EDHIP_F32 && fp.in_dtype != EDHIP_F64)))
         return hipErrorNotSupported;
     if (order >= 4) {
         // Two poles = a cascade of two one-pole filters (mirror-boundary filters commute: both are
@@ -1126,11 +1197,12 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
     }
     if (fp.len < 64)
         return hipErrorNotSupported;
-    const int64_t esz = fp.in_dtype == EDHIP_F32 ? 4 : 8;
-    if (((uintptr_t)fp.in % esz) || ((uintptr_t)fp.out % esz))
+    const int64_t esz = mixed ? 4 : (fp.in_dtype == EDHIP_F32 ? 4 : 8);
+    const int64_t esz_in = in16 ? 2 : esz, esz_out = out16 ? 2 : esz;
+    if (((uintptr_t)fp.in % esz_in) || ((uintptr_t)fp.out % esz_out))
         return hipErrorNotSupported;
     for (int d = 0; d < ndim; ++d)
-        if (in_stride_bytes[d] % esz || out_stride_bytes[d] % esz)
+        if (in_stride_bytes[d] % esz_in || out_stride_bytes[d] % esz_out)
             return hipErrorNotSupported;
 
     FastFilter p;
@@ -1138,15 +1210,17 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
     p.in = fp.in;
     p.out = fp.out;
     p.len = fp.len;
-    p.in_axis_stride = in_stride_bytes[axis] / esz;
-    p.out_axis_stride = out_stride_bytes[axis] / esz;
+    p.in_axis_stride = in_stride_bytes[axis] / esz_in;
+    p.out_axis_stride = out_stride_bytes[axis] / esz_out;
+    p.in16 = in16;
+    p.out16 = out16;
     p.nlines = 1;
     for (int d = 0; d < ndim; ++d) {
         if (d == axis)
             continue;
         p.outer_len[p.nouter] = shape[d];
-        p.in_outer_stride[p.nouter] = in_stride_bytes[d] / esz;
-        p.out_outer_stride[p.nouter] = out_stride_bytes[d] / esz;
+        p.in_outer_stride[p.nouter] = in_stride_bytes[d] / esz_in;
+        p.out_outer_stride[p.nouter] = out_stride_bytes[d] / esz_out;
         p.win_outer[p.nouter] = d;
         p.nlines *= shape[d];
         p.nouter++;
@@ -1178,13 +1252,13 @@ hipError_t launch_spline_filter_fast(const FilterParams& fp, int order, int ndim
     p.nseg = (int)((nblocks_line + seg_blocks - 1) / seg_blocks);
 
     if (!ed_env("EDHIP_NO_LINE_TILES")) {
-        const hipError_t e = fp.in_dtype == EDHIP_F32 ? launch_line_tiles<float>(p, stream)
-                                                      : launch_line_tiles<double>(p, stream);
-        if (e != hipErrorNotSupported || window)
+        const hipError_t e = (mixed || fp.in_dtype == EDHIP_F32) ? launch_line_tiles<float>(p, stream)
+                                                                 : launch_line_tiles<double>(p, stream);
+        if (e != hipErrorNotSupported || window || mixed)
             return e;
         (void)hipGetLastError();
     }
-    if (window)
+    if (window || mixed)
         return hipErrorNotSupported;
     {
         // block-recompute kernels: lane <-> line (UNIT: the filtered axis itself is contiguous)

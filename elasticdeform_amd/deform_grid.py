@@ -149,6 +149,22 @@ def _widen(t, order, prefilter):
     return None
 
 
+def _direct16(x, axes, order, prefilter, crop):
+    """Reduced-precision opt-in, 16-bit float volume: can it stay in 16 bits in HBM?  (The float32 kernels then
+    widen it where they read it and narrow where they write: the first prefilter pass, K1's store, K2's load of
+    dY, the last transposed prefilter pass -- no cast passes, 16 instead of 44 bytes of casts + I/O per voxel
+    around the float32 intermediates.)  This is only the host's guess from shapes; the library has the last word
+    (EDHIP_ERR_UNSUPPORTED, nothing launched) and the caller then falls back to widening with a cast."""
+    if not _reduced or (_flags & _lib.FLAG_EXACT) or crop is not None or not prefilter or order not in (2, 3):
+        return False
+    torch = _torch()
+    if x.dtype not in (torch.float16, torch.bfloat16) or not x.is_contiguous() or len(axes) != 3 or x.dim() < 3:
+        return False
+    if tuple(axes) != tuple(range(x.dim() - 3, x.dim())) or int(x.shape[-1]) % 4:
+        return False
+    return all(64 <= int(x.shape[a]) <= 256 for a in axes)
+
+
 def _narrow(t32, like):
     """float32 result -> the storage dtype of `like`: round to nearest even for 16-bit floats; the
     reference's store rule for integers (deform.c:292-306: round half away from zero, clamp)."""
@@ -457,7 +473,8 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
         Xs_dev = [_to_device(x, device) for x in Xs]
         # reduced-precision opt-in: 16-bit float volumes (and integer images with order > 1) are
         # computed in float32 and narrowed at the end
-        wide = [_widen(x, int(plan.order[i]), prefilter) for i, x in enumerate(Xs_dev)]
+        direct = [_direct16(x, plan.axis[i], int(plan.order[i]), prefilter, crop) for i, x in enumerate(Xs_dev)]
+        wide = [None if direct[i] else _widen(x, int(plan.order[i]), prefilter) for i, x in enumerate(Xs_dev)]
         Xd = [w if w is not None else x for w, x in zip(wide, Xs_dev)]
         dd = _to_device(displacement, device)
 
@@ -469,7 +486,17 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
         Xf, in_descs = [], []
         for i, x in enumerate(Xd):
             xf = None
-            if not (prefilter and plan.order[i] > 1):
+            if direct[i]:
+                # 16-bit storage: the first filter pass widens, the chain continues in place in float32
+                xf = torch.empty(x.shape, dtype=torch.float32, device=device)
+                if _lib.spline_filter_axes(_desc(x), _desc(xf), list(plan.axis[i]), int(plan.order[i]), False,
+                                           _flags | _lib.FLAG_FAST, stream, may_decline=True) != 0:
+                    direct[i] = False
+                    wide[i] = x = Xd[i] = x.to(torch.float32)
+                    xf = None
+            if xf is not None:
+                pass
+            elif not (prefilter and plan.order[i] > 1):
                 xf = x
             elif wins[i] is not None:
                 # a full-size buffer of which only the window is written -- and read: the kernels' taps stay
@@ -484,15 +511,25 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
             Xf.append(xf)                  # keeps the buffers alive until the launch is enqueued
 
         # every output element is written by the kernel (value or cval), so no zero fill is needed
+        # (a 16-bit volume that stayed in 16 bits: K1 reads the float32 coefficients and narrows at its store)
         outs = [torch.empty(tuple(int(s) for s in shape), dtype=x.dtype, device=device)
                 for shape, x in zip(plan.output_shapes, Xd)]
 
         bflag = _box_flag_forward(displacement, df, device, stream)
         if dflag and any(w is not None for w in wins):
             bflag |= _lib.FLAG_GRID_STAYS        # (edhip_source_window has just filtered this very grid on this stream)
-        _lib.deform(False, in_descs, _desc(df), plan.output_offset,
-                    [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine, _flags | dflag | bflag, stream, prepared=_prepared(plan, len(Xd)))
+        fast16 = _lib.FLAG_FAST if any(direct) else 0
+        if _lib.deform(False, in_descs, _desc(df), plan.output_offset,
+                       [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
+                       plan.inverse_affine, _flags | dflag | bflag | fast16, stream, prepared=_prepared(plan, len(Xd)),
+                       may_decline=bool(fast16)) != 0:
+            # the library declined the 16-bit stores: float32 outputs, narrowed by a cast like the other route
+            outs = [torch.empty(o.shape, dtype=torch.float32, device=device) if d else o for o, d in zip(outs, direct)]
+            wide = [xf if d else w for xf, d, w in zip(Xf, direct, wide)]
+            direct = [False] * len(direct)
+            _lib.deform(False, in_descs, _desc(df), plan.output_offset,
+                        [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
+                        plan.inverse_affine, _flags | dflag | bflag, stream, prepared=_prepared(plan, len(Xd)))
         outs = [_narrow(o, xs) if w is not None else o for o, xs, w in zip(outs, Xs_dev, wide)]
         res = [_from_device(o, x) for o, x in zip(outs, Xs)]
         if sig is not None:
@@ -547,22 +584,32 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         return res if isinstance(dY, list) else res[0]
     with torch.cuda.device(device):
         dY_dev = [_to_device(dy, device) for dy in dYs]
-        wide = [_widen(dy, int(plan.order[i]), prefilter) for i, dy in enumerate(dY_dev)]
+        # 16-bit dY that can stay in 16 bits (_direct16): K2 widens it where it reads it, the accumulators are float32
+        direct = [_direct16(dy, plan.axis[i], int(plan.order[i]), prefilter, crop) and tuple(X_shape[i]) == tuple(dy.shape)
+                  for i, dy in enumerate(dY_dev)]
+        wide = [None if direct[i] else _widen(dy, int(plan.order[i]), prefilter) for i, dy in enumerate(dY_dev)]
         dYd = [w if w is not None else dy for w, dy in zip(wide, dY_dev)]
         # gradient accumulators start at zero (deform_grid.py:243): cleared by the library next to its
         # tables kernel (EDHIP_FLAG_ZERO_GRADIENT) instead of by a fill launch of their own
-        dXs = [torch.empty(tuple(int(v) for v in s), dtype=dy.dtype, device=device)
-               for s, dy in zip(X_shape, dYd)]
+        dXs = [torch.empty(tuple(int(v) for v in s), dtype=torch.float32 if d else dy.dtype, device=device)
+               for s, dy, d in zip(X_shape, dYd, direct)]
 
         dd = _to_device(displacement, device)
         df, dflag = _prefilter_displacement(dd, device)
 
         stream = _stream(device)
-        _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
-                    [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
-                    plan.inverse_affine,
-                    _flags | dflag | _lib.FLAG_ZERO_GRADIENT | _box_flag_gradient(displacement, df, device, stream),
-                    stream, prepared=_prepared(plan, len(dXs)))
+        gflags = _flags | dflag | _lib.FLAG_ZERO_GRADIENT | _box_flag_gradient(displacement, df, device, stream)
+        if _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
+                       [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
+                       plan.inverse_affine, gflags | (_lib.FLAG_FAST if any(direct) else 0),
+                       stream, prepared=_prepared(plan, len(dXs)), may_decline=any(direct)) != 0:
+            # the library declined the 16-bit loads: widen dY with a cast, like the other route
+            wide = [dy.to(torch.float32) if d else w for dy, d, w in zip(dY_dev, direct, wide)]
+            dYd = [w if w is not None else dy for w, dy in zip(wide, dY_dev)]
+            direct = [False] * len(direct)
+            _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
+                        [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
+                        plan.inverse_affine, gflags, stream, prepared=_prepared(plan, len(dXs)))
 
         # gradient of the prefilter: its transpose along each deformed axis (deform_grid.py:276-286).
         # With a crop the scatter only touched a box of dX: the transposed filter runs on that box
@@ -571,6 +618,16 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
         wins = _crop_windows(plan, dXs, _desc(df), dflag, crop, prefilter, device, stream, grid_stays=True)
         dXf = []
         for i, x in enumerate(dXs):
+            if direct[i]:
+                # the transposed chain in place in float32; its last pass narrows into the 16-bit result
+                g16 = torch.empty(x.shape, dtype=dY_dev[i].dtype, device=device)
+                if _lib.spline_filter_axes(_desc(x), _desc(g16), list(plan.axis[i]), int(plan.order[i]), True,
+                                           _flags | _lib.FLAG_FAST | _lib.FLAG_SCRATCH_INPUT, stream,
+                                           may_decline=True) == 0:
+                    dXf.append(g16)
+                    continue
+                direct[i] = False
+                wide[i] = x                 # (float32 chain below, narrowed by a cast)
             if not (prefilter and plan.order[i] > 1):
                 dXf.append(x)
             elif wins[i] is not None and _lib.spline_filter_axes_window(

@@ -115,7 +115,19 @@ enum edhip_flags {
                                   coordinates, near-tie voxels re-evaluated exactly; the rest: exact kernels) */
     EDHIP_FLAG_EXACT = 1,      /* fp64 arithmetic in the reference's own evaluation order (bit-comparable) */
     EDHIP_FLAG_FAST = 2,       /* fp64 coordinates, restructured (separable) sums, data-width tap accumulation
-                                  (what AUTO selects for floating-point data) */
+                                  (what AUTO selects for floating-point data).
+                                  Given explicitly it also opens the pairs of a float32 array and a 16-bit float one
+                                  (EDHIP_F16 / EDHIP_BF16; an extension -- the reference rejects float16, deform.c:742-747):
+                                  float32 arithmetic with 16 bits in HBM on one side, converted inside the kernel that
+                                  reads or writes it instead of by a cast pass --
+                                    edhip_deform  inputs float32, outputs 16-bit: forward = the result is rounded to nearest
+                                                  even at the store; gradient = dY is widened at the load (dX stays float32);
+                                                  3 deformed axes, orders 1-3, unit stride along the last one;
+                                    edhip_spline_filter_axes  16-bit input, float32 output: the first pass widens;
+                                                  float32 input, 16-bit output with EDHIP_FLAG_SCRATCH_INPUT: the last pass
+                                                  narrows; orders 2 / 3, lines of 64..256 samples, dense arrays.
+                                  A pair outside those envelopes returns EDHIP_ERR_UNSUPPORTED before anything is launched
+                                  (without the flag such pairs run on the exact kernels like any other dtype pair). */
     /* edhip_deform only: `displacement` is the RAW control grid; the library applies the order-3
      * mirror prefilter along every grid axis itself (what deform_grid.py:166-169,269-272 does with
      * SciPy before calling the C code), in one launch, with the same arithmetic and the same
@@ -146,7 +158,12 @@ enum edhip_flags {
      * of the previous RAW_DISPLACEMENT call on this stream (edhip_source_window followed by edhip_deform inside
      * one deform_grid call): when the library finds that call's filtered copy still in the stream's workspace
      * (same pointer, dtype, shape and strides, workspace not moved) it does not filter the grid again. */
-    EDHIP_FLAG_GRID_STAYS = 64
+    EDHIP_FLAG_GRID_STAYS = 64,
+    /* edhip_spline_filter_axes: the caller hands `input` over as scratch -- every pass but the last runs in place on
+     * it and the last one writes `output` (instead of: input -> output, then in place on the output).  With a
+     * float32 input and an EDHIP_F16 / EDHIP_BF16 output the chain is computed in float32 and only its result is
+     * rounded to 16 bits (the last pass narrows on its way out: 6 instead of 8 bytes per sample, and no cast pass). */
+    EDHIP_FLAG_SCRATCH_INPUT = 128
 };
 
 /* strided N-d array in device memory: the POD stand-in for PyArrayObject* */

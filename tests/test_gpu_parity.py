@@ -909,6 +909,99 @@ def test_reduced_precision_io_opt_in():
         ed.set_arithmetic("auto")
 
 
+@pytest.mark.parametrize("tdt", ["float16", "bfloat16"])
+@pytest.mark.parametrize("kw", [dict(order=3, mode="mirror"), dict(order=2, mode="nearest"),
+                                dict(order=3, mode="constant", cval=0.25,
+                                     affine=np.array([[0.98, 0.05, 0.0, 1.5], [-0.04, 1.02, 0.03, -2.0],
+                                                      [0.0, -0.02, 0.97, 0.75]]))])
+def test_reduced_precision_stays_in_16_bits(tdt, kw):
+    """16-bit float volumes whose lines fit the whole-line tile kernels never get a widening / narrowing cast
+    pass: the first prefilter pass reads 16 bits, K1 stores 16 bits, K2 loads dY in 16 bits, the last transposed
+    prefilter pass stores 16 bits (EDHIP_FLAG_FAST pairs of float32 and 16-bit arrays in the C ABI).  Forward:
+    bit-equal to the float32 pipeline on the widened volume, rounded by a cast.  Gradient: the same within the
+    atomics' float32 noise, i.e. within one 16-bit ulp of the scale.  And the route is really taken."""
+    import importlib
+    from elasticdeform_amd import _lib
+    tdt = getattr(torch, tdt)
+    rng = np.random.default_rng(43)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = (72, 96, 128)
+    X = torch.from_numpy(rng.random(n).astype(np.float32)).to(dev).to(tdt)
+    dY = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(dev).to(tdt)
+    disp = rng.standard_normal((3, 4, 4, 4)) * 4.0
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    seen = []
+    real_deform, real_filter = _lib.deform, _lib.spline_filter_axes
+
+    def spy_deform(gradient, in_descs, disp_desc, off, out_descs, *a, **k):
+        st = real_deform(gradient, in_descs, disp_desc, off, out_descs, *a, **k)
+        seen.append(("deform", int(in_descs[0].dtype), int(out_descs[0].dtype), st))
+        return st
+
+    def spy_filter(in_desc, out_desc, *a, **k):
+        st = real_filter(in_desc, out_desc, *a, **k)
+        seen.append(("filter", int(in_desc.dtype), int(out_desc.dtype), st))
+        return st
+
+    prev = ed.set_reduced_precision(True)
+    _lib.deform, _lib.spline_filter_axes = spy_deform, spy_filter
+    try:
+        got = ed.deform_grid(X, disp, **kw)
+        g = ed.deform_grid_gradient(dY, disp, **kw)
+    finally:
+        _lib.deform, _lib.spline_filter_axes = real_deform, real_filter
+        ed.set_reduced_precision(prev)
+    f32, h16 = _lib.DTYPE_CODES["float32"], _lib.DTYPE_CODES[str(tdt).split(".")[1]]
+    seen16 = [e for e in seen if h16 in e[1:3]]
+    assert seen16 == [("filter", h16, f32, 0), ("deform", f32, h16, 0), ("deform", f32, h16, 0), ("filter", f32, h16, 0)], seen
+    assert got.dtype == tdt and g.dtype == tdt
+    want = ed.deform_grid(X.float(), disp, **kw).to(tdt)
+    assert torch.equal(got, want)
+    gw = ed.deform_grid_gradient(dY.float(), disp, **kw)
+    ulp = 2.0 ** -10 if tdt == torch.float16 else 2.0 ** -7
+    scale = max(1.0, float(gw.abs().max()))
+    assert float((g.float() - gw).abs().max()) <= ulp * scale * 0.51 + 1e-5 * scale
+    # and against the fp64 oracle on the widened data
+    ref = orc.deform_grid(X.float().cpu().numpy().astype(np.float64), disp, **kw)
+    assert np.abs(got.float().cpu().numpy() - ref).max() <= ulp * max(1.0, np.abs(ref).max()) * 1.01 + 2e-5
+
+
+def test_16_bit_pairs_in_the_c_abi_decline_cleanly():
+    """EDHIP_FLAG_FAST with a float32 / 16-bit pair the tile kernels cannot take: EDHIP_ERR_UNSUPPORTED, nothing
+    launched, and the Python layer falls back to the cast route with the same result."""
+    import importlib
+    from elasticdeform_amd import _lib
+    rng = np.random.default_rng(44)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    prev = ed.set_reduced_precision(True)
+    try:
+        # lines of 40 samples: below the whole-line tile kernels
+        x16 = torch.from_numpy(rng.random((40, 40, 40)).astype(np.float32)).to(dev).to(torch.bfloat16)
+        xf = torch.full((40, 40, 40), 7.0, dtype=torch.float32, device=dev)
+        st = _lib.spline_filter_axes(dgm._desc(x16), dgm._desc(xf), [0, 1, 2], 3, False, _lib.FLAG_FAST, stream,
+                                     may_decline=True)
+        assert st == _lib.ERR_UNSUPPORTED
+        assert float(xf.min()) == 7.0 and float(xf.max()) == 7.0
+        # order 5 forward with a 16-bit output: the one-wave kernels do not narrow
+        x32 = torch.from_numpy(rng.random((64, 64, 64)).astype(np.float32)).to(dev)
+        out16 = torch.full((64, 64, 64), 3.0, dtype=torch.bfloat16, device=dev)
+        disp = torch.from_numpy(rng.standard_normal((3, 3, 3, 3))).to(dev)
+        df = dgm._filter_axes(disp, [1, 2, 3], 3, False, dev)
+        st = _lib.deform(False, [dgm._desc(x32)], dgm._desc(df), None, [dgm._desc(out16)], [(0, 1, 2)], [5], [3], [0.0],
+                         None, _lib.FLAG_FAST, stream, may_decline=True)
+        assert st == _lib.ERR_UNSUPPORTED
+        assert float(out16.float().min()) == 3.0 and float(out16.float().max()) == 3.0
+        # a crop keeps the Python layer on the cast route; the result is the float32 pipeline's, narrowed
+        X = torch.from_numpy(rng.random((80, 80, 80)).astype(np.float32)).to(dev).to(torch.float16)
+        kw = dict(order=3, crop=(slice(8, 60), slice(0, 80), slice(4, 44)))
+        d = rng.standard_normal((3, 3, 3, 3)) * 3
+        assert torch.equal(ed.deform_grid(X, d, **kw), ed.deform_grid(X.float(), d, **kw).half())
+    finally:
+        ed.set_reduced_precision(prev)
+
+
 @pytest.mark.parametrize("order", [4, 5, 3])
 def test_box_reduction_barrier_regression(order):
     """Regression for a race found by tests/fuzz/fuzz_hot.py: the hot kernels fold a wave's
