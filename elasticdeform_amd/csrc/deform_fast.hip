@@ -143,6 +143,36 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
         }
 
         // ---- E[h][j]: contract the grid over the slow axes, 64 lanes in parallel -------------
+        // Four deformed axes with a small control grid: the 64 taps of the three slow axes are the 64 LANES (one
+        // independent grid load per lane and element, a butterfly sum per element) instead of 64 dependent loads in
+        // each of a dozen busy lanes -- that chain was 95 us per row and 0.38 ms of a 32^4 forward call of ANY order.
+        if (NS == 3 && nE <= 64) {
+            const int l0 = lane >> 4, l1 = (lane >> 2) & 3, l2 = lane & 3;
+            const int64_t offs = g.disp_stride[1] * s_i[rr][0][l0] + g.disp_stride[2] * s_i[rr][NSD > 1 ? 1 : 0][l1] +
+                                 g.disp_stride[3] * s_i[rr][NSD > 2 ? 2 : 0][l2];
+            const double wprod = s_w[rr][0][l0] * s_w[rr][NSD > 1 ? 1 : 0][l1] * s_w[rr][NSD > 2 ? 2 : 0][l2];
+            double mine = 0.0;
+            for (int e0 = 0; e0 < nE; e0 += 4) {
+                double a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {       // four independent loads in flight, four interleaved butterflies
+                    const int e = e0 + u < nE ? e0 + u : nE - 1;
+                    const int h = e / (int)ncpx, j = e - h * (int)ncpx;
+                    a[u] = load_as_double(g.disp + g.disp_stride[0] * h + g.disp_stride[NAXIS] * j + offs, g.disp_dtype) * wprod;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        a[u] += __shfl_xor(a[u], m);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    mine = lane == e0 + u ? a[u] : mine;
+            }
+            if (lane < nE)
+                s_E[wave][lane] = mine;
+        } else
         for (int e = lane; e < nE; e += 64) {
             const int h = e / (int)ncpx, j = e - h * (int)ncpx;
             const char* base = g.disp + g.disp_stride[0] * h + g.disp_stride[NAXIS] * j;
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
                                 a0 += w[0][l0] * a1;
                             }
                             val = a0;
-                        } else {
+                        } else if constexpr (NAXIS == 3) {
                             T a0 = 0;
 #pragma unroll
                             for (int l0 = 0; l0 < NT; ++l0) {
@@ -279,6 +309,31 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
 #pragma unroll
                                     for (int l2 = 0; l2 < NT; ++l2)
                                         a2 += w[X][l2] * p1[tap[X][l2]];
+                                    a1 += w[1][l1] * a2;
+                                }
+                                a0 += w[0][l0] * a1;
+                            }
+                            val = a0;
+                        } else {
+                            // four deformed axes (round 4; the reference takes any number in one loop,
+                            // _deform_grid.c:158-175): (order+1)^4 taps, accumulated axis by axis
+                            T a0 = 0;
+#pragma unroll
+                            for (int l0 = 0; l0 < NT; ++l0) {
+                                T a1 = 0;
+#pragma unroll
+                                for (int l1 = 0; l1 < NT; ++l1) {
+                                    const T* p1 = p + (tap[0][l0] + tap[1][l1]);
+                                    T a2 = 0;
+#pragma unroll
+                                    for (int l2 = 0; l2 < NT; ++l2) {
+                                        const T* p2 = p1 + tap[2][l2];
+                                        T a3 = 0;
+#pragma unroll
+                                        for (int l3 = 0; l3 < NT; ++l3)
+                                            a3 += w[X][l3] * p2[tap[X][l3]];
+                                        a2 += w[2][l2] * a3;
+                                    }
                                     a1 += w[1][l1] * a2;
                                 }
                                 a0 += w[0][l0] * a1;
@@ -303,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
                             for (int l1 = 0; l1 < NT; ++l1)
                                 atomic_add(p0 + tap[X][l1], g0 * w[X][l1]);
                         }
-                    } else {
+                    } else if constexpr (NAXIS == 3) {
 #pragma unroll
                         for (int l0 = 0; l0 < NT; ++l0) {
                             const T g0 = grad * w[0][l0];
@@ -315,6 +370,24 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
 #pragma unroll
                                 for (int l2 = 0; l2 < NT; ++l2)
                                     atomic_add(p1 + tap[X][l2], g1 * w[X][l2]);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int l0 = 0; l0 < NT; ++l0) {
+                            const T g0 = grad * w[0][l0];
+#pragma unroll
+                            for (int l1 = 0; l1 < NT; ++l1) {
+                                const T g1 = g0 * w[1][l1];
+                                T* p1 = p + (tap[0][l0] + tap[1][l1]);
+#pragma unroll
+                                for (int l2 = 0; l2 < NT; ++l2) {
+                                    const T g2 = g1 * w[2][l2];
+                                    T* p2 = p1 + tap[2][l2];
+#pragma unroll
+                                    for (int l3 = 0; l3 < NT; ++l3)
+                                        atomic_add(p2 + tap[X][l3], g2 * w[X][l3]);
+                                }
                             }
                         }
                     }
@@ -709,6 +782,15 @@ hipError_t launch_axes(const GridGeom& g, const IOView& v, int gradient, hipStre
     case 1: return launch_order<T, 1>(g, v, gradient, stream);
     case 2: return launch_order<T, 2>(g, v, gradient, stream);
     case 3: return launch_order<T, 3>(g, v, gradient, stream);
+    case 4:
+        // (orders 0-3: 256 taps per voxel; orders 4 / 5 -- 625 / 1296 -- stay on the exact kernel)
+        switch (v.order) {
+        case 0: return launch_typed<T, 4, 0>(g, v, gradient, stream);
+        case 1: return launch_typed<T, 4, 1>(g, v, gradient, stream);
+        case 2: return launch_typed<T, 4, 2>(g, v, gradient, stream);
+        case 3: return launch_typed<T, 4, 3>(g, v, gradient, stream);
+        default: return hipErrorNotSupported;
+        }
     default: return hipErrorNotSupported;
     }
 }
@@ -718,7 +800,7 @@ hipError_t launch_axes(const GridGeom& g, const IOView& v, int gradient, hipStre
 bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient)
 {
     (void)gradient;
-    if (g.naxis < 1 || g.naxis > 3)
+    if (g.naxis < 1 || g.naxis > 4 || (g.naxis == 4 && v.order > 3))
         return false;
     if (v.in_dtype != v.out_dtype)
         return false;

@@ -243,6 +243,29 @@ def test_ragged_shapes_vs_oracle(shape, points, dtype):
                     np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * max(1.0, np.abs(gw).max()))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_four_deformed_axes_on_the_fast_kernel(dtype):
+    """Four deformed axes (the reference takes any number in one loop, _deform_grid.c:158-175): orders 0-3 of
+    floating-point volumes run on the row kernel of deform_fast.hip (per-row contraction of the 4-D control grid,
+    256 taps per voxel), orders 4 / 5 on the exact kernel; with a channel axis, a crop and every mode."""
+    rng = np.random.default_rng(404)
+    eps = 1e-5 if dtype == np.float32 else 1e-11
+    X = rng.random((2, 9, 12, 10, 68)).astype(dtype)
+    disp = rng.standard_normal((4, 3, 2, 3, 4)) * 2.0
+    for order in (0, 1, 2, 3, 4):
+        for mode, crop in (("mirror", None), ("constant", None), ("wrap", (slice(2, 8), slice(0, 12), slice(3, 9), slice(5, 66))),
+                           ("nearest", None), ("reflect", None)):
+            kw = dict(order=order, mode=mode, cval=0.5, axis=(1, 2, 3, 4), crop=crop)
+            want = orc.deform_grid(X, disp, **kw)
+            got = ed.deform_grid(X, disp, **kw)
+            np.testing.assert_allclose(got, want, rtol=eps, atol=eps)
+            if order in (1, 3) and mode in ("mirror", "wrap"):
+                dY = rng.random(want.shape).astype(dtype)
+                gw = orc.deform_grid_gradient(dY, disp, X_shape=X.shape, prefilter=False, **kw)
+                gg = ed.deform_grid_gradient(dY, disp, X_shape=X.shape, prefilter=False, **kw)
+                np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * max(1.0, np.abs(gw).max()))
+
+
 def test_integer_gradient_is_bit_exact():
     """*(T*)p += (T)t accumulates in the array dtype (deform.c:309-312): integer atomics are
     associative, so even the scatter-add is bit-reproducible for integer gradients."""
