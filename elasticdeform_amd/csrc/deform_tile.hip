@@ -1216,10 +1216,17 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
             ed_env("EDHIP_RECORDS"))
             return hipErrorNotSupported;
     }
-    tg.strip_tiles = kStrip;
+    // (the forward kernels prefer strips of 4: 256^3 order 3, K1 call 237.5 -> 228.7 us, sigma 10 342.8 -> 338.0, order 1
+    // 159.4 -> 155.8 -- twice the workgroups for the tail of the launch to be dealt from; the gradient kernel, which
+    // walks a strip in 16-wide tiles, prefers 8: 310.7 against 313.3 us; profiles/r04_bench_misc.txt)
+    tg.strip_tiles = GRAD ? kStrip : kStrip / 2;
     while (tg.strip_tiles > (GRAD ? 2 : 1) &&
            (int64_t)nb * tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles) < 1024)
         tg.strip_tiles >>= 1;
+#ifdef EDHIP_EXPERIMENTS
+    if (const char* st = ed_env("EDHIP_STRIP"))
+        tg.strip_tiles = atoi(st) >= 1 && atoi(st) <= kStrip ? atoi(st) : tg.strip_tiles;
+#endif
     tg.strips_x = (tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles;
     const int64_t nstrips = (int64_t)tg.tiles[0] * tg.tiles[1] * tg.strips_x;
     const int64_t ntiles = (int64_t)tg.tiles[0] * tg.tiles[1] * tg.tiles[2];

@@ -9,6 +9,7 @@ cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 python bench.py --workload cfg4 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 python bench.py --workload cfg5 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg5.json 2> $O/bench_cfg5.err
+python bench.py --dtype bf16 > $O/bench_bf16.json 2> $O/bench_bf16.err
 EDHIP_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload cfg5 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_2ranks_gloo.json 2> $O/bench_2r.err
 EDHIP_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload cfg5 --batch 8 --steps 5 --warmup 2 --collective > $O/bench_cfg5_collective_gloo.json 2> $O/bench_coll.err
 cd /tmp && rocprofv3 --kernel-trace --stats -d $O/prof -o r04 --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress > $O/prof.log 2>&1
@@ -30,6 +31,7 @@ T() { timeout 120 python tools/time_k12.py "$@" 2>&1 | tail -1; }
 { for o in 1 2 3; do T 256 $o 5; done; T 256 3 10; T 256 3 15; T 128 3 5; } > $O/misc.txt 2>/dev/null
 timeout 600 python tools/time_matrix.py 2>&1 | grep -v amdgpu.ids > $O/time_matrix.txt
 timeout 300 python tools/time_crop_window.py 2>&1 | grep -v amdgpu.ids > $O/time_crop_window.txt
+if [ -n "$SKIP_RECORDS" ]; then tail -c 900 $O/bench_cfg2.json; exit 0; fi
 # ---- profiling build: records route vs shipped route
 cp elasticdeform_amd/libedhip.so /tmp/libedhip_ship.so
 cp tools/libedhip_exp.so elasticdeform_amd/libedhip.so
