@@ -143,6 +143,10 @@ struct GridPrefilter {
     int64_t stride_bytes[kMaxAxes + 1];
     double pole, gain;
     double pole_pow[kMaxAxes + 1];   // pole^(shape[ax] - 1), host libm
+    // EDHIP_FLAG_ZERO_GRADIENT: a dense, 16-byte-aligned block that workgroups 1 .. of the launch clear while
+    // workgroup 0 filters the grid (the grid's recursion is one workgroup's latency: the rest of the chip is idle)
+    char* zero_ptr;
+    long long zero_bytes;
 };
 hipError_t launch_grid_prefilter(const GridPrefilter& p, hipStream_t stream);
 

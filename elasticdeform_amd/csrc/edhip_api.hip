@@ -50,9 +50,12 @@ int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
 
 // Geometry shared by every input of a call (deform.c:381-391,439-451,771-776); with
 // EDHIP_FLAG_RAW_DISPLACEMENT the control grid is prefiltered into the head of the workspace.
+// zero_ptr / zero_bytes / zero_done: a gradient block the grid-prefilter launch may clear on its spare workgroups
+// (*zero_done says whether it did: only a RAW_DISPLACEMENT call that really launches the prefilter)
 int make_geometry(const edhip_array* displacement, const int64_t* in_len, const int64_t* out_len,
                   const int64_t* output_offset, int naxis, const double* affine, uint32_t flags,
-                  hipStream_t stream, ed::GridGeom& g, char* err, size_t errlen)
+                  hipStream_t stream, ed::GridGeom& g, char* err, size_t errlen, char* zero_ptr = nullptr,
+                  long long zero_bytes = 0, bool* zero_done = nullptr)
 {
     using namespace ed;
     memset(&g, 0, sizeof(g));
@@ -123,6 +126,11 @@ int make_geometry(const edhip_array* displacement, const int64_t* in_len, const 
                            memcmp(stamp->stride, now.stride, sizeof(now.stride)) == 0;
         if (!stays) {
             *stamp = GridStamp();
+            if (zero_ptr && zero_done && ((uintptr_t)zero_ptr & 15) == 0) {
+                gp.zero_ptr = zero_ptr;
+                gp.zero_bytes = zero_bytes;
+                *zero_done = true;
+            }
             e = launch_grid_prefilter(gp, stream);
             if (e != hipSuccess)
                 return hip_fail(err, errlen, e, "grid prefilter launch");
@@ -319,19 +327,6 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         if (displacement->shape[k] <= 0)
             return fail(err, errlen, EDHIP_ERR_INVALID, "invalid displacement shape");
 
-    // ---- shared geometry ------------------------------------------------------------------------
-    GridGeom g;
-    {
-        int64_t in_len[kMaxAxes], out_len[kMaxAxes];
-        for (int k = 0; k < naxis; ++k) {
-            in_len[k] = inputs[0].shape[axis[k]];
-            out_len[k] = outputs[0].shape[axis[k]];
-        }
-        const int st = make_geometry(displacement, in_len, out_len, output_offset, naxis, affine, flags,
-                                     stream, g, err, errlen);
-        if (st != EDHIP_OK)
-            return st;
-    }
     // EDHIP_FLAG_ZERO_GRADIENT: the dense blocks to clear (checked for every input before anything is enqueued)
     const bool zero = gradient && (flags & EDHIP_FLAG_ZERO_GRADIENT);
     char* zero_ptr[EDHIP_MAX_INPUTS];
@@ -341,7 +336,28 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
             if (!dense_block(inputs[i], &zero_ptr[i], &zero_bytes[i]))
                 return fail(err, errlen, EDHIP_ERR_INVALID, "EDHIP_FLAG_ZERO_GRADIENT needs dense gradient arrays");
     }
+    // ---- shared geometry ------------------------------------------------------------------------
+    // (a RAW_DISPLACEMENT call filters the control grid here, in one workgroup: the spare workgroups of that launch
+    // clear the first gradient block -- cleared[0] -- instead of the tables launch further down)
+    GridGeom g;
+    bool cleared[EDHIP_MAX_INPUTS] = {};
+    {
+        int64_t in_len[kMaxAxes], out_len[kMaxAxes];
+        for (int k = 0; k < naxis; ++k) {
+            in_len[k] = inputs[0].shape[axis[k]];
+            out_len[k] = outputs[0].shape[axis[k]];
+        }
+        const bool early = zero && zero_bytes[0] > 0;
+        const int st = make_geometry(displacement, in_len, out_len, output_offset, naxis, affine, flags,
+                                     stream, g, err, errlen, early ? zero_ptr[0] : nullptr, early ? zero_bytes[0] : 0,
+                                     early ? &cleared[0] : nullptr);
+        if (st != EDHIP_OK)
+            return st;
+    }
     auto clear_now = [&](int i) -> hipError_t {
+        if (cleared[i])
+            return hipSuccess;
+        cleared[i] = true;
         return zero_bytes[i] > 0 ? hipMemsetAsync(zero_ptr[i], 0, (size_t)zero_bytes[i], stream) : hipSuccess;
     };
     if (g.nvox <= 0) {
@@ -423,7 +439,7 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
             // block it cannot take is cleared HERE, in front of the scatter (it used to be cleared behind a
             // launch that returned success with zero_done unset: the computed gradient was wiped).
             hipError_t ce = hipSuccess;
-            if (zero) {
+            if (zero && !cleared[i]) {
                 if (((uintptr_t)zero_ptr[i] & 15) == 0) {
                     one.zero_ptr = zero_ptr[i];
                     one.zero_bytes = zero_bytes[i];
@@ -440,6 +456,8 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
             // not touched the block: cleared now, and whoever takes the call next finds it cleared)
             // (zero_done unset behind an aligned block: the tables launch -- which precedes every scatter of the
             // tile path -- was not made, so nothing has been added to the block yet)
+            if (zero && one.zero_ptr && one.zero_done)
+                cleared[i] = true;
             if (zero && one.zero_ptr && !one.zero_done && (e == hipSuccess || e == hipErrorNotSupported)) {
                 const hipError_t c2 = clear_now(i);
                 if (e == hipSuccess)

@@ -482,6 +482,19 @@ __global__ __launch_bounds__(256) void grid_prefilter_kernel(const GridPrefilter
 {
     __shared__ double s[4096];
     const int tid = threadIdx.x;
+    if (blockIdx.x > 0) {
+        // the gradient's accumulators (see GridPrefilter::zero_ptr): 64 MB in the ~7 us this launch takes anyway,
+        // and a few more -- it used to ride on the tables launch behind this one (25 us for an 8 us kernel)
+        const long long nfill = (long long)(gridDim.x - 1) * 256;
+        const long long me = (long long)(blockIdx.x - 1) * 256 + tid;
+        const long long n16 = p.zero_bytes >> 4;
+        int4* p16 = reinterpret_cast<int4*>(p.zero_ptr);
+        for (long long i = me; i < n16; i += nfill)
+            p16[i] = make_int4(0, 0, 0, 0);
+        if (me < (p.zero_bytes & 15))
+            p.zero_ptr[(n16 << 4) + me] = 0;
+        return;
+    }
     const int total = p.total;
     // gather (arbitrary strides) -> LDS, C order
     for (int e = tid; e < total; e += 256) {
@@ -545,7 +558,12 @@ __global__ __launch_bounds__(256) void grid_prefilter_kernel(const GridPrefilter
 
 hipError_t launch_grid_prefilter(const GridPrefilter& p, hipStream_t stream)
 {
-    hipLaunchKernelGGL(grid_prefilter_kernel, dim3(1), dim3(256), 0, stream, p);
+    long long fill = 0;
+    if (p.zero_ptr && p.zero_bytes > 0) {
+        fill = (p.zero_bytes + 65535) / 65536;          // 64 KiB per workgroup and round
+        fill = fill < 1 ? 1 : (fill > 2048 ? 2048 : fill);
+    }
+    hipLaunchKernelGGL(grid_prefilter_kernel, dim3(1 + (unsigned)fill), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
