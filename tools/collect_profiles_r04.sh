@@ -5,7 +5,16 @@
 # (hot_grad2_kernel) against the shipped gradient kernel -- times, per-wave phase clocks, PMC.
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; rm -rf $O; mkdir -p $O
 export PYTHONPATH=$R
+# PMC passes first: bench.py reports roofline.traffic from profiles/hbm_traffic.json when its source hash matches
 cd $R
+OUTNAME=r04/pmc bash tools/pmc_hot.sh
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  ITERS=6 rocprofv3 --kernel-trace --pmc $c -d $O/pmc/$c -o p --output-format csv -- python $R/tools/time_k12.py > $O/pmc/$c.log 2>&1
+done
+cd $R; python tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt
+python tools/hbm_traffic.py $O/pmc "${COMMIT:-unknown}" > $O/hbm_traffic.json
+cp $O/hbm_traffic.json $R/profiles/hbm_traffic.json
 python bench.py --steps 20 --warmup 5 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 python bench.py --workload cfg4 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 python bench.py --workload cfg5 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg5.json 2> $O/bench_cfg5.err
@@ -20,13 +29,6 @@ for w in auto off; do
   python $R/tools/kernel_stats_csv.py $O/cfg4_$w/p_kernel_stats.csv > $O/cfg4_stats_$w.txt 2>/dev/null
 done
 cd $R
-OUTNAME=r04/pmc bash tools/pmc_hot.sh
-cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  ITERS=6 rocprofv3 --kernel-trace --pmc $c -d $O/pmc/$c -o p --output-format csv -- python $R/tools/time_k12.py > $O/pmc/$c.log 2>&1
-done
-cd $R; python tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt
-python tools/hbm_traffic.py $O/pmc "${COMMIT:-unknown}" > $O/hbm_traffic.json
 T() { timeout 120 python tools/time_k12.py "$@" 2>&1 | tail -1; }
 { for o in 1 2 3; do T 256 $o 5; done; T 256 3 10; T 256 3 15; T 128 3 5; } > $O/misc.txt 2>/dev/null
 timeout 600 python tools/time_matrix.py 2>&1 | grep -v amdgpu.ids > $O/time_matrix.txt
