@@ -1332,6 +1332,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
 #ifdef EDHIP_EXPERIMENTS
             if (const char* ss = ed_env("EDHIP_SELF_SERVE"))
                 self_serve = self_serve_boxes = atoi(ss) != 0;
+            if (const char* lb = ed_env("EDHIP_LARGE_BOXES"))       // 0 never, 1 always, 2 forward only, 3 gradient only
+                large_boxes = atoi(lb) == 1 || (atoi(lb) == 2 && !GRAD) || (atoi(lb) == 3 && GRAD);
 #endif
             tg.hint_host = sh->dev;
             tg.hint_seq = sh->begin_call(key, (unsigned)(ntiles * nb));
