@@ -241,3 +241,33 @@ def test_relayout_permutations_for_non_innermost_deformed_axes():
     for p in ([3, 0, 1, 2], [0, 4, 1, 2, 3]):
         inv = dgm._inverse_perm(p)
         assert [p[i] for i in inv] == list(range(len(p))) and [inv[a] for a in p] == list(range(len(p)))
+
+
+def test_sixteen_bit_volumes_stay_in_16_bits_only_where_the_tile_kernels_can_take_them():
+    """deform_grid._direct16: the host's guess whether a 16-bit float volume can go through the float32 kernels
+    without a cast pass (the library has the last word: EDHIP_ERR_UNSUPPORTED, nothing launched).  Opt-in only,
+    never with 'exact' arithmetic, a crop, orders other than 2 / 3, lines outside 64..256, a last axis that is not a
+    multiple of four samples, deformed axes that are not the three innermost, or float32 data."""
+    torch = pytest.importorskip("torch")
+    import importlib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    x = torch.zeros((72, 96, 128), dtype=torch.bfloat16)
+    ok = lambda t=x, axes=(0, 1, 2), order=3, prefilter=True, crop=None: dgm._direct16(t, axes, order, prefilter, crop)
+    assert not ok()                                   # reduced precision is an opt-in
+    prev = dgm.set_reduced_precision(True)
+    try:
+        assert ok() and ok(order=2) and ok(torch.zeros((2, 64, 64, 64), dtype=torch.float16), axes=(1, 2, 3))
+        assert not ok(order=1) and not ok(order=4) and not ok(prefilter=False)
+        assert not ok(crop=(slice(0, 8),) * 3)
+        assert not ok(x.float())
+        assert not ok(torch.zeros((72, 96, 130), dtype=torch.bfloat16))          # last axis not a multiple of 4
+        assert not ok(torch.zeros((40, 96, 128), dtype=torch.bfloat16))          # a line below the tile kernels
+        assert not ok(torch.zeros((72, 96, 260), dtype=torch.bfloat16))          # ... and above them
+        assert not ok(torch.zeros((72, 96, 128, 4), dtype=torch.bfloat16), axes=(0, 1, 2))   # channel-last
+        assert not ok(x.transpose(0, 1))                                        # not contiguous
+        assert not ok(torch.zeros((96, 128), dtype=torch.bfloat16), axes=(0, 1))
+        dgm.set_arithmetic("exact")
+        assert not ok()
+    finally:
+        dgm.set_arithmetic("auto")
+        dgm.set_reduced_precision(prev)
