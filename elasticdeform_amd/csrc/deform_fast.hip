@@ -52,6 +52,7 @@ struct FastView {
     int64_t out_stride[NAXIS];
 };
 
+// (four axes: ~190-245 registers, two waves per SIMD; capping the kernel at 168 / 128 registers spills 20-109 of them)
 template <typename T, int NAXIS, int ORDER, bool GRAD>
 __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, const IOView v,
                                                              const FastView<NAXIS> fv,
@@ -179,6 +180,21 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
             double acc = 0.0;
             if (NS == 0) {
                 acc = load_as_double(base, g.disp_dtype);
+            } else if constexpr (NS == 3) {
+                // (large control grids with four deformed axes: 64 taps, four at a time -- unrolled in full they held
+                // 128 registers and left the whole kernel one wave per SIMD)
+#pragma unroll 4
+                for (int t = 0; t < 64; ++t) {
+                    int64_t offs = 0;
+                    double wprod = 1.0;
+#pragma unroll
+                    for (int a = 0; a < NS; ++a) {
+                        const int l = (t >> (2 * (NS - 1 - a))) & 3;
+                        offs += g.disp_stride[a + 1] * s_i[rr][a][l];
+                        wprod *= s_w[rr][a][l];
+                    }
+                    acc += load_as_double(base + offs, g.disp_dtype) * wprod;
+                }
             } else {
                 constexpr int NTAP = 1 << (2 * NS);
 #pragma unroll
@@ -316,14 +332,30 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
                             val = a0;
                         } else {
                             // four deformed axes (round 4; the reference takes any number in one loop,
-                            // _deform_grid.c:158-175): (order+1)^4 taps, accumulated axis by axis
+                            // _deform_grid.c:158-175): (order+1)^4 taps.  The two slow axes are ROLLED loops that pick
+                            // their tap with a select chain, the (order+1)^2 inner taps are unrolled: fully unrolled
+                            // the kernel held 256 registers (two waves per SIMD) and every load's latency showed.
                             T a0 = 0;
-#pragma unroll
+#pragma unroll 1
                             for (int l0 = 0; l0 < NT; ++l0) {
-                                T a1 = 0;
+                                int64_t t0 = tap[0][0];
+                                T w0 = w[0][0];
 #pragma unroll
+                                for (int q = 1; q < NT; ++q) {
+                                    t0 = l0 == q ? tap[0][q] : t0;
+                                    w0 = l0 == q ? w[0][q] : w0;
+                                }
+                                T a1 = 0;
+#pragma unroll 1
                                 for (int l1 = 0; l1 < NT; ++l1) {
-                                    const T* p1 = p + (tap[0][l0] + tap[1][l1]);
+                                    int64_t t1 = tap[1][0];
+                                    T w1 = w[1][0];
+#pragma unroll
+                                    for (int q = 1; q < NT; ++q) {
+                                        t1 = l1 == q ? tap[1][q] : t1;
+                                        w1 = l1 == q ? w[1][q] : w1;
+                                    }
+                                    const T* p1 = p + (t0 + t1);
                                     T a2 = 0;
 #pragma unroll
                                     for (int l2 = 0; l2 < NT; ++l2) {
@@ -334,9 +366,9 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
                                             a3 += w[X][l3] * p2[tap[X][l3]];
                                         a2 += w[2][l2] * a3;
                                     }
-                                    a1 += w[1][l1] * a2;
+                                    a1 += w1 * a2;
                                 }
-                                a0 += w[0][l0] * a1;
+                                a0 += w0 * a1;
                             }
                             val = a0;
                         }
@@ -373,13 +405,27 @@ __global__ __launch_bounds__(kBlock) void deform_fast_kernel(const GridGeom g, c
                             }
                         }
                     } else {
-#pragma unroll
+#pragma unroll 1
                         for (int l0 = 0; l0 < NT; ++l0) {
-                            const T g0 = grad * w[0][l0];
+                            int64_t t0 = tap[0][0];
+                            T w0 = w[0][0];
 #pragma unroll
+                            for (int q = 1; q < NT; ++q) {
+                                t0 = l0 == q ? tap[0][q] : t0;
+                                w0 = l0 == q ? w[0][q] : w0;
+                            }
+                            const T g0 = grad * w0;
+#pragma unroll 1
                             for (int l1 = 0; l1 < NT; ++l1) {
-                                const T g1 = g0 * w[1][l1];
-                                T* p1 = p + (tap[0][l0] + tap[1][l1]);
+                                int64_t t1 = tap[1][0];
+                                T w1 = w[1][0];
+#pragma unroll
+                                for (int q = 1; q < NT; ++q) {
+                                    t1 = l1 == q ? tap[1][q] : t1;
+                                    w1 = l1 == q ? w[1][q] : w1;
+                                }
+                                const T g1 = g0 * w1;
+                                T* p1 = p + (t0 + t1);
 #pragma unroll
                                 for (int l2 = 0; l2 < NT; ++l2) {
                                     const T g2 = g1 * w[2][l2];
