@@ -159,8 +159,12 @@ __device__ __forceinline__ void hot_prologue(const HotGeom& hg, const HotStrip& 
         const int r = tid >> 2;
         const int oz = min(sp.tz * kT + (r >> 3), hg.out_len[0] - 1);
         const int oy = min(sp.ty * kT + (r & 7), hg.out_len[1] - 1);
+        // (wide control grids: Q is laid out per x-strip, hg.ncpx columns each -- TileGeom::q_win)
+        const long long qrow_id = hg.q_strips > 1
+                                      ? ((long long)oz * hg.out_len[1] + oy) * hg.q_strips + sp.tx0 / hg.strip_tiles
+                                      : (long long)oz * hg.out_len[1] + oy;
         const double2* src = reinterpret_cast<const double2*>(
-            hg.q + sp.sample * hg.q_bstride + ((long long)oz * hg.out_len[1] + oy) * (4 * hg.ncpx));
+            hg.q + sp.sample * hg.q_bstride + qrow_id * (4 * hg.ncpx));
         double2* dst = reinterpret_cast<double2*>(smem + kOffQ) + r * row16;
         for (int k = tid & 3; k < row16; k += 4)
             dst[k] = src[k];

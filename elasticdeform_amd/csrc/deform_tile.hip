@@ -148,14 +148,33 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
                 tg.keep_flags[sample] = same;
         }
     }
+    // wide control grids (TileGeom::q_win): the lowest control column each x-strip touches
+    __shared__ int c0s[256];
+    if (tg.q_win) {
+        for (int sidx = tid; sidx < tg.q_strips; sidx += kBlock)
+            c0s[sidx] = 0x7fffffff;
+        __syncthreads();
+        for (int ox = tid; ox < tg.out_len[2]; ox += kBlock) {
+            AxTab t;
+            entry(2, ox, t);
+            const int lo = min(min(t.idx[0], t.idx[1]), min(t.idx[2], t.idx[3]));
+            atomicMin(&c0s[ox / tg.q_strip_vox], lo);
+        }
+        __syncthreads();
+    }
     if (oz == 0 && sample == 0) {
         AxTab* xt = const_cast<AxTab*>(tg.xt_global);
         for (int ox = tid; ox < tg.out_len[2]; ox += kBlock) {
             AxTab t;
             entry(2, ox, t);
+            const int c0 = tg.q_win ? c0s[ox / tg.q_strip_vox] : 0;
 #pragma unroll
-            for (int l = 0; l < 4; ++l)
-                t.idx[l] *= 4;          // element offset of control column idx in a Q row [ncpx][4]
+            for (int l = 0; l < 4; ++l) {
+                // element offset of control column idx in a Q row [ncpx][4] ([q_win][4], from the strip's lowest
+                // column: the host sized q_win for every strip; the clamp only keeps a wrong size inside the row)
+                const int rel = t.idx[l] - c0;
+                t.idx[l] = (tg.q_win ? min(rel, tg.q_win - 1) : rel) * 4;
+            }
             xt[ox] = t;
         }
     }
@@ -172,6 +191,36 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     }
     __syncthreads();
     double* q = const_cast<double*>(tg.q_global) + (int64_t)sample * tg.q_bstride;
+    if (tg.q_win) {
+        // per strip: q_win columns from the strip's lowest one (columns beyond the grid: zero, never read)
+        const int W = tg.q_win;
+        for (int oy = tid; oy < tg.out_len[1]; oy += kBlock) {
+            AxTab ty;
+            entry(1, oy, ty);
+            double* row = q + ((int64_t)oz * tg.out_len[1] + oy) * tg.q_strips * (4 * W);
+            for (int sidx = 0; sidx < tg.q_strips; ++sidx) {
+                const int c0 = c0s[sidx];
+                for (int k = 0; k < W; ++k) {
+                    const int j2 = c0 + k;
+                    double acc[3] = {0.0, 0.0, 0.0};
+                    if (j2 < ncpx) {
+#pragma unroll
+                        for (int h = 0; h < 3; ++h) {
+#pragma unroll
+                            for (int l = 0; l < 4; ++l)
+                                acc[h] += ty.w[l] * sP[h * nyx + ty.idx[l] * ncpx + j2];
+                        }
+                    }
+                    double* dst = row + ((int64_t)sidx * W + k) * 4;
+                    dst[0] = acc[0];
+                    dst[1] = acc[1];
+                    dst[2] = acc[2];
+                    dst[3] = 0.0;
+                }
+            }
+        }
+        return;
+    }
     for (int oy = tid; oy < tg.out_len[1]; oy += kBlock) {
         AxTab ty;
         entry(1, oy, ty);
@@ -996,9 +1045,27 @@ inline size_t label_list_bytes(const GridGeom& g)
     return (size_t)(cap + 32) * sizeof(int) + 64;
 }
 
+// the tile kernels keep a strip's 64 Q rows in LDS next to a 32 KiB box: up to this many control columns
+inline bool wide_grid(const GridGeom& g) { return kOffQ + q_bytes(g) + 16 + 32768 > (size_t)64 * 1024; }
+// wide grids: strips of kWideStripTiles tiles, the columns such a strip touches (conservative; <= kWideMaxWin or the
+// row kernel of deform_fast.hip takes the call)
+constexpr int kWideStripTiles = 4;
+constexpr int kWideMaxWin = 16;
+inline int wide_window(const GridGeom& g)
+{
+    const double r = g.in_len[2] > 1 ? (double)(g.ncp[2] - 1) / (double)(g.in_len[2] - 1) : 0.0;
+    return (int)std::floor(kWideStripTiles * kT * r) + 6;
+}
 inline size_t q_global_bytes(const GridGeom& g)
 {
-    return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 4 * (size_t)g.ncp[2];
+    size_t cols = (size_t)g.ncp[2];
+    if (wide_grid(g)) {
+        // Q[o_z][o_y][strip][window][4] (TileGeom::q_win)
+        const size_t strips = (size_t)((g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT));
+        const size_t per_strip = strips * (size_t)wide_window(g);
+        cols = per_strip > cols ? per_strip : cols;
+    }
+    return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 4 * cols;
 }
 
 // ================================================================================================
@@ -1208,6 +1275,24 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // launch still has a few workgroups per CU (even lengths for the gradient: its kernel walks 16-wide
     // tiles; the forward kernels go down to one tile per workgroup -- a tile is a serial chain of
     // coordinates, box reduction, staging and gather, ~8 us, and a 32^3 volume has 64 of them)
+    // Wide control grid: the level-1 kernels of deform_hot.hip on per-strip Q tables, in self-serve form, or nothing
+    // (hipErrorNotSupported before anything is launched: the row kernel of deform_fast.hip then takes the call --
+    // at 24.7 ms for the gradient of a 256^3 volume with a 16^3 grid, where this route takes 0.x ms)
+    const bool wide = wide_grid(g);
+    tg.q_win = tg.q_strip_vox = 0;
+    tg.q_strips = 1;
+    if (wide) {
+        if constexpr (!(std::is_same<T, float>::value && ORDER >= 1 && ORDER <= 3))
+            return hipErrorNotSupported;
+        const int win = wide_window(g);
+        const int64_t strips = (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT);
+        if (nb != 1 || tg.in_stride[2] != 1 || tg.out_stride[2] != 1 || win > kWideMaxWin || strips > 256 ||
+            ed_env("EDHIP_NO_HOT") || ed_env("EDHIP_WAVE") || ed_env("EDHIP_RECORDS"))
+            return hipErrorNotSupported;
+        tg.q_win = win;
+        tg.q_strip_vox = kWideStripTiles * kT;
+        tg.q_strips = (int)strips;
+    }
     if (v.out16) {
         // 16-bit output side: the level-1 kernels of deform_hot.hip (orders 1-3) in self-serve form, or nothing
         if constexpr (!(std::is_same<T, float>::value && ORDER >= 1 && ORDER <= 3))
@@ -1220,7 +1305,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // 159.4 -> 155.8 -- twice the workgroups for the tail of the launch to be dealt from; the gradient kernel, which
     // walks a strip in 16-wide tiles, prefers 8: 310.7 against 313.3 us; profiles/r04_bench_misc.txt)
     tg.strip_tiles = GRAD ? kStrip : kStrip / 2;
-    while (tg.strip_tiles > (GRAD ? 2 : 1) &&
+    if (wide)
+        tg.strip_tiles = kWideStripTiles;       // (the per-strip Q layout is made for exactly this length)
+    while (!wide && tg.strip_tiles > (GRAD ? 2 : 1) &&
            (int64_t)nb * tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles) < 1024)
         tg.strip_tiles >>= 1;
 #ifdef EDHIP_EXPERIMENTS
@@ -1483,14 +1570,16 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 hg.nstrips = tg.nstrips;
                 hg.total_strips = tg.nstrips * nb;
                 hg.ntiles = tg.ntiles;
-                hg.ncpx = tg.ncpx;
+                const int hot_cols = wide ? tg.q_win : tg.ncpx;       // (wide grids: the strip's window of columns)
+                hg.ncpx = hot_cols;
+                hg.q_strips = tg.q_strips;
                 hg.mode = tg.mode;
                 hg.has_affine = tg.has_affine;
                 hg.dbg = tg.dbg;
                 hg.self_serve = (self_serve && ORDER <= 3) ? 1 : 0;      // (orders 4 / 5: the one-wave kernels, which spill as before)
                 hg.io16 = v.out16;
-                if (v.out16)
-                    hg.self_serve = 1;          // (the spill levels do not know about 16-bit storage)
+                if (v.out16 || wide)
+                    hg.self_serve = 1;          // (the spill levels know neither 16-bit storage nor per-strip tables)
                 hg.cval = (float)ve.cval;
                 hg.nstep = ve.nstep;
                 hg.nsteps = ve.nsteps;
@@ -1504,14 +1593,14 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 size_t hlds = 0;
                 {
                     int off_small = 0;
-                    (void)hot_lds_bytes(GRAD, tg.ncpx, &hg.small_cap, &off_small, false);
+                    (void)hot_lds_bytes(GRAD, hot_cols, &hg.small_cap, &off_small, false);
                     if (large_boxes)
-                        hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box, true);
+                        hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, true);
                     if (!hlds)
-                        hlds = hot_lds_bytes(GRAD, tg.ncpx, &hg.box_cap, &hg.off_box, false);
+                        hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, false);
                     hg.hint = sh ? tg.hint : nullptr;
                 }
-                if (v.out16 && !hlds)
+                if ((v.out16 || wide) && !hlds)
                     return hipErrorNotSupported;        // (nothing has been launched yet)
                 hg.lds_grp = (int)((hlds + 15) & ~(size_t)15);
                 // EDHIP_FLAG_KEEP_BOXES / USE_BOXES: the forward kernel's tile boxes -- and, orders 1-3, its
@@ -1714,7 +1803,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         served_all = hg.self_serve != 0;
                         if (!GRAD && hg.boxes && key)
                             *key = cur;
-                    } else if (he != hipErrorNotSupported || v.out16)
+                    } else if (he != hipErrorNotSupported || v.out16 || wide)
                         e = he;
                 }
 
@@ -1853,9 +1942,14 @@ bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
     if (in_span >= 0x7fffffffLL || out_span >= 0x7fffffffLL)   // 32-bit element offsets inside a volume
         return false;
     // head + Q + box must stay within a 64 KiB block; the per-call Q table within 512 MiB; the
-    // tables kernel keeps 3 * ncp_y * ncp_x doubles in LDS
-    if (kOffQ + q_bytes(g) + 16 + 32768 > (size_t)64 * 1024)
-        return false;
+    // tables kernel keeps 3 * ncp_y * ncp_x doubles in LDS.  Wider control grids: float32 volumes of orders 1-3 with
+    // unit stride along x go to the level-1 kernels on per-strip Q tables (launch_tile), everything else to the
+    // row kernel of deform_fast.hip
+    if (wide_grid(g)) {
+        if (v.in_dtype != EDHIP_F32 || v.order < 1 || v.order > 3 || v.in_stride[2] != 4 || v.out_stride[2] != 4 ||
+            wide_window(g) > kWideMaxWin || (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT) > 256)
+            return false;
+    }
     if (q_global_bytes(g) > ((size_t)512 << 20) || 24 * (size_t)g.ncp[1] * (size_t)g.ncp[2] > 48 * 1024)
         return false;
     return true;

@@ -280,6 +280,12 @@ struct TileGeom {
     int strip_tiles;      // tiles per strip (8, or 4 / 2 for small outputs)
     int nstrips;
     int ncpx;             // control points along x = stride of one component row of Q
+    // Wide control grids (more columns than the 64 Q rows of a strip can hold in LDS next to a box): the tables
+    // kernel writes Q per x-STRIP -- only the q_win columns a strip of q_strip_vox voxels touches, starting at
+    // the strip's lowest column -- as Q[o_z][o_y][strip][q_win][4], and the x-table's column indices relative to
+    // that start.  The level-1 kernels of deform_hot.hip then see a grid of q_win columns; nobody else reads the
+    // tables of such a call (launch_tile runs it in self-serve form).  q_win == 0: the plain layout.
+    int q_win, q_strip_vox, q_strips;
     int box_cap;          // elements per LDS copy
     int off_ov;           // LDS byte offset of the overlay region (box | D, P)
     int in_stride[3];     // element strides (the tile kernels require < 2^31 elements per volume)
@@ -407,6 +413,7 @@ struct HotGeom {
     // straight from / to global memory
     int self_serve;
     int io16;                     // IOView::out16: the output side (img_r / img_w) holds 16-bit floats
+    int q_strips;                 // TileGeom::q_strips (1: the plain Q layout; ncpx then is the window width)
     float4* rec;
     long long rec_bstride;
     int rec_only;

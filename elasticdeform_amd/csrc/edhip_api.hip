@@ -452,6 +452,14 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
                 (void)hipGetLastError();
                 return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "16-bit output next to a float32 volume: outside the level-1 tile kernels");
             }
+            if (e == hipErrorNotSupported) {
+                // (a wide control grid the level-1 kernels declined -- batches, layouts: nothing was launched, the
+                // row kernel takes the call; the gradient block is cleared below if the tile path has not done it)
+                (void)hipGetLastError();
+                if (zero && !cleared[i] && clear_now(i) != hipSuccess)
+                    return fail(err, errlen, EDHIP_ERR_DEVICE, "clearing the gradient arrays failed");
+                e = launch_deform_fast(g, v, gradient != 0, stream);
+            }
             // (a tile path that declined the call -- or served it on a route without the tables' fill -- has
             // not touched the block: cleared now, and whoever takes the call next finds it cleared)
             // (zero_done unset behind an aligned block: the tables launch -- which precedes every scatter of the

@@ -266,6 +266,46 @@ def test_four_deformed_axes_on_the_fast_kernel(dtype):
                 np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * max(1.0, np.abs(gw).max()))
 
 
+@pytest.mark.parametrize("points", [(3, 4, 16), (6, 20, 31), (14, 14, 14), (2, 2, 40)])
+def test_wide_control_grids_run_on_the_tile_kernels(points):
+    """Control grids with more columns than a strip's Q rows can hold in LDS (more than 13 along x) used to fall to the
+    row kernel (a 256^3 gradient with a 16^3 grid: 24.7 ms).  float32 volumes of orders 1-3 now run on the level-1
+    tile kernels with per-strip Q tables (TileGeom::q_win): same results as ever (the tables hold the same values),
+    and the route is really taken (the library's level-1 timing hook fires); float64 and orders 4 / 5 keep the row
+    kernel."""
+    from elasticdeform_amd import _lib
+    rng = np.random.default_rng(sum(points))
+    shape = (40, 70, 150)
+    L = _lib.load()
+    for order in (1, 2, 3):
+        for mode, extra in (("mirror", {}), ("constant", dict(crop=(slice(3, 30), slice(0, 70), slice(20, 141)))),
+                            ("wrap", dict(affine=np.eye(3, 4) + rng.standard_normal((3, 4)) * 0.03))):
+            X = rng.random(shape).astype(np.float32)
+            disp = rng.standard_normal((3,) + points) * 1.5
+            kw = dict(order=order, mode=mode, cval=0.25, **extra)
+            want = orc.deform_grid(X, disp, **kw)
+            L.edhip_profile_dominant(1)
+            try:
+                got = ed.deform_grid(X, disp, **kw)
+                hot_us = L.edhip_profile_last_us()
+            finally:
+                L.edhip_profile_dominant(0)
+            np.testing.assert_allclose(got, want, **F32_TOL)
+            assert hot_us > 0, "the level-1 tile kernel did not run"
+            dY = rng.random(want.shape).astype(np.float32)
+            gw = orc.deform_grid_gradient(dY, disp, X_shape=shape, **kw)
+            gg = ed.deform_grid_gradient(dY, disp, X_shape=shape, **kw)
+            _f32_grad_check(gg, gw, orc.deform_grid_gradient(dY.astype(np.float64), disp, X_shape=shape, **kw))
+    # a channel axis, and the same call in float64 (row kernel) as a cross-check of the two routes
+    X = rng.random((2,) + shape).astype(np.float32)
+    disp = rng.standard_normal((3,) + points) * 1.5
+    kw = dict(order=3, mode="mirror", axis=(1, 2, 3))
+    g32 = ed.deform_grid(X, disp, **kw)
+    g64 = ed.deform_grid(X.astype(np.float64), disp, **kw)
+    np.testing.assert_allclose(g32, g64, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(g64, orc.deform_grid(X.astype(np.float64), disp, **kw), rtol=1e-11, atol=1e-11)
+
+
 def test_integer_gradient_is_bit_exact():
     """*(T*)p += (T)t accumulates in the array dtype (deform.c:309-312): integer atomics are
     associative, so even the scatter-add is bit-reproducible for integer gradients."""
