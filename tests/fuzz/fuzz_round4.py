@@ -4,6 +4,7 @@
 * device-side crop window (edhip_source_window + windowed filter passes), forced to engage whatever the volume's size:
   float32 / float64 volumes with lines of 64..200 samples, random crops, all five modes, affine maps, a channel axis,
   several inputs per call -- forward against the oracle, gradient against the exact gradient (fp64 oracle);
+* wide control grids (14..47 columns along x) on the per-strip Q tables, any shape / crop / affine map, orders 1-3;
 * 16-bit float volumes that stay in 16 bits (set_reduced_precision): forward bit-equal to the float32 pipeline narrowed
   by a cast, gradient within half a 16-bit ulp of it -- and equal with the direct route switched off."""
 import importlib
@@ -26,7 +27,7 @@ dev = torch.device("cuda", 0)
 fails = 0
 saved = (dgm.CROP_WINDOW_MIN_SAVING, dgm.CROP_WINDOW_MAX_FRACTION)
 for case in range(ncases):
-    kind = "window" if rng.integers(0, 3) else "half"
+    kind = ["window", "window", "half", "wide"][int(rng.integers(0, 4))]
     shape = tuple(int(rng.integers(64, 150)) for _ in range(3))
     if kind == "half":
         shape = shape[:2] + (4 * (shape[2] // 4),)
@@ -83,6 +84,39 @@ for case in range(ncases):
                     "gradient err vs exact %.3e, reference's own %.3e (scale %.3g)" % (egpu, eref, gs)
             else:
                 assert float(np.abs(gg - truth).max()) <= 1e-10 * gs, "float64 gradient"
+        elif kind == "wide":
+            # control grids too wide for a strip's Q rows in LDS: per-strip tables (TileGeom::q_win), or the row kernel
+            shape = tuple(int(rng.integers(20, 120)) for _ in range(3))
+            pts = (int(rng.integers(2, 20)), int(rng.integers(2, 20)), int(rng.integers(14, 48)))
+            order = int(rng.integers(1, 4))
+            kw["order"] = order
+            if rng.integers(0, 3) == 0:
+                crop = []
+                for n in shape:
+                    a = int(rng.integers(0, max(1, n // 2)))
+                    crop.append(slice(a, int(rng.integers(a + 1, n + 1))))
+                kw["crop"] = tuple(crop)
+            if rng.integers(0, 3) == 0:
+                kw["affine"] = np.eye(3, 4) + rng.standard_normal((3, 4)) * 0.05
+            kw["prefilter"] = bool(rng.integers(0, 2))
+            desc = "case %d wide shape=%s pts=%s o%d %s sigma=%g %s" % (
+                case, shape, pts, order, mode, sigma, {k: v for k, v in kw.items() if k in ("crop", "prefilter")})
+            disp = rng.standard_normal((3,) + pts) * min(sigma, 3.0)
+            dd = torch.from_numpy(disp).to(dev)
+            X = rng.random(shape).astype(np.float32)
+            want = orc.deform_grid(X, disp, **kw)
+            got = ed.deform_grid(torch.from_numpy(X).to(dev), dd, **kw).cpu().numpy()
+            err = float(np.abs(got - want).max()) if want.size else 0.0
+            assert err <= 2e-5, "forward max abs err %.3e" % err
+            dY = rng.random(want.shape).astype(np.float32)
+            gg = ed.deform_grid_gradient(torch.from_numpy(dY).to(dev), dd, X_shape=shape, **kw).cpu().numpy()
+            gw = orc.deform_grid_gradient(dY, disp, X_shape=shape, **kw)
+            truth = orc.deform_grid_gradient(dY.astype(np.float64), disp, X_shape=shape, **kw)
+            gs = max(1.0, float(np.abs(truth).max()))
+            eref = float(np.abs(gw.astype(np.float64) - truth).max())
+            egpu = float(np.abs(gg.astype(np.float64) - truth).max())
+            assert egpu <= 4 * eref + 8 * np.finfo(np.float32).eps * gs, \
+                "gradient err vs exact %.3e, reference's own %.3e (scale %.3g)" % (egpu, eref, gs)
         else:
             tdt = torch.bfloat16 if rng.integers(0, 2) else torch.float16
             ulp = 2.0 ** -7 if tdt == torch.bfloat16 else 2.0 ** -10
