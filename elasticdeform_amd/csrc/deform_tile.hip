@@ -1281,17 +1281,27 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     const bool wide = wide_grid(g);
     tg.q_win = tg.q_strip_vox = 0;
     tg.q_strips = 1;
+    // (orders 4 / 5: the one-wave kernels of deform_wave.hip read their Q columns from global memory as they walk --
+    // no LDS limit on the grid's width: plain tables, and what they cannot hold goes straight to the direct level,
+    // because the level-2 kernel stages Q rows like the others.  256^3, 16^3 grid, order 5 on the row kernel:
+    // forward 4.7 ms, gradient 83 ms)
+    constexpr bool kWaveOrder = std::is_same<T, float>::value && ORDER >= 4;
+    const bool wide_wave = wide && kWaveOrder;
     if (wide) {
-        if constexpr (!(std::is_same<T, float>::value && ORDER >= 1 && ORDER <= 3))
+        if constexpr (!(std::is_same<T, float>::value && ORDER >= 1))
             return hipErrorNotSupported;
-        const int win = wide_window(g);
-        const int64_t strips = (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT);
-        if (nb != 1 || tg.in_stride[2] != 1 || tg.out_stride[2] != 1 || win > kWideMaxWin || strips > 256 ||
-            ed_env("EDHIP_NO_HOT") || ed_env("EDHIP_WAVE") || ed_env("EDHIP_RECORDS"))
+        if (nb != 1 || tg.in_stride[2] != 1 || tg.out_stride[2] != 1 || ed_env("EDHIP_NO_HOT") || ed_env("EDHIP_WAVE") ||
+            ed_env("EDHIP_RECORDS"))
             return hipErrorNotSupported;
-        tg.q_win = win;
-        tg.q_strip_vox = kWideStripTiles * kT;
-        tg.q_strips = (int)strips;
+        if (!wide_wave) {
+            const int win = wide_window(g);
+            const int64_t strips = (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT);
+            if (win > kWideMaxWin || strips > 256)
+                return hipErrorNotSupported;
+            tg.q_win = win;
+            tg.q_strip_vox = kWideStripTiles * kT;
+            tg.q_strips = (int)strips;
+        }
     }
     if (v.out16) {
         // 16-bit output side: the level-1 kernels of deform_hot.hip (orders 1-3) in self-serve form, or nothing
@@ -1305,9 +1315,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // 159.4 -> 155.8 -- twice the workgroups for the tail of the launch to be dealt from; the gradient kernel, which
     // walks a strip in 16-wide tiles, prefers 8: 310.7 against 313.3 us; profiles/r04_bench_misc.txt)
     tg.strip_tiles = GRAD ? kStrip : kStrip / 2;
-    if (wide)
+    if (tg.q_win)
         tg.strip_tiles = kWideStripTiles;       // (the per-strip Q layout is made for exactly this length)
-    while (!wide && tg.strip_tiles > (GRAD ? 2 : 1) &&
+    while (!tg.q_win && tg.strip_tiles > (GRAD ? 2 : 1) &&
            (int64_t)nb * tg.tiles[0] * tg.tiles[1] * ((tg.tiles[2] + tg.strip_tiles - 1) / tg.strip_tiles) < 1024)
         tg.strip_tiles >>= 1;
 #ifdef EDHIP_EXPERIMENTS
@@ -1570,7 +1580,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 hg.nstrips = tg.nstrips;
                 hg.total_strips = tg.nstrips * nb;
                 hg.ntiles = tg.ntiles;
-                const int hot_cols = wide ? tg.q_win : tg.ncpx;       // (wide grids: the strip's window of columns)
+                const int hot_cols = tg.q_win ? tg.q_win : tg.ncpx;       // (wide grids: the strip's window of columns)
                 hg.ncpx = hot_cols;
                 hg.q_strips = tg.q_strips;
                 hg.mode = tg.mode;
@@ -1600,7 +1610,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, false);
                     hg.hint = sh ? tg.hint : nullptr;
                 }
-                if ((v.out16 || wide) && !hlds)
+                if ((v.out16 || (wide && !wide_wave)) && !hlds)
                     return hipErrorNotSupported;        // (nothing has been launched yet)
                 hg.lds_grp = (int)((hlds + 15) & ~(size_t)15);
                 // EDHIP_FLAG_KEEP_BOXES / USE_BOXES: the forward kernel's tile boxes -- and, orders 1-3, its
@@ -1747,7 +1757,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 if (const char* wm = ed_env("EDHIP_WAVE"))        // 1 forward, 2 gradient, 3 both, 0 neither
                     wave_mode = atoi(wm);
 #endif
-                if (hlds && !hot_done && (wave_mode & (GRAD ? 2 : 1))) {
+                if ((hlds || wide_wave) && !hot_done && (wave_mode & (GRAD ? 2 : 1))) {
                     HotGeom wg = hg;
                     wg.self_serve = 0;
                     wg.strip_tiles = 4;
@@ -1792,10 +1802,12 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                             hot_done = wave_done = true;
                             if (!GRAD && hg.boxes && key)
                                 *key = cur;
-                        } else if (he != hipErrorNotSupported)
+                        } else if (he != hipErrorNotSupported || wide_wave)
                             e = he;
                     }
                 }
+                if (wide_wave && !wave_done && e == hipSuccess)
+                    e = hipErrorNotSupported;        // (no other level-1 kernel can take a grid this wide)
                 if (hlds && !wave_done && !hot_done && e == hipSuccess) {
                     const hipError_t he = launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
                     if (he == hipSuccess) {
@@ -1860,7 +1872,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     t2.box_cap = (int)((box2 - (GRAD ? 64 : 0)) / sizeof(T));      // gradient: cells of sizeof(T) + wave sums
     const size_t lds2 = t2.off_ov + box2;
     const unsigned n2 = (unsigned)(ntiles * nb < wgs2 ? ntiles * nb : wgs2);
-    const bool skip_l2 = ed_env("EDHIP_SKIP_L2") != nullptr;      // debugging aid
+    const bool skip_l2 = ed_env("EDHIP_SKIP_L2") != nullptr || wide_wave;      // (debugging aid; wide grids: see above)
     if (served_all)
         return e;               // level 1 has served every tile
     if (e == hipSuccess && !skip_l2) {
@@ -1946,8 +1958,10 @@ bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
     // unit stride along x go to the level-1 kernels on per-strip Q tables (launch_tile), everything else to the
     // row kernel of deform_fast.hip
     if (wide_grid(g)) {
-        if (v.in_dtype != EDHIP_F32 || v.order < 1 || v.order > 3 || v.in_stride[2] != 4 || v.out_stride[2] != 4 ||
-            wide_window(g) > kWideMaxWin || (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT) > 256)
+        if (v.in_dtype != EDHIP_F32 || v.order < 1 || v.in_stride[2] != 4 || v.out_stride[2] != 4)
+            return false;
+        if (v.order <= 3 &&
+            (wide_window(g) > kWideMaxWin || (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT) > 256))
             return false;
     }
     if (q_global_bytes(g) > ((size_t)512 << 20) || 24 * (size_t)g.ncp[1] * (size_t)g.ncp[2] > 48 * 1024)

@@ -4,7 +4,7 @@
 * device-side crop window (edhip_source_window + windowed filter passes), forced to engage whatever the volume's size:
   float32 / float64 volumes with lines of 64..200 samples, random crops, all five modes, affine maps, a channel axis,
   several inputs per call -- forward against the oracle, gradient against the exact gradient (fp64 oracle);
-* wide control grids (14..47 columns along x) on the per-strip Q tables, any shape / crop / affine map, orders 1-3;
+* wide control grids (14..47 columns along x) on the per-strip Q tables, any shape / crop / affine map, orders 1-5;
 * 16-bit float volumes that stay in 16 bits (set_reduced_precision): forward bit-equal to the float32 pipeline narrowed
   by a cast, gradient within half a 16-bit ulp of it -- and equal with the direct route switched off."""
 import importlib
@@ -88,7 +88,7 @@ for case in range(ncases):
             # control grids too wide for a strip's Q rows in LDS: per-strip tables (TileGeom::q_win), or the row kernel
             shape = tuple(int(rng.integers(20, 120)) for _ in range(3))
             pts = (int(rng.integers(2, 20)), int(rng.integers(2, 20)), int(rng.integers(14, 48)))
-            order = int(rng.integers(1, 4))
+            order = int(rng.integers(1, 6))      # 1-3: per-strip tables; 4 / 5: the one-wave kernels on plain tables
             kw["order"] = order
             if rng.integers(0, 3) == 0:
                 crop = []

@@ -296,6 +296,17 @@ def test_wide_control_grids_run_on_the_tile_kernels(points):
             gw = orc.deform_grid_gradient(dY, disp, X_shape=shape, **kw)
             gg = ed.deform_grid_gradient(dY, disp, X_shape=shape, **kw)
             _f32_grad_check(gg, gw, orc.deform_grid_gradient(dY.astype(np.float64), disp, X_shape=shape, **kw))
+    # orders 4 / 5: the one-wave kernels read their Q columns from global memory -- plain tables, no level 2
+    for order in (4, 5):
+        X = rng.random(shape).astype(np.float32)
+        disp = rng.standard_normal((3,) + points) * 1.5
+        kw = dict(order=order, mode="mirror")
+        np.testing.assert_allclose(ed.deform_grid(X, disp, **kw), orc.deform_grid(X, disp, **kw), **F32_TOL)
+        dY = rng.random(shape).astype(np.float32)
+        # (no flat bound: at these orders the reference's own float32 transposed prefilter is 1e-4 from the exact
+        # gradient -- see _f32_grad_check)
+        _f32_grad_check(ed.deform_grid_gradient(dY, disp, **kw), orc.deform_grid_gradient(dY, disp, **kw),
+                        orc.deform_grid_gradient(dY.astype(np.float64), disp, **kw), flat=False)
     # a channel axis, and the same call in float64 (row kernel) as a cross-check of the two routes
     X = rng.random((2,) + shape).astype(np.float32)
     disp = rng.standard_normal((3,) + points) * 1.5
