@@ -106,6 +106,34 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
         if (tg.label_list)
             tg.label_list[0] = 0;
     }
+    if (oz == 0 && tg.slack) {
+        // margin of K1's sampled tile boxes (deform_k1.hip): a fraction of the rigorous bound of multilinear
+        // interpolation between samples <= 3 voxels apart, 9/8 * sum_k r_k^2 max |second difference| with
+        // |second difference| <= 4 max |D_f|; slack_scale holds everything but the maximum
+        __shared__ double smax[3][kBlock / 64];
+        const int ntot = (int)g.ncp[0] * nyx;
+        for (int h = 0; h < 3; ++h) {
+            double m = 0.0;
+            for (int e = tid; e < ntot; e += kBlock) {
+                const int j0 = e / nyx, j = e - j0 * nyx;
+                const int j1 = j / ncpx, j2 = j - j1 * ncpx;
+                m = fmax(m, fabs(load_as_double(disp + g.disp_stride[0] * h + g.disp_stride[1] * j0 +
+                                                    g.disp_stride[2] * j1 + g.disp_stride[3] * j2, g.disp_dtype)));
+            }
+            for (int sh = 32; sh >= 1; sh >>= 1)
+                m = fmax(m, __shfl_xor(m, sh));
+            if ((tid & 63) == 0)
+                smax[h][tid >> 6] = m;
+        }
+        __syncthreads();
+        if (tid < 3) {
+            double m = 0.0;
+            for (int w = 0; w < kBlock / 64; ++w)
+                m = fmax(m, smax[tid][w]);
+            const double sl = tg.slack_scale * m;
+            tg.slack[sample * 4 + tid] = sl >= 0.02 ? (sl <= 0.75 ? sl : 0.75) : 0.02;     // (NaN -> 0.02)
+        }
+    }
     auto entry = [&](int a, int oi, AxTab& t) {
         const double cp = control_coordinate(g.ncp[a], (int64_t)oi + g.off[a], g.in_len[a]);
         const int64_t start = window_start(cp, 3);
@@ -1056,6 +1084,9 @@ inline int wide_window(const GridGeom& g)
     const double r = g.in_len[2] > 1 ? (double)(g.ncp[2] - 1) / (double)(g.in_len[2] - 1) : 0.0;
     return (int)std::floor(kWideStripTiles * kT * r) + 6;
 }
+// x table + the per-sample margins of K1's sampled boxes (TileGeom::slack) behind it
+inline size_t xt_only_bytes(const GridGeom& g) { return (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63; }
+inline size_t xt_block_bytes(const GridGeom& g, int nbatch) { return xt_only_bytes(g) + (((size_t)nbatch * 32 + 63) & ~(size_t)63); }
 inline size_t q_global_bytes(const GridGeom& g)
 {
     size_t cols = (size_t)g.ncp[2];
@@ -1361,7 +1392,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     }
     // scratch: first-level spill list | second-level spill list | x table | Q
     const size_t list_bytes = (sizeof(int) * ((size_t)ntiles * nb + 1) + 63) & ~(size_t)63;
-    const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
+    const size_t xt_bytes = xt_block_bytes(g, nb);
     const size_t q_all = ((q_global_bytes(g) * (size_t)nb) + 63) & ~(size_t)63;
     hipError_t e = hipSuccess;
     // (edhip_deform reserved deform_tile_workspace_bytes() up front, so this does not move the
@@ -1379,6 +1410,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     tg.hint_host = nullptr;
     tg.hint_seq = 0;
     tg.xt_global = (const AxTab*)((char*)ws + 2 * list_bytes);
+    tg.slack = nullptr;          // (set by the route that reads it: K1 of deform_k1.hip)
+    tg.slack_scale = 0.0;
     tg.q_global = (const double*)((char*)ws + 2 * list_bytes + xt_bytes);
     tg.worklist = nullptr;
     tg.spill = list_a;
@@ -1601,7 +1634,32 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 for (int k = 0; k < 12; ++k)
                     hg.affine[k] = tg.affine[k];
                 size_t hlds = 0;
-                {
+                // forward, orders 1-3: K1 of round 5 (deform_k1.hip: sampled tile boxes, fast tiles); the profiling
+                // build can still run the kernel it replaced (EDHIP_K1_OLD)
+                [[maybe_unused]] const bool k1_new = !GRAD && ORDER <= 3 && tg.strip_tiles <= 4 && !ed_env("EDHIP_K1_OLD") &&
+                                                     !ed_env("EDHIP_RECORDS");
+                if (k1_new) {
+                    int off_small = 0;
+                    (void)k1_lds_bytes(hot_cols, &hg.small_cap, &off_small, false);
+                    if (large_boxes)
+                        hlds = k1_lds_bytes(hot_cols, &hg.box_cap, &hg.off_box, true);
+                    if (!hlds)
+                        hlds = k1_lds_bytes(hot_cols, &hg.box_cap, &hg.off_box, false);
+                    hg.hint = sh ? tg.hint : nullptr;
+                    // margin of the sampled boxes: 15 % of the rigorous interpolation bound (see the tables kernel)
+                    double r2 = 0.0;
+                    for (int k = 0; k < 3; ++k) {
+                        const double r = g.in_len[k] > 1 ? (double)(g.ncp[k] - 1) / (double)(g.in_len[k] - 1) : 0.0;
+                        r2 += r * r;
+                    }
+                    tg.slack = (double*)((char*)ws + 2 * list_bytes + xt_only_bytes(g));
+                    tg.slack_scale = 0.15 * 1.125 * 4.0 * r2;
+                    hg.slack = tg.slack;
+#ifdef EDHIP_EXPERIMENTS
+                    if (const char* pp = ed_env("EDHIP_DEBUG_PTR"))
+                        hg.dbgbuf = (unsigned long long*)strtoull(pp, nullptr, 16);
+#endif
+                } else {
                     int off_small = 0;
                     (void)hot_lds_bytes(GRAD, hot_cols, &hg.small_cap, &off_small, false);
                     if (large_boxes)
@@ -1809,7 +1867,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 if (wide_wave && !wave_done && e == hipSuccess)
                     e = hipErrorNotSupported;        // (no other level-1 kernel can take a grid this wide)
                 if (hlds && !wave_done && !hot_done && e == hipSuccess) {
-                    const hipError_t he = launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
+                    const hipError_t he = k1_new ? launch_k1_level1(hg, ORDER, nblk, hlds, stream)
+                                                 : launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
                     if (he == hipSuccess) {
                         hot_done = true;
                         served_all = hg.self_serve != 0;
@@ -1928,7 +1987,7 @@ size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch)
     for (int k = 0; k < 3; ++k)
         ntiles *= (g.out_len[k] + kT - 1) / kT;
     const size_t list_bytes = (sizeof(int) * ((size_t)ntiles * nbatch + 1) + 63) & ~(size_t)63;
-    const size_t xt_bytes = (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63;
+    const size_t xt_bytes = xt_block_bytes(g, nbatch);
     const size_t q = q_global_bytes(g);
     if (q > ((size_t)512 << 20))
         return kWorkspaceGridBytes;

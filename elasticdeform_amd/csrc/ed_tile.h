@@ -49,6 +49,7 @@ struct HotParams {
     long long out_step_stride[8];
     int nstep;
     int pad_;
+    double slack[3];       // K1: margin of the sampled tile boxes (HotGeom::slack), per axis
 };
 static_assert(sizeof(HotParams) <= 416, "HotParams must fit its LDS slot");
 
@@ -318,6 +319,10 @@ struct TileGeom {
     int* label_list;      // label kernel: [0] = count, [1..cap] = linear ids of near-tie voxels (or nullptr)
     int label_cap;
     const int* worklist;  // second-level pass: [0] = count, [1..] = tile ids to process (else nullptr)
+    // K1's sampled tile boxes (deform_k1.hip): block (0, sample) of the tables kernel leaves the margin they are
+    // widened by, per component, in slack[sample * 4 + h] = clamp(slack_scale * max |D_f[h]|, 0.02, 0.75) voxels
+    double* slack;
+    double slack_scale;
     const double* q_global;   // [O_z][O_y][ncpx][4]: displacement contracted over z and y (component padded to 4)
     const AxTab* xt_global;   // [O_x]: cubic weights / control indices along x (x 4: Q element offsets)
     int dbg;              // ablation switches for profiling (EDHIP_TILE_DBG), 0 in production
@@ -383,6 +388,7 @@ struct HotGeom {
     float* img_w;             // forward: destination
     const double* q;          // per-call tables (see tile_tables_kernel)
     const AxTab* xt;
+    const double* slack;      // TileGeom::slack
     int* spill;               // tiles the LDS box cannot hold -> the general kernels
     int* hint;                // [0]: count of the tiles whose box exceeds small_cap elements (or nullptr)
     int small_cap;            // box_cap of the standard configuration (== box_cap unless the large boxes are in use)
@@ -447,6 +453,11 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, bool l
 hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream);
 size_t hot_grad2_lds_bytes(int* box_cap, bool large = false);
 hipError_t launch_hot_grad2(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream);
+
+// K1 of round 5 (deform_k1.hip): float32 forward, orders 1-3, sampled tile boxes; same argument block, strips of at
+// most 4 tiles; hipErrorNotSupported (nothing launched) otherwise
+size_t k1_lds_bytes(int ncpx, int* box_cap, int* off_box, bool large = false);
+hipError_t launch_k1_level1(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream);
 
 // one-wavefront-per-tile kernels (deform_wave.hip): same argument block; `strip_tiles`, `strips_x`,
 // `nstrips`, `total_strips` describe the strips of the 64-thread workgroups, `box_cap` the floats /
