@@ -32,6 +32,8 @@
 // the same sums, bit for bit, as every other level (crop identity full[crop] == cropped, README.md:113).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ed_device.h"
 #include "ed_params.h"
 #include "ed_tile.h"
@@ -47,7 +49,10 @@ __device__ unsigned long long g_k1_stats[8];
 
 namespace {
 
-constexpr int kK1Strip = 4;                              // tiles per strip, at most
+#ifndef ED_K1_STRIP
+#define ED_K1_STRIP 4
+#endif
+constexpr int kK1Strip = ED_K1_STRIP;                    // tiles per strip, at most
 constexpr int kK1Tab = 0;                                // AxTab[kK1Strip * 8]; idx = byte offset of the control column
 constexpr int kK1Rec = kK1Tab + kK1Strip * kT * 48;      // TileRec[kK1Strip]
 constexpr int kK1Red = kK1Rec + kK1Strip * 64;           // int[kK1Strip][8]: exact boxes of the general tiles
@@ -64,18 +69,19 @@ struct TileRec {
     int pitch;          // floats per box row: 16 or 48 (0: too wide)
     int nrows;          // ext[0] * ext[1]
     int plane;          // ext[1] * pitch
-    int goff;           // element offset of the box origin in the volume (meaningful for kTDma)
+    int goff;           // element offset of the box origin in the volume (meaningful for kTDma + kTZYin)
     int pad_[5];
 };
 static_assert(sizeof(TileRec) == 64, "TileRec layout");
 enum : int {
     kTAny = 1,          // some voxel of the tile is gathered
     kTStaged = 2,       // ... and the box fits: staged, gathered from LDS
-    kTFast = 4,         // full tile, coordinates inside the array: no boundary tests, sampled box, checked
-    kTDma = 8,          // the box (and the shifted copy's extra element) lies inside the volume: LDS-DMA
+    kTFast = 4,         // full tile, coordinates inside the array: no boundary tests
+    kTDma = 8,          // the box rows (and the shifted copy's extra element) lie inside the array along x: LDS-DMA
     kTXin = 16,         // the box lies inside the array along x
-    kTEdge = 32,        // general tile: its exact box is still to be reduced
+    kTZYin = 32,        // ... and along z and y: no mirror map of plane / row indices while staging
     kTUnfit = 64,       // the box does not fit (self-serve: k1_fix gathers the tile from global memory)
+    kTGen = 128,        // general tile (array faces, partial tiles): boundary map, constant / valid flags
 };
 
 #define ED_RED6(CTRL)                                      \
@@ -297,13 +303,15 @@ __device__ __forceinline__ void k1_derive(const HotGeom& hg, const K1Strip& sp, 
     const bool sane = any && ext[0] <= 1024u && ext[1] <= 1024u;
     const int nrows = sane ? (int)(ext[0] * ext[1]) : 0;
     const bool fits = sane && pitch > 0 && nrows * pitch <= hg.box_cap;
-    // the box and the shifted copy's extra element lie inside the volume: no mirror map while staging
-    const bool dma = fits && lo[0] >= 0 && lo[0] + (int)ext[0] <= hg.in_len[0] && lo[1] >= 0 &&
-                     lo[1] + (int)ext[1] <= hg.in_len[1] && lo[2] >= 0 && lo[2] + pitch + 1 <= hg.in_len[2];
+    // rows (with the shifted copy's extra element) inside the array along x: LDS-DMA, whole rows; planes / rows
+    // beyond the array's z / y ends are mirror-mapped as planes / rows
+    const bool dma = fits && lo[2] >= 0 && lo[2] + pitch + 1 <= hg.in_len[2];
     const bool xin = fits && lo[2] >= 0 && lo[2] + (int)ext[2] <= hg.in_len[2];
+    const bool zyin = fits && lo[0] >= 0 && lo[0] + (int)ext[0] <= hg.in_len[0] && lo[1] >= 0 &&
+                      lo[1] + (int)ext[1] <= hg.in_len[1];
     TileRec r;
     r.flags = (any ? kTAny : 0) | (fits ? kTStaged : 0) | (fast && fits ? kTFast : 0) | (dma ? kTDma : 0) |
-              (xin ? kTXin : 0) | (any && !fits ? kTUnfit : 0);
+              (xin ? kTXin : 0) | (zyin ? kTZYin : 0) | (any && !fits ? kTUnfit : 0) | (fast ? 0 : kTGen);
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
         r.b0[h] = lo[h];
@@ -312,7 +320,7 @@ __device__ __forceinline__ void k1_derive(const HotGeom& hg, const K1Strip& sp, 
     r.pitch = pitch;
     r.nrows = nrows;
     r.plane = (int)ext[1] * pitch;
-    r.goff = dma ? lo[0] * hg.vol_sz + lo[1] * hg.vol_sy + lo[2] : 0;
+    r.goff = (dma && zyin) ? lo[0] * hg.vol_sz + lo[1] * hg.vol_sy + lo[2] : 0;
     int4* dst = reinterpret_cast<int4*>(rec + t);
     dst[0] = make_int4(r.b0[0], r.b0[1], r.b0[2], r.flags);
     dst[1] = make_int4(r.ext[0], r.ext[1], r.ext[2], r.pitch);
@@ -445,8 +453,8 @@ __device__ __forceinline__ void k1_fix(const HotGeom& hg, const K1Strip& sp, cha
     for (int ti = 0; ti < sp.ntile; ++ti) {
         const int flags = uni(rec[ti].flags);
         const bool whole = (flags & kTUnfit) != 0;
-        if (!whole && !(missed && (flags & kTFast)))
-            continue;
+        if (!whole && !missed)
+            continue;        // (every tile the loops took: also a general tile without a box -- all samples constant)
         const int ox = (sp.tx0 + ti) * kT + xx;
         XEnt xe;
 #pragma unroll 1
@@ -471,10 +479,15 @@ __device__ __forceinline__ void k1_fix(const HotGeom& hg, const K1Strip& sp, cha
             float fr[3];
             const bool cst = k1_coords<ORDER, AFFINE>(hg, hp, d, b, P, st, fr, raw);
             if (!whole) {
-                // The loop worked with the RAW window start (a fast tile's voxels skip the range test), and it
-                // served the voxel iff that window lay inside the box: the box of a fast tile holds only windows
-                // of coordinates inside the array (see the kernel), so raw == mapped for every voxel skipped here.
-                const int rz = raw[0] - rec[ti].b0[0], ry = raw[1] - rec[ti].b0[1], rx = raw[2] - rec[ti].b0[2];
+                // A fast tile's voxels worked with the RAW window start (no range test), a general tile's with the
+                // mapped one; the loop served the voxel iff that window lay inside the box (a constant voxel of a
+                // general tile needs no window).  The box of a fast tile holds only windows of coordinates inside
+                // the array (see the kernel), so raw == mapped for every voxel of a fast tile skipped here.
+                const bool gen = (flags & kTGen) != 0;
+                if (gen && cst)
+                    continue;
+                const int rz = (gen ? st[0] : raw[0]) - rec[ti].b0[0], ry = (gen ? st[1] : raw[1]) - rec[ti].b0[1],
+                          rx = (gen ? st[2] : raw[2]) - rec[ti].b0[2];
                 const bool inside = rz >= 0 && rz + NT <= rec[ti].ext[0] && ry >= 0 && ry + NT <= rec[ti].ext[1] &&
                                     rx >= 0 && rx + NT + kPadX <= rec[ti].ext[2];
                 if (inside)
@@ -531,6 +544,7 @@ __device__ __forceinline__ void k1_fix(const HotGeom& hg, const K1Strip& sp, cha
 struct VoxState {
     int addr[2];          // LDS byte address of tap (0, 0, 0) in the copy that matches the window's parity
     float frac[2][3];
+    int flg;              // general tiles: bit i = voxel i is gathered, bit 2 + i = voxel i is stored
 };
 
 template <int ORDER, bool AFFINE, bool OUT16, int SPLIT>
@@ -551,7 +565,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
     const int wave = tid >> 6;
     // profiling build, EDHIP_DEBUG_PTR: per-wave cycle sums of the loop's intervals (tools/k1_phases.py)
 #ifdef EDHIP_EXPERIMENTS
-    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
     long long tmark = hg.dbgbuf ? (long long)__builtin_readcyclecounter() : 0;
 #define ED_TICK(K) do { if (hg.dbgbuf) { const long long now_ = __builtin_readcyclecounter(); tacc[K] += now_ - tmark; tmark = now_; } } while (0)
 #else
@@ -561,7 +575,6 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
 
     const HotParams* hp = reinterpret_cast<const HotParams*>(smem + kK1Hot);
     TileRec* rec = reinterpret_cast<TileRec*>(smem + kK1Rec);
-    int* red = reinterpret_cast<int*>(smem + kK1Red);
     const int boxbase = hg.off_box;                        // LDS byte offset of the first copy
     const int odd_shift = (hg.box_cap - 1) * 4;            // first copy -> second copy, one element back
     float* box0 = reinterpret_cast<float*>(smem + hg.off_box);
@@ -585,13 +598,101 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
                                      fma(hp->affine[h * 4 + 1], (double)oy, hp->affine[h * 4 + 3] + hp->offd[h]))
                                : 0.0;
 
+    // ---- the boxes of the strip's tiles -----------------------------------------------------------------------
+    // wave t samples tile t: the coordinate at 4 x 4 x 4 of its voxels, widened by the margin
+    for (int t = wave; t < ntile; t += 4) {
+        const int nz = min(kT, hg.out_len[0] - sp.tz * kT), ny = min(kT, hg.out_len[1] - sp.ty * kT),
+                  nx = min(kT, hg.out_len[2] - (sp.tx0 + t) * kT);
+        const int pz = ((lane >> 4) * (nz - 1)) / 3, py = (((lane >> 2) & 3) * (ny - 1)) / 3, px = ((lane & 3) * (nx - 1)) / 3;
+        XEnt xe;
+        k1_xent(smem, t * kT + px, (pz * kT + py) * 32, xe);
+        double d[3];
+        k1_disp<0>(smem, xe, d);
+        const int o[3] = {sp.tz * kT + pz, sp.ty * kT + py, (sp.tx0 + t) * kT + px};
+        double c[3];
+        int lo[3], hi[3];
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            if (AFFINE)
+                c[h] = fma(hp->affine[h * 4 + 2], (double)o[2],
+                           fma(hp->affine[h * 4 + 0], (double)o[0],
+                               fma(hp->affine[h * 4 + 1], (double)o[1], hp->affine[h * 4 + 3] + hp->offd[h]))) + d[h];
+            else
+                c[h] = (double)(o[h] + hg.off[h]) + d[h];
+            const double cr = (ORDER & 1) ? c[h] : c[h] + 0.5;
+            lo[h] = (int)floor(cr - hp->slack[h]);
+            hi[h] = (int)floor(cr + hp->slack[h]);
+        }
+        wave_box63(lo, hi);
+        // fast: a full tile whose every coordinate, margin included, is one coord_axis_fast accepts
+        int rlo[3], rhi[3];
+        bool fast = nz == kT && ny == kT && nx == kT && !ED_DBG(hg.dbg, 1 << 16);
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            rlo[h] = __builtin_amdgcn_readlane(lo[h], 63);
+            rhi[h] = __builtin_amdgcn_readlane(hi[h], 63);
+            fast = fast && rlo[h] >= ((ORDER & 1) ? 0 : 1) && rhi[h] <= hg.in_len[h] - 2;
+        }
+        if (!fast) {
+            // general tile: the range of the MAPPED coordinate over the samples (a sample that maps to the constant
+            // has no window); where the raw range straddles an end of the array, the end itself is included --
+            // the fold of 'mirror' / 'reflect', the clamp of 'nearest'.  ('wrap' jumps to the far end: such a
+            // box does not fit, and k1_fix or the spill levels take the tile.)
+            bool cst = false;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                double m = c[h];
+                if (!(m >= 0.0 && m <= hp->last[h]))
+                    m = map_coordinate_fast(m, hg.in_len[h], hg.mode, hp->period[h], hp->inv_period[h]);
+                cst = cst || !(m > -1.0);
+                const double mr = (ORDER & 1) ? m : m + 0.5;
+                lo[h] = (int)floor(mr - hp->slack[h]);
+                hi[h] = (int)floor(mr + hp->slack[h]);
+            }
+            if (cst) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    lo[h] = 0x7fffffff;
+                    hi[h] = (int)0x80000000;
+                }
+            }
+            wave_box63(lo, hi);
+        }
+        if (lane == 63) {
+            int blo[3], bhi[3];
+            bool any = true;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                if (!fast) {
+                    any = any && hi[h] >= lo[h];
+                    // the lowest / highest floor a coordinate that stays in (or is folded / clamped back into) the
+                    // array can have, wherever the raw range reaches beyond what coord_axis_fast accepts
+                    const int lowfold = hg.mode == EDHIP_MODE_REFLECT ? -1 : 0;
+                    if (rlo[h] < ((ORDER & 1) ? 0 : 1) && rhi[h] >= lowfold)
+                        lo[h] = min(lo[h], lowfold);
+                    if (rhi[h] > hg.in_len[h] - 2 && rlo[h] <= hg.in_len[h] - 1)
+                        hi[h] = max(hi[h], hg.in_len[h] - 1);
+                }
+                blo[h] = lo[h] - H;
+                bhi[h] = hi[h] - H + ORDER + (h == 2 ? kPadX : 0);
+            }
+            if (!any) {          // every sample maps to the constant
+                blo[0] = blo[1] = blo[2] = 0;
+                bhi[0] = bhi[1] = bhi[2] = -1;
+            }
+            k1_derive(hg, sp, rec, t, blo, bhi, kPadX, fast);
+        }
+    }
+    lds_barrier();
+    ED_TICK(0);
+
     // ---- staging: the source box of tile ti into LDS, two copies, the second shifted by one element -----------
     auto stage = [&](int ti, const float* src) {
         const int4 r0 = *reinterpret_cast<const int4*>(rec + ti);
         const int4 r1 = *(reinterpret_cast<const int4*>(rec + ti) + 1);
         const int4 r2 = *(reinterpret_cast<const int4*>(rec + ti) + 2);
         const int flags = uni(r0.w);
-        if (!(flags & kTStaged))
+        if (!(flags & kTStaged) || ED_DBG(hg.dbg, 1 << 18))       // (ablation 1 << 18: no staging)
             return;
         const int by = uni(r1.y), pitch = uni(r1.w);
         if (flags & kTDma) {
@@ -600,27 +701,45 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
             // lane -> (row, 16-byte chunk).  The plane's address is scalar arithmetic; a lane adds its own row /
             // chunk offset, which only depends on the pitch.  (Rows in one flat sequence over the planes fill
             // every lane, but cost a division, two multiplies and 64-bit adds per lane and instruction.)
-            const float* g0 = src + uni(r2.z);
             const int ez = uni(r1.x);
             const bool p16 = pitch == 16;
             const int RW = p16 ? 16 : 5;
             const int lr = p16 ? lane >> 2 : (lane * 21846) >> 18;      // lane / 12
             const int q = p16 ? lane & 3 : lane - lr * 12;
-            const long long rowoff = (long long)lr * hg.vol_sy + 4 * q;
-            for (int zr = wave; zr < ez; zr += 4) {
-                const float* gp = g0 + (long long)zr * hg.vol_sz;
-                const int lrow0 = zr * by;
-                for (int y0 = 0; y0 < by; y0 += RW) {
-                    if (lr < RW && y0 + lr < by) {
-                        const float* g = gp + ((long long)y0 * hg.vol_sy + rowoff);
-                        glds16(g, box0 + (lrow0 + y0) * pitch);
-                        glds16(g + 1, box1 + (lrow0 + y0) * pitch);
+            if (flags & kTZYin) {
+                const float* g0 = src + uni(r2.z);
+                const long long rowoff = (long long)lr * hg.vol_sy + 4 * q;
+                for (int zr = wave; zr < ez; zr += 4) {
+                    const float* gp = g0 + (long long)zr * hg.vol_sz;
+                    const int lrow0 = zr * by;
+                    for (int y0 = 0; y0 < by; y0 += RW) {
+                        if (lr < RW && y0 + lr < by) {
+                            const float* g = gp + ((long long)y0 * hg.vol_sy + rowoff);
+                            glds16(g, box0 + (lrow0 + y0) * pitch);
+                            glds16(g + 1, box1 + (lrow0 + y0) * pitch);
+                        }
+                    }
+                }
+            } else {
+                // planes / rows beyond the array's z / y ends: the mirror map of the reference's taps
+                // (deform.c:791-813), applied to the plane / row index
+                const int b0z = uni(r0.x), b0y = uni(r0.y);
+                const float* g0 = src + (uni(r0.z) + 4 * q);
+                for (int zr = wave; zr < ez; zr += 4) {
+                    const float* gp = g0 + (long long)mirror_i32(b0z + zr, hg.in_len[0]) * hg.vol_sz;
+                    const int lrow0 = zr * by;
+                    for (int y0 = 0; y0 < by; y0 += RW) {
+                        if (lr < RW && y0 + lr < by) {
+                            const float* g = gp + (long long)mirror_i32(b0y + y0 + lr, hg.in_len[1]) * hg.vol_sy;
+                            glds16(g, box0 + (lrow0 + y0) * pitch);
+                            glds16(g + 1, box1 + (lrow0 + y0) * pitch);
+                        }
                     }
                 }
             }
         } else {
-            // edge tile: every box index goes through the mirror map, as the reference does with the taps of a
-            // window that sticks out (deform.c:791-813)
+            // the box sticks out along x: every box index goes through the mirror map, as the reference does with
+            // the taps of a window that sticks out (deform.c:791-813)
             const int b0z = uni(r0.x), b0y = uni(r0.y), b0x = uni(r0.z), ex = uni(r1.z), nrows = uni(r2.x);
             const float inv_by = __frcp_rn((float)by);
             const bool xin = (flags & kTXin) != 0;
@@ -658,151 +777,13 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
         return pitch == 16 ? k1_gather<ORDER, 16, SPLIT>(bp, plane, w0, w1, w2) : k1_gather<ORDER, 48, SPLIT>(bp, plane, w0, w1, w2);
     };
 
-    // ---- the boxes of the strip's tiles -----------------------------------------------------------------------
-    // wave t samples tile t: the coordinate at 4 x 4 x 4 of its voxels, widened by the margin
-    if (wave < ntile) {
-        const int t = wave;
-        const int nz = min(kT, hg.out_len[0] - sp.tz * kT), ny = min(kT, hg.out_len[1] - sp.ty * kT),
-                  nx = min(kT, hg.out_len[2] - (sp.tx0 + t) * kT);
-        const int pz = ((lane >> 4) * (nz - 1)) / 3, py = (((lane >> 2) & 3) * (ny - 1)) / 3, px = ((lane & 3) * (nx - 1)) / 3;
-        XEnt xe;
-        k1_xent(smem, t * kT + px, (pz * kT + py) * 32, xe);
-        double d[3];
-        k1_disp<0>(smem, xe, d);
-        const int o[3] = {sp.tz * kT + pz, sp.ty * kT + py, (sp.tx0 + t) * kT + px};
-        int lo[3], hi[3];
-#pragma unroll
-        for (int h = 0; h < 3; ++h) {
-            double c;
-            if (AFFINE)
-                c = fma(hp->affine[h * 4 + 2], (double)o[2],
-                        fma(hp->affine[h * 4 + 0], (double)o[0],
-                            fma(hp->affine[h * 4 + 1], (double)o[1], hp->affine[h * 4 + 3] + hp->offd[h]))) + d[h];
-            else
-                c = (double)(o[h] + hg.off[h]) + d[h];
-            if (!(ORDER & 1))
-                c += 0.5;
-            lo[h] = (int)floor(c - hp->slack[h]);
-            hi[h] = (int)floor(c + hp->slack[h]);
-        }
-        wave_box63(lo, hi);
-        if (lane == 63) {
-            // fast: a full tile whose every coordinate, margin included, is one coord_axis_fast accepts
-            bool fast = nz == kT && ny == kT && nx == kT && !ED_DBG(hg.dbg, 1 << 16);
-#pragma unroll
-            for (int h = 0; h < 3; ++h)
-                fast = fast && lo[h] >= ((ORDER & 1) ? 0 : 1) && hi[h] <= hg.in_len[h] - 2;
-            if (fast) {
-                int blo[3], bhi[3];
-#pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    blo[h] = lo[h] - H;
-                    bhi[h] = hi[h] - H + ORDER + (h == 2 ? kPadX : 0);
-                }
-                k1_derive(hg, sp, rec, t, blo, bhi, kPadX, true);
-            } else {
-                rec[t].flags = kTEdge;
-            }
-        }
-    }
-    lds_barrier();
-    ED_TICK(0);
-
-    // ---- general tiles (array faces, partial tiles): one at a time, the exact box of the tile's tap windows, as
-    //      the reference's taps define it; boundary map, constant and valid flags ------------------------------------
-    for (int t = 0; t < ntile; ++t) {
-        if (!(uni(rec[t].flags) & kTEdge))
-            continue;
-        const int ox = (sp.tx0 + t) * kT + xx;
-        int start[2][3];
-        float frac[2][3];
-        bool valid[2], cst[2];
-        {
-            XEnt xe;
-            k1_xent(smem, t * kT + xx, lrow, xe);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                double d[3];
-                if (i == 0)
-                    k1_disp<0>(smem, xe, d);
-                else
-                    k1_disp<ROW1>(smem, xe, d);
-                const int b[3] = {oz0 + 4 * i + hg.off[0], oy + hg.off[1], ox + hg.off[2]};
-                double P[3] = {0.0, 0.0, 0.0};
-                if (AFFINE) {
-#pragma unroll
-                    for (int h = 0; h < 3; ++h)
-                        P[h] = fma(hp->affine[h * 4 + 2], (double)ox, Pzy[h][i]);
-                }
-                cst[i] = k1_coords<ORDER, AFFINE>(hg, hp, d, b, P, start[i], frac[i]);
-                valid[i] = oz0 + 4 * i < hg.out_len[0] && oy < hg.out_len[1] && ox < hg.out_len[2];
-            }
-        }
-        {
-            int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-            int hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (valid[i] && !cst[i]) {
-#pragma unroll
-                    for (int h = 0; h < 3; ++h) {
-                        lo[h] = min(lo[h], start[i][h]);
-                        hi[h] = max(hi[h], start[i][h] + ORDER + (h == 2 ? kPadX : 0));
-                    }
-                }
-            }
-            wave_box63(lo, hi);
-            if (lane == 63) {
-                int* r = red + t * 8;
-                atomicMin(&r[0], lo[0]);
-                atomicMin(&r[1], lo[1]);
-                atomicMin(&r[2], lo[2]);
-                atomicMax(&r[3], hi[0]);
-                atomicMax(&r[4], hi[1]);
-                atomicMax(&r[5], hi[2]);
-            }
-        }
-        lds_barrier();
-        if (tid == 0) {
-            const int* r = red + t * 8;
-            const int lo[3] = {r[0], r[1], r[2]};
-            const int hi[3] = {r[3], r[4], r[5]};
-            k1_derive(hg, sp, rec, t, lo, hi, kPadX, false);
-        }
-        lds_barrier();
-        const int flags = uni(rec[t].flags);
-        if ((flags & kTAny) && !(flags & kTStaged))
-            continue;                  // does not fit: the spill list, or k1_fix below
-        const int b0z = uni(rec[t].b0[0]), b0y = uni(rec[t].b0[1]), b0x = uni(rec[t].b0[2]);
-        const int pitch = uni(rec[t].pitch), plane = uni(rec[t].plane);
-        for (long long ss = 0; ss < hg.nsteps; ++ss) {
-            long long vol_off = 0, img_off = 0;
-            if (hg.nstep)
-                k1_step_offsets(hp, ss, vol_off, img_off);
-            stage(t, vol + vol_off);
-            if (flags & kTStaged)
-                dma_barrier();
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (!valid[i])
-                    continue;
-                float val = hg.cval;
-                if (!cst[i]) {
-                    const int rz = start[i][0] - b0z, ry = start[i][1] - b0y, rx = start[i][2] - b0x;
-                    const int off = __mul24(rz, plane) + (__mul24(ry, pitch) + rx);
-                    val = gather(__mul24(off & 1, odd_shift) + (off * 4 + boxbase), frac[i], pitch, plane);
-                }
-                store_out<OUT16>(img, img_off + obase + i * 4 * hg.img_sz + t * kT, val, io16);
-            }
-            lds_barrier();             // the gathers are done with the box
-        }
-    }
-
-    // ---- fast tiles: full tiles whose coordinates stay inside the array ---------------------------------------------
-    // window start and fractions of the lane's two voxels of tile ti, as LDS addresses relative to the tile's box;
-    // no range test, no boundary map -- a window that is not inside the box raises the lane's flag
+    // ---- coordinates of the lane's two voxels of tile ti, as LDS addresses relative to the tile's box -------------
+    // GEN false (fast tiles): no range test, no boundary map, every voxel gathered and stored.  GEN true: general
+    // coordinates (deform.c:771-824), constant and valid flags.  Either way a window that is not inside the box
+    // raises the lane's flag.
     int bad = 0;
-    auto fast_coords = [&](int ti, VoxState& vs) {
+    auto tile_coords = [&](auto gen_tag, int ti, VoxState& vs) {
+        constexpr bool GEN = decltype(gen_tag)::value;
         const int4 r0 = *reinterpret_cast<const int4*>(rec + ti);
         const int4 r1 = *(reinterpret_cast<const int4*>(rec + ti) + 1);
         const int4 r2 = *(reinterpret_cast<const int4*>(rec + ti) + 2);
@@ -812,99 +793,139 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
         const int ox = (sp.tx0 + ti) * kT + xx;
         XEnt xe;
         k1_xent(smem, ti * kT + xx, lrow, xe);
-        // window start relative to the box = floor part of the coordinate + k (tile- and lane-constant)
-        int kz, ky, kx;
-        if (AFFINE) {
-            kz = -H - b0z;
-            ky = -H - b0y;
-            kx = -H - b0x;
-        } else {
-            kz = oz0 + hg.off[0] - H - b0z;        // second voxel: + 4
-            ky = oy + hg.off[1] - H - b0y;
-            kx = ox + hg.off[2] - H - b0x;
-        }
+        vs.flg = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             double d[3];
-            if (i == 0)
+            if (ED_DBG(hg.dbg, 1 << 19)) {     // (ablation: no displacement -- no table reads, no fp64 sums)
+                d[0] = d[1] = d[2] = 0.25;
+            } else if (i == 0)
                 k1_disp<0>(smem, xe, d);
             else
                 k1_disp<ROW1>(smem, xe, d);
             ED_NO_DS_MERGE();          // (the backend pairs the two voxels' reads into ds_read2st64_b64: 16 LDS cycles each)
-            int ci[3];
+            int rz, ry, rx;
+            if constexpr (GEN) {
+                const int b[3] = {oz0 + 4 * i + hg.off[0], oy + hg.off[1], ox + hg.off[2]};
+                double P[3] = {0.0, 0.0, 0.0};
+                if (AFFINE) {
 #pragma unroll
-            for (int h = 0; h < 3; ++h) {
-                // (coord_axis_fast without its range test: the same floor, the same fraction)
-                const double c = AFFINE ? fma(hp->affine[h * 4 + 2], (double)ox, Pzy[h][i]) + d[h] : d[h];
-                const double fl = floor((ORDER & 1) ? c : c + 0.5);
-                ci[h] = (int)fl;
-                vs.frac[i][h] = (float)(c - fl);
+                    for (int h = 0; h < 3; ++h)
+                        P[h] = fma(hp->affine[h * 4 + 2], (double)ox, Pzy[h][i]);
+                }
+                int start[3];
+                const bool cst = k1_coords<ORDER, AFFINE>(hg, hp, d, b, P, start, vs.frac[i]);
+                const bool valid = oz0 + 4 * i < hg.out_len[0] && oy < hg.out_len[1] && ox < hg.out_len[2];
+                rz = start[0] - b0z;
+                ry = start[1] - b0y;
+                rx = start[2] - b0x;
+                if (valid && !cst)
+                    bad |= (rz | ry | rx) | ((ez - rz) | (ey - ry) | (ex - rx));
+                vs.flg |= (valid && !cst ? 1 << i : 0) | (valid ? 4 << i : 0);
+            } else {
+                // window start relative to the box = floor part of the coordinate + k (tile- and lane-constant)
+                const int kz = AFFINE ? -H - b0z : oz0 + 4 * i + hg.off[0] - H - b0z;
+                const int ky = AFFINE ? -H - b0y : oy + hg.off[1] - H - b0y;
+                const int kx = AFFINE ? -H - b0x : ox + hg.off[2] - H - b0x;
+                int ci[3];
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    // (coord_axis_fast without its range test: the same floor, the same fraction)
+                    const double c = AFFINE ? fma(hp->affine[h * 4 + 2], (double)ox, Pzy[h][i]) + d[h] : d[h];
+                    const double fl = floor((ORDER & 1) ? c : c + 0.5);
+                    ci[h] = (int)fl;
+                    vs.frac[i][h] = (float)(c - fl);
+                }
+                rz = ci[0] + kz;
+                ry = ci[1] + ky;
+                rx = ci[2] + kx;
+                bad |= (rz | ry | rx) | ((ez - rz) | (ey - ry) | (ex - rx));
             }
-            const int rz = ci[0] + kz + ((!AFFINE && i) ? 4 : 0), ry = ci[1] + ky, rx = ci[2] + kx;
-            bad |= (rz | ry | rx) | ((ez - rz) | (ey - ry) | (ex - rx));
             // (24-bit multiplies: a window inside the box has small non-negative offsets; one outside is flagged)
             const int off = __mul24(rz, plane) + (__mul24(ry, pitch) + rx);
             // aligned pairs from the copy whose shift matches the parity of rx (pitch and plane are even)
             vs.addr[i] = __mul24(off & 1, odd_shift) + (off * 4 + boxbase);
         }
     };
-    // the fast tile after ti (ntile: none)
-    auto next_fast = [&](int ti) {
-        int t = ti + 1;
-        while (t < ntile && !(uni(rec[t].flags) & kTFast))
-            ++t;
-        return t;
-    };
 
-    // tile loop, software-pipelined: the coordinates of the next fast tile under the copies of this one
-    VoxState cur, nxt;
-    int ti = next_fast(-1);
-    if (ti < ntile)
-        fast_coords(ti, cur);
-    ED_TICK(1);
-    while (ti < ntile) {
-        long long vol_off = 0, img_off = 0;
-        if (hg.nstep)
-            k1_step_offsets(hp, 0, vol_off, img_off);
-        stage(ti, vol + vol_off);
-        ED_TICK(2);
-        const int tn = next_fast(ti);
-        if (tn < ntile)
-            fast_coords(tn, nxt);
-        ED_TICK(3);
-        const int pitch = uni(rec[ti].pitch), plane = uni(rec[ti].plane);
-        for (long long ss = 0; ss < hg.nsteps; ++ss) {
-            if (ss > 0) {
-                k1_step_offsets(hp, ss, vol_off, img_off);
-                stage(ti, vol + vol_off);
+    // ---- tile loop, software-pipelined: the coordinates of the next tile of the class under the copies of this one ---
+    auto run_tiles = [&](auto gen_tag) {
+        constexpr bool GEN = decltype(gen_tag)::value;
+        auto next_tile = [&](int ti) {          // the next tile of the class after ti (ntile: none)
+            int t = ti + 1;
+            for (; t < ntile; ++t) {
+                const int f = uni(rec[t].flags);
+                if (GEN ? ((f & kTGen) && !(f & kTUnfit)) : (f & kTFast) != 0)
+                    break;
             }
-            dma_barrier();       // B2: retires this wave's copies (vmcnt) and everyone's
-            ED_TICK(4);
+            return t;
+        };
+        VoxState cur, nxt;
+        int ti = next_tile(-1);
+        if (ti < ntile)
+            tile_coords(gen_tag, ti, cur);
+        ED_TICK(GEN ? 6 : 1);
+        while (ti < ntile) {
+            long long vol_off = 0, img_off = 0;
+            if (hg.nstep)
+                k1_step_offsets(hp, 0, vol_off, img_off);
+            stage(ti, vol + vol_off);
+            ED_TICK(GEN ? 6 : 2);
+            const int tn = next_tile(ti);
+            if (tn < ntile)
+                tile_coords(gen_tag, tn, nxt);
+            ED_TICK(GEN ? 6 : 3);
+            const bool staged = !GEN || (uni(rec[ti].flags) & kTStaged);
+            const int pitch = uni(rec[ti].pitch), plane = uni(rec[ti].plane);
+            for (long long ss = 0; ss < hg.nsteps; ++ss) {
+                if (ss > 0) {
+                    k1_step_offsets(hp, ss, vol_off, img_off);
+                    stage(ti, vol + vol_off);
+                }
+                if (staged)
+                    dma_barrier();       // B2: retires this wave's copies (vmcnt) and everyone's
+                ED_TICK(GEN ? 6 : 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float val = gather(cur.addr[i], cur.frac[i], pitch, plane);
-                // streaming store (a tile writes 32-byte row segments)
-                store_out<OUT16>(img, img_off + obase + i * 4 * hg.img_sz + ti * kT, val, io16);
+                for (int i = 0; i < 2; ++i) {
+                    if (GEN && !(cur.flg & (4 << i)))
+                        continue;
+                    float val = hg.cval;
+                    if (ED_DBG(hg.dbg, 1 << 17))           // (ablation: no gather)
+                        val = cur.frac[i][0] + cur.frac[i][1] + cur.frac[i][2] + __int_as_float(cur.addr[i]);
+                    else if (!GEN || (cur.flg & (1 << i)))
+                        val = gather(cur.addr[i], cur.frac[i], pitch, plane);
+                    if (ED_DBG(hg.dbg, 1 << 20) && val != -12345.678f)      // (ablation: no stores)
+                        continue;
+                    // streaming store (a tile writes 32-byte row segments)
+                    store_out<OUT16>(img, img_off + obase + i * 4 * hg.img_sz + ti * kT, val, io16);
+                }
+                if (staged)
+                    lds_barrier();       // B1: every gather of this tile is done with the box
             }
-            lds_barrier();       // B1: every gather of this tile is done with the box
+            ED_TICK(GEN ? 6 : 5);
+            cur = nxt;
+            ti = tn;
         }
-        ED_TICK(5);
-        cur = nxt;
-        ti = tn;
+    };
+    run_tiles(std::false_type{});
+    bool anygen = false, unfit = false;
+    for (int t = 0; t < ntile; ++t) {
+        const int f = uni(rec[t].flags);
+        anygen = anygen || (f & kTGen);
+        unfit = unfit || (hg.self_serve && (f & kTUnfit));
     }
+    if (anygen)
+        run_tiles(std::true_type{});
 #ifdef EDHIP_EXPERIMENTS
     if (hg.dbgbuf && lane == 0) {
         unsigned long long* d = hg.dbgbuf + ((size_t)blockIdx.x * 4 + wave) * 8;
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < 7; ++q)
             d[q] = (unsigned long long)tacc[q];
-        d[6] = (unsigned long long)ntile;
+        d[7] = (unsigned long long)ntile;
     }
 #endif
 #undef ED_TICK
     // ---- what the loops could not serve: unfit tiles (self-serve), windows outside a sampled box ------------------
-    bool unfit = false;
-    for (int t = 0; t < ntile; ++t)
-        unfit = unfit || (hg.self_serve && (uni(rec[t].flags) & kTUnfit));
     const bool missed = __any(bad < 0);
     if (unfit || missed)
         k1_fix<ORDER, AFFINE, OUT16>(hg, sp, smem, missed, io16);
@@ -913,9 +934,10 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
 template <int ORDER>
 hipError_t launch_k1_order(const HotGeom& hg, unsigned nblk, size_t lds, hipStream_t stream)
 {
-    // reads of the gather: 2 = a plane at a time in reverse order (shipped); the profiling build also has
-    // 1 = in order of use, kept apart, 0 = as the backend fuses them (ds_read2_b64)
-    [[maybe_unused]] const int split = ed_env("EDHIP_K1_SPLIT") ? atoi(ed_env("EDHIP_K1_SPLIT")) : 2;
+    // reads of the gather: 1 = in order of use, kept apart (shipped); the profiling build also has 0 = as the backend
+    // fuses them (ds_read2_b64: +25 %), 2 / 3 = two rows / a plane at a time in reverse order of use (one s_waitcnt
+    // per group instead of one per read, but a group's first multiply-add waits for its last read: +16 %)
+    [[maybe_unused]] const int split = ed_env("EDHIP_K1_SPLIT") ? atoi(ed_env("EDHIP_K1_SPLIT")) : 1;
 #ifdef EDHIP_EXPERIMENTS
 #define ED_K1_GO(A, O16)                                                                                              \
     do {                                                                                                              \
@@ -929,7 +951,7 @@ hipError_t launch_k1_order(const HotGeom& hg, unsigned nblk, size_t lds, hipStre
             hipLaunchKernelGGL((k1_fwd_kernel<ORDER, A, O16, 0>), dim3(nblk), dim3(kBlock), lds, stream, hg);         \
     } while (0)
 #else
-#define ED_K1_GO(A, O16) hipLaunchKernelGGL((k1_fwd_kernel<ORDER, A, O16, 2>), dim3(nblk), dim3(kBlock), lds, stream, hg)
+#define ED_K1_GO(A, O16) hipLaunchKernelGGL((k1_fwd_kernel<ORDER, A, O16, 1>), dim3(nblk), dim3(kBlock), lds, stream, hg)
 #endif
     if (hg.io16) {
         if (hg.has_affine)

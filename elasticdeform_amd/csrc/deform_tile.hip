@@ -1636,7 +1636,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 size_t hlds = 0;
                 // forward, orders 1-3: K1 of round 5 (deform_k1.hip: sampled tile boxes, fast tiles); the profiling
                 // build can still run the kernel it replaced (EDHIP_K1_OLD)
-                [[maybe_unused]] const bool k1_new = !GRAD && ORDER <= 3 && tg.strip_tiles <= 4 && !ed_env("EDHIP_K1_OLD") &&
+                [[maybe_unused]] const bool k1_new = !GRAD && ORDER <= 3 && tg.strip_tiles <= 8 && !ed_env("EDHIP_K1_OLD") &&
                                                      !ed_env("EDHIP_RECORDS");
                 if (k1_new) {
                     int off_small = 0;

@@ -28,10 +28,10 @@ e0.record(); _lib.deform(False, *a_f); e1.record()
 torch.cuda.synchronize()
 del os.environ["EDHIP_DEBUG_PTR"]
 b = buf.cpu().numpy().astype(np.float64)
-b = b[b[:, 6] > 0]
-names = ["prologue+boxes", "wait B1", "stage issue", "coords(t+1)", "wait B2 (DMA)", "gather+store"]
-tot = b[:, :6].sum(axis=1)
+b = b[b[:, 7] > 0]
+names = ["prologue+boxes", "first coords", "stage issue", "coords(t+1)", "wait B2 (DMA)", "gather+store+B1", "general tiles"]
+tot = b[:, :7].sum(axis=1)
 print("sigma %g order %d: forward call %.1f us; %d waves reported; ticks per wave and strip: mean %.0f" % (sigma, order, e0.elapsed_time(e1) * 1e3, len(b), tot.mean()))
 for k, nm in enumerate(names):
     print("  %-16s mean %8.0f ticks (%.1f %%)   per tile %7.0f   p10 %8.0f p90 %8.0f" %
-          (nm, b[:, k].mean(), 100 * b[:, k].mean() / tot.mean(), (b[:, k] / b[:, 6]).mean(), np.percentile(b[:, k], 10), np.percentile(b[:, k], 90)))
+          (nm, b[:, k].mean(), 100 * b[:, k].mean() / tot.mean(), (b[:, k] / b[:, 7]).mean(), np.percentile(b[:, k], 10), np.percentile(b[:, k], 90)))
