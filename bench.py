@@ -165,6 +165,22 @@ def relaunch(args):
     return subprocess.call(cmd, env=env)
 
 
+# What K1 / K2 and their launch routing are built from: the PMC-derived numbers of profiles/hbm_traffic.json (HBM
+# bytes per launch, VALUBusy, LDS busy) are reported only while the hash of these files matches the tree the bench
+# runs in -- an edit to a kernel, to the strip length / routing in the launcher or to the API layer voids the stamp.
+KERNEL_SOURCES = ("deform_k1.hip", "deform_hot.hip", "ed_hot.h", "ed_tile.h", "ed_device.h", "deform_tile.hip",
+                  "edhip_api.hip", "ed_params.h")
+
+
+def kernel_sources_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for fn in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "elasticdeform_amd", "csrc", fn), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cfg4_main(args):
     """BASELINE cfg4 on one GPU: multi-input + axis + crop + affine, forward + gradient per step."""
     import importlib
@@ -223,9 +239,38 @@ def cfg4_main(args):
         dgm.CROP_WINDOW_MIN_SAVING, dgm.CROP_WINDOW_MAX_FRACTION = saved
     vox = float(sum(int(np.prod(o.shape)) for o in outs))
     ms = elapsed / args.steps * 1e3
-    # algorithmic bytes of the step when every input is filtered whole (the reference's pipeline,
-    # deform_grid.py:155-164, 277-286): the three float32 channels through 3 forward + 3 transposed passes
-    filt_bytes = 2.0 * 24.0 * float(img.size)
+    # Algorithmic bytes of the step, SURVEY.md 8(d): "with crop use bytes(output) + bytes(source bounding box actually
+    # needed)".  The box is the filter window the library computed ON THE DEVICE for this very call
+    # (edhip_source_window: the source box + the filter's decay margin); it is read back here, outside every timed
+    # region, from the tensors _crop_windows hands to the filter passes.  An input without a window counts whole.
+    seen = []
+    real_cw = dgm._crop_windows
+
+    def spy(plan, xs, *a, **k):
+        wins = real_cw(plan, xs, *a, **k)
+        seen.append([(tuple(int(d) for d in x.shape), w) for x, w in zip(xs, wins)])
+        return wins
+    dgm._crop_windows = spy
+    try:
+        fwd()
+        bwd()
+        torch.cuda.synchronize()
+    finally:
+        dgm._crop_windows = real_cw
+
+    def window_voxels(shape, w):
+        if w is None:
+            return float(np.prod(shape))
+        wv = w.cpu().numpy().reshape(-1, 2)
+        return float(np.prod([max(int(b) - int(a), 0) for a, b in wv]))
+    # per call: [image (3 channels, order 3), labels (order 0: no filter, no window)]
+    win_f = window_voxels(*seen[0][0]) if seen else float(img.size)
+    win_g = window_voxels(*seen[1][0]) if len(seen) > 1 else float(img.size)
+    out_img, out_lab = float(np.prod(outs[0].shape)), float(np.prod(outs[1].shape))
+    fwd_bytes = 24.0 * win_f + 4.0 * win_f + 4.0 * out_img + 8.0 * out_lab      # K3 passes, K1 source box, K1 stores, labels
+    grad_bytes = 4.0 * out_img + 4.0 * win_g + 24.0 * win_g + 8.0 * out_lab     # dY, dX box, K4 passes, labels
+    step_bytes = fwd_bytes + grad_bytes
+    whole_bytes = 2.0 * (24.0 + 4.0) * float(img.size) + 8.0 * out_img + 16.0 * out_lab
     res = {"metric": "Mvoxels/s fwd+grad, cfg4 multi-input crop 64^3", "value": round(vox * args.steps / elapsed / 1e6, 2),
            "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -233,11 +278,17 @@ def cfg4_main(args):
                                   "axis [(1,2,3),(0,1,2)], crop %d^3, affine rotate 10 deg + zoom 1.1, 5x5x5 grid sigma 5, "
                                   "prefilter on, deform_grid + deform_grid_gradient per step" % (n, n, n // 4),
                       "parallelism": "1 GPU"},
-           "roofline": {"bound": "hbm", "achieved": round(filt_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(filt_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
-                        "kernel": "whole step against the prefilter's algorithmic bytes when every channel is filtered whole "
-                                  "(K3 / K4: 24 B per input voxel each); the deform kernels touch 4 x 64^3 voxels",
-                        "algorithmic_bytes_per_step": int(filt_bytes)},
+           "roofline": {"bound": "hbm", "achieved": round(step_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(step_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                        "kernel": "whole step against the bytes of the source window actually filtered and read "
+                                  "(SURVEY 8d: outputs + source box): per voxel of the window 24 B (K3 / K4 passes) + 4 B "
+                                  "(K1 read / K2 dX), per output voxel 4 B, labels 8 B; the window is the device-side one "
+                                  "of this call (edhip_source_window), read back outside the timed region",
+                        "algorithmic_bytes_per_step": int(step_bytes),
+                        "window_voxels": {"forward": int(win_f), "gradient": int(win_g), "whole_input": int(img.size)},
+                        "if_filtered_whole": {"algorithmic_bytes_per_step": int(whole_bytes),
+                                              "note": "the reference's pipeline (deform_grid.py:155-164, 277-286) moves "
+                                                      "these bytes; NOT what this step is priced on"}},
            "crop_window": window,
            "output_voxels_per_step": int(vox)}
     print(json.dumps(res), flush=True)
@@ -547,14 +598,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            import hashlib
             with open(tpath) as f:
                 traffic_db = json.load(f)
-            h = hashlib.sha256()
-            for fn in ("deform_hot.hip", "ed_tile.h", "ed_device.h"):
-                with open(os.path.join(ROOT, "elasticdeform_amd", "csrc", fn), "rb") as fh:
-                    h.update(fh.read())
-            if traffic_db.get("kernel_sources_sha16") != h.hexdigest()[:16]:
+            if traffic_db.get("kernel_sources_sha16") != kernel_sources_sha16():
                 traffic_db = {}
         except Exception:
             traffic_db = {}
@@ -566,6 +612,9 @@ def main():
                 "frac": round(achieved / 8000.0, 4),
                 "traffic": t.get("bytes_per_launch") if t else None,
                 "traffic_measured_at": t.get("commit") if t else None,
+                # (PMC passes of the same stamp: SQ_ACTIVE_INST_VALU x 4 / SIMDs / busy cycles, SQ_LDS_IDX_ACTIVE / CUs / busy cycles)
+                "valu_busy": t.get("valu_busy") if t else None,
+                "lds_busy": t.get("lds_busy") if t else None,
                 "kernel": name,
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "avg_launch_us": round(us, 2), "median_launch_us": round(med, 2),
@@ -578,9 +627,9 @@ def main():
         except Exception:
             return None
 
-    k1_obj = kernel_obj("K1", "K1 forward deform: hot_fwd_kernel<3,false> (deform_hot.hip; the strip launch of "
+    k1_obj = kernel_obj("K1", "K1 forward deform: k1_fwd_kernel<3,false> (deform_k1.hip; the strip launch of "
                         "one edhip_deform gradient=0 call on the prefiltered input; whole_call adds the "
-                        "tables kernel and the two spill passes)", k1_us, k1_med, k1_ms)
+                        "tables kernel)", k1_us, k1_med, k1_ms)
     k2_obj = kernel_obj("K2", "K2 gradient scatter-add: hot_grad_kernel<3,false> (deform_hot.hip; the strip "
                         "launch of one edhip_deform gradient=1 call; whole_call adds the tables kernel and "
                         "the two spill passes)", k2_us, k2_med, k2_ms)

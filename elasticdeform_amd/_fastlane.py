@@ -189,24 +189,17 @@ class Lane(object):
                 else:
                     self.ins[i] = dgm._desc(x)
                 self.outs[i] = _like_desc(dgm, x, self.shapes[i])
-        # upper bound of what the crop-aware prefilter could save (deform_grid._crop_windows): calls
-        # that might engage it stay on the general path
-        self.max_saving = 0.0
-        if crop is not None and prefilter:
-            in_shapes = self.shapes if gradient else [tuple(x.shape) for x in xs]
+        # would the crop-aware prefilter engage (deform_grid._crop_windows)?  Such calls stay on the general path;
+        # the rule is the general path's own (one helper), so that repeated identical calls take one route
+        self.window_pays = False
+        if crop is not None and prefilter and not (flags & _lib.FLAG_EXACT):
+            in_shapes = self.shapes if gradient else [tuple(int(d) for d in x.shape) for x in xs]
+            names = [str(dt).replace('torch.', '') for dt in self.dtypes]
+            todo = [i for i in range(n) if int(plan.order[i]) in dgm._WINDOW_MARGIN.get(names[i], {})]
             ax0 = plan.axis[0]
             in_len = [int(in_shapes[0][a]) for a in ax0]
             out_len = [int(plan.output_shapes[0][a]) for a in ax0]
-            for i in range(n):
-                if plan.order[i] > 1 and self.dtypes[i] in (torch.float32, torch.float64):
-                    m = _host.PREFILTER_MARGIN.get(int(plan.order[i]), 64)
-                    full = sub = 1.0
-                    for d in in_shapes[i]:
-                        full *= int(d)
-                    sub = full
-                    for a, n_in, n_out in zip(plan.axis[i], in_len, out_len):
-                        sub *= float(min(n_in, n_out + 2 * m)) / float(in_shapes[i][a])
-                    self.max_saving += full - sub
+            self.window_pays = dgm._crop_window_pays(plan, in_shapes, names, todo, in_len, out_len)
 
     def run(self, dgm, X, xs, displacement):
         torch = _torch

@@ -53,6 +53,20 @@
 #include "ed_workspace.h"
 #include "ed_tile.h"
 
+#ifdef EDHIP_EXPERIMENTS
+// profiling build: control columns the per-strip Q window of a wide grid (TileGeom::q_win) did not hold -- the
+// tables kernel clamps them silently; tests/fuzz/fuzz_round4.py asserts the count stays 0 (edhip_debug_wide_clamped)
+__device__ unsigned g_wide_clamped;
+extern "C" unsigned edhip_debug_wide_clamped(void)
+{
+    unsigned v = 0xffffffffu, z = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_wide_clamped), sizeof(v)) != hipSuccess)
+        return 0xffffffffu;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_clamped), &z, sizeof(z));
+    return v;
+}
+#endif
+
 namespace ed {
 
 namespace {
@@ -201,6 +215,10 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
                 // element offset of control column idx in a Q row [ncpx][4] ([q_win][4], from the strip's lowest
                 // column: the host sized q_win for every strip; the clamp only keeps a wrong size inside the row)
                 const int rel = t.idx[l] - c0;
+#ifdef EDHIP_EXPERIMENTS
+                if (tg.q_win && (rel < 0 || rel >= tg.q_win))
+                    atomicAdd(&g_wide_clamped, 1u);      // (the host's window formula was too small: must never count)
+#endif
                 t.idx[l] = (tg.q_win ? min(rel, tg.q_win - 1) : rel) * 4;
             }
             xt[ox] = t;

@@ -57,10 +57,13 @@ SpillHint* spill_hint(hipStream_t stream);          // nullptr when pinned memor
 struct GridStamp {
     const void* raw = nullptr;
     const void* ws = nullptr;
+    unsigned long long generation = 0;    // workspace_generation() when the copy was made
     int dtype = 0, ndim = 0;
     long long shape[9] = {}, stride[9] = {};
 };
 GridStamp* grid_stamp(hipStream_t stream);
+// counts the times the stream's workspace buffer was freed or replaced (a stamp from an earlier generation is void)
+unsigned long long workspace_generation(hipStream_t stream);
 
 // Drains the devices that own scratch and frees every cached buffer.
 void workspace_release_all();

@@ -13,6 +13,9 @@ struct Buffer {
     void* ptr = nullptr;
     size_t cap = 0;
     bool transient = false;      // allocated stream-ordered for one oversized call; freed by workspace_trim
+    // bumped whenever `ptr` is freed or replaced: what a GridStamp remembers about the head of the buffer is void
+    // then, even if the allocator hands the same address back (the new buffer's head is cleared)
+    unsigned long long generation = 0;
 };
 // Requests above this are not kept: the float32 order-4/5 cascade asks for a dense temporary of the
 // array's size (up to 1 GiB here) and the exact filter for 256 MiB; cached per stream they stay
@@ -85,11 +88,13 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
         b.ptr = nullptr;
         b.cap = 0;
         b.transient = false;
+        ++b.generation;
         if (e != hipSuccess) {
             *err = e;
             return nullptr;
         }
     }
+    ++b.generation;          // (a new allocation follows)
     if (bytes > kKeepBytes) {
         // oversized, one call only: stream-ordered allocation, released by workspace_trim() when the
         // call has enqueued its work (no host synchronisation, nothing stays pinned)
@@ -269,6 +274,17 @@ void workspace_trim(hipStream_t stream)
     it->second.ptr = nullptr;
     it->second.cap = 0;
     it->second.transient = false;
+    ++it->second.generation;
+}
+
+unsigned long long workspace_generation(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return 0;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_buffers.find(std::make_pair(dev, stream));
+    return it == g_buffers.end() ? 0 : it->second.generation;
 }
 
 void workspace_release_all()
@@ -290,8 +306,9 @@ void workspace_release_all()
         }
         kv.second.ptr = nullptr;
         kv.second.cap = 0;
+        kv.second.transient = false;
+        ++kv.second.generation;          // (entries stay: a GridStamp taken before the release must not match again)
     }
-    g_buffers.clear();
     for (auto& kv : g_keep) {
         if (kv.second.ptr && hipSetDevice(kv.first.first) == hipSuccess) {
             (void)hipDeviceSynchronize();

@@ -114,6 +114,7 @@ int make_geometry(const edhip_array* displacement, const int64_t* in_len, const 
         GridStamp now;
         now.raw = displacement->data;
         now.ws = ws;
+        now.generation = workspace_generation(stream);
         now.dtype = displacement->dtype;
         now.ndim = naxis + 1;
         for (int k = 0; k <= naxis; ++k) {
@@ -121,6 +122,7 @@ int make_geometry(const edhip_array* displacement, const int64_t* in_len, const 
             now.stride[k] = displacement->stride_bytes[k];
         }
         const bool stays = (flags & EDHIP_FLAG_GRID_STAYS) && stamp->raw == now.raw && stamp->ws == now.ws &&
+                           stamp->generation == now.generation &&
                            stamp->dtype == now.dtype && stamp->ndim == now.ndim &&
                            memcmp(stamp->shape, now.shape, sizeof(now.shape)) == 0 &&
                            memcmp(stamp->stride, now.stride, sizeof(now.stride)) == 0;

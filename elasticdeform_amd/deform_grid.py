@@ -24,6 +24,8 @@ There is no CPU fallback: without a GPU or without the built library the call ra
 import os
 import sys
 
+import warnings
+
 import numpy
 
 from . import _fastlane
@@ -291,6 +293,28 @@ _WINDOW_MARGIN = {'float32': {2: 12, 3: 16}, 'float64': {2: 24, 3: 32}}
 _WINDOW_MIN_LINE = 64                # the whole-line tile kernels' shortest line
 
 
+def _crop_window_pays(plan, shapes, names, todo, in_len, out_len):
+    """What the host knows without the device: does the smallest possible window (output box + margins + taps, at
+    least a tile kernel's shortest line) save enough filter work, summed over the inputs `todo`?  One rule for the
+    general path (_crop_windows) and for the repeat-call lanes (_fastlane.Lane.window_pays), so that repeated
+    identical calls take the same route and return the same bits."""
+    def volume(i, lens):            # voxels of input i when its deformed axes have extents `lens`
+        v = float(numpy.prod([int(d) for d in shapes[i]], dtype=numpy.float64))
+        for a, l in zip(plan.axis[i], lens):
+            v *= float(l) / float(shapes[i][a])
+        return v
+
+    def at_least(i):                # no window is smaller than the output box plus margins and taps
+        m = _WINDOW_MARGIN[names[i]][int(plan.order[i])]
+        return [min(n_in, max(n_out + 2 * m + int(plan.order[i]) + 3, _WINDOW_MIN_LINE))
+                for n_in, n_out in zip(in_len, out_len)]
+    if not todo:
+        return False
+    full = sum(volume(i, in_len) for i in todo)
+    least = sum(volume(i, at_least(i)) for i in todo)
+    return not (full - least < CROP_WINDOW_MIN_SAVING or least > CROP_WINDOW_MAX_FRACTION * full)
+
+
 def _crop_windows(plan, xs, disp_desc, dflag, crop, prefilter, device, stream, grid_stays=False):
     """Per input: a device tensor holding its filter window (2 ints per dimension, edhip_source_window), or
     None for 'filter the whole array'.  Floating-point volumes of orders 2 / 3 outside 'exact' arithmetic: the
@@ -307,20 +331,8 @@ def _crop_windows(plan, xs, disp_desc, dflag, crop, prefilter, device, stream, g
     ax0 = plan.axis[0]
     in_len = [int(xs[0].shape[a]) for a in ax0]
     out_len = [int(plan.output_shapes[0][a]) for a in ax0]
-
-    def volume(i, lens):            # voxels of input i when its deformed axes have extents `lens`
-        v = float(numpy.prod([int(d) for d in xs[i].shape], dtype=numpy.float64))
-        for a, l in zip(plan.axis[i], lens):
-            v *= float(l) / float(xs[i].shape[a])
-        return v
-
-    def at_least(i):                # no window is smaller than the output box plus margins and taps
-        m = _WINDOW_MARGIN[_dtype_name(xs[i])][int(plan.order[i])]
-        return [min(n_in, max(n_out + 2 * m + int(plan.order[i]) + 3, _WINDOW_MIN_LINE))
-                for n_in, n_out in zip(in_len, out_len)]
-    full = sum(volume(i, in_len) for i in todo)
-    least = sum(volume(i, at_least(i)) for i in todo)
-    if full - least < CROP_WINDOW_MIN_SAVING or least > CROP_WINDOW_MAX_FRACTION * full:
+    if not _crop_window_pays(plan, [tuple(int(d) for d in x.shape) for x in xs], [_dtype_name(x) for x in xs], todo,
+                             in_len, out_len):
         return wins
     torch = _torch()
     for i in todo:
@@ -336,9 +348,9 @@ def _crop_windows(plan, xs, disp_desc, dflag, crop, prefilter, device, stream, g
                                 _WINDOW_MIN_LINE,
                                 _flags | dflag | _lib.FLAG_FAST | (_lib.FLAG_GRID_STAYS if (grid_stays and dflag) else 0),
                                 stream, win.data_ptr())
-        grid_stays = True           # (the next input's window: same grid, just filtered)
         if st == 0:
             wins[i] = win
+            grid_stays = True       # (the next input's window: same grid, just filtered by THIS call)
     return wins
 
 
@@ -369,7 +381,7 @@ def _lane_lookup(gradient, X, displacement, order, mode, cval, crop, prefilter, 
     lane = _fastlane.lookup(sig)
     if lane is None:
         return sig, None
-    if lane is False or lane.max_saving >= CROP_WINDOW_MIN_SAVING:
+    if lane is False or lane.window_pays:
         return None, None
     return sig, lane
 
@@ -381,8 +393,11 @@ def _lane_build(sig, gradient, xs, dd, plan, prefilter, X_shape, crop):
         return
     try:
         lane = _fastlane.Lane(_this, gradient, xs, dd, plan, prefilter, X_shape, _flags, crop)
-    except Exception:
-        lane = False        # (the result of this call is already computed: a lane that cannot be built is no lane)
+    except (RuntimeError, ValueError, TypeError, MemoryError) as exc:
+        # the result of this call is already computed: a lane that cannot be built is no lane -- but say so once
+        warnings.warn("elasticdeform_amd: no repeat-call lane for this signature (%s: %s)" % (type(exc).__name__, exc),
+                      RuntimeWarning, stacklevel=3)
+        lane = False
     _fastlane.remember(sig, lane)
 
 

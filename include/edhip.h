@@ -126,8 +126,13 @@ enum edhip_flags {
                                     edhip_spline_filter_axes  16-bit input, float32 output: the first pass widens;
                                                   float32 input, 16-bit output with EDHIP_FLAG_SCRATCH_INPUT: the last pass
                                                   narrows; orders 2 / 3, lines of 64..256 samples, dense arrays.
-                                  A pair outside those envelopes returns EDHIP_ERR_UNSUPPORTED before anything is launched
-                                  (without the flag such pairs run on the exact kernels like any other dtype pair). */
+                                  A pair outside those envelopes returns EDHIP_ERR_UNSUPPORTED
+                                  (without the flag such pairs run on the exact kernels like any other dtype pair).
+                                  edhip_deform decides per input: the control-grid prefilter of a RAW_DISPLACEMENT call
+                                  (and the clear of a ZERO_GRADIENT call) has been enqueued by then, and with several
+                                  inputs the kernels of the inputs in front of the declined one have run -- a caller
+                                  that retries another way must treat every output of the call as unwritten and zero
+                                  gradient accumulators again.  The filter entry points decline before any launch. */
     /* edhip_deform only: `displacement` is the RAW control grid; the library applies the order-3
      * mirror prefilter along every grid axis itself (what deform_grid.py:166-169,269-272 does with
      * SciPy before calling the C code), in one launch, with the same arithmetic and the same

@@ -150,5 +150,17 @@ for case in range(ncases):
         print("   ", str(e).strip().split("\n")[0][:300])
     finally:
         dgm.CROP_WINDOW_MIN_SAVING, dgm.CROP_WINDOW_MAX_FRACTION = saved
+# profiling build only: the tables kernel counts control columns a wide grid's per-strip window did not hold
+try:
+    from elasticdeform_amd import _lib
+    import ctypes
+    fn = _lib.load().edhip_debug_wide_clamped
+    fn.restype = ctypes.c_uint
+    clamped = int(fn())
+    if clamped:
+        fails += 1
+        print("FAIL: %d control columns outside a per-strip Q window (TileGeom::q_win under-sized)" % clamped)
+except AttributeError:
+    pass
 print("%d cases, %d failures (seed %d)" % (ncases, fails, seed))
 sys.exit(1 if fails else 0)

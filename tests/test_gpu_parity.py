@@ -1628,3 +1628,78 @@ def test_zero_gradient_flag_clears_dense_accumulators_on_every_route():
     with pytest.raises(Exception):
         _lib.deform(True, [dgm._desc(big[:, :, ::2])], dgm._desc(d), None, [dgm._desc(dY)], [(0, 1, 2)], [3], [3], [0.0],
                     None, _lib.FLAG_AUTO | _lib.FLAG_RAW_DISPLACEMENT | _lib.FLAG_ZERO_GRADIENT, stream)
+
+
+# ---- round 5: K1 with sampled tile boxes (csrc/deform_k1.hip) ------------------------------------------------------
+@pytest.mark.parametrize("mode", ["nearest", "wrap", "reflect", "mirror", "constant"])
+def test_k1_general_tiles_every_mode(mode):
+    """K1 takes the tiles at the array's faces (and partial tiles) through general coordinates with a SAMPLED box -- the
+    range of the mapped coordinate over 64 of the tile's voxels, the array's ends included where the raw range
+    straddles them -- and checks every window against it (deform_k1.hip).  Displacements far larger than the array's
+    margin, so that whole tiles fold, clamp, wrap or turn constant; extents that leave partial tiles on every axis;
+    crop and affine map."""
+    rng = np.random.default_rng(len(mode) * 7 + 1)
+    shape = (53, 70, 91)
+    X = rng.random(shape).astype(np.float32)
+    aff = np.eye(3, 4)
+    aff[:, :3] += rng.standard_normal((3, 3)) * 0.05
+    aff[:, 3] = rng.standard_normal(3) * 2
+    for order in (1, 2, 3):
+        for sigma, extra in ((9.0, {}), (4.0, dict(crop=(slice(5, 50), slice(0, 70), slice(11, 80)))), (6.0, dict(affine=aff))):
+            disp = rng.standard_normal((3, 4, 3, 5)) * sigma
+            kw = dict(order=order, mode=mode, cval=-0.75, **extra)
+            want = orc.deform_grid(X, disp, **kw)
+            got = ed.deform_grid(X, disp, **kw)
+            # (prefiltered white noise of unit range reaches ~2.5: the 1e-5 budget scales with it)
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=3e-5, err_msg="order %d sigma %g %s" % (order, sigma, list(extra)))
+
+
+@pytest.mark.parametrize("points", [(9, 9, 9), (13, 11, 13)])
+def test_k1_windows_outside_their_sampled_box_are_redone(points):
+    """A control grid of 9-13 points on a 64^3 volume bends the field inside a tile far beyond what the margin of the
+    sampled boxes covers (the margin is capped at 0.75 voxels): many windows fall outside their tile's box, the lanes
+    raise their flags, and the waves redo those voxels straight from global memory (k1_fix).  Same results as ever --
+    the margin only decides how often that happens."""
+    rng = np.random.default_rng(sum(points))
+    shape = (64, 64, 64)
+    X = rng.random(shape).astype(np.float32)
+    for order, mode in ((3, "mirror"), (1, "constant"), (2, "nearest"), (3, "reflect")):
+        disp = rng.standard_normal((3,) + points) * 3.0
+        kw = dict(order=order, mode=mode, cval=0.5)
+        np.testing.assert_allclose(ed.deform_grid(X, disp, **kw), orc.deform_grid(X, disp, **kw), rtol=1e-5, atol=3e-5,
+                                   err_msg="order %d %s" % (order, mode))
+    # several channels (step axes) through the same boxes, and a batch with one control grid per sample
+    Xc = rng.random((3,) + shape).astype(np.float32)
+    disp = rng.standard_normal((3,) + points) * 3.0
+    kw = dict(order=3, mode="mirror", axis=(1, 2, 3))
+    np.testing.assert_allclose(ed.deform_grid(Xc, disp, **kw), orc.deform_grid(Xc, disp, **kw), rtol=1e-5, atol=3e-5)
+
+
+def test_grid_stamp_does_not_outlive_its_workspace():
+    """EDHIP_FLAG_GRID_STAYS: the filtered copy of the control grid lives in the head of the
+    stream's workspace; a call that frees or regrows that buffer must void the stamp, or the next call would skip
+    the prefilter and work from a cleared grid.  Sequence on one stream: RAW call (stamps), a filter call that
+    grows the workspace far beyond the first call's, the RAW + GRID_STAYS call again -- same result."""
+    import importlib
+    from elasticdeform_amd import _lib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    stream_obj = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream_obj):
+        stream = stream_obj.cuda_stream
+        X = torch.from_numpy(rng.random((40, 48, 56), dtype=np.float32)).to(dev)
+        disp = torch.from_numpy(rng.standard_normal((3, 4, 4, 5)) * 2.0).to(dev)
+        out1, out2 = torch.empty_like(X), torch.empty_like(X)
+
+        def call(out, flags):
+            assert _lib.deform(False, [dgm._desc(X)], dgm._desc(disp), None, [dgm._desc(out)], [(0, 1, 2)], [1], [3], [0.0],
+                               None, _lib.FLAG_AUTO | _lib.FLAG_RAW_DISPLACEMENT | flags, stream) == 0
+        call(out1, 0)
+        # an order-5 float64 filter of a long 1-D array runs on the exact kernel with fp64 scratch from the workspace
+        big = torch.from_numpy(rng.random(3_000_000)).to(dev)
+        big_out = torch.empty_like(big)
+        _lib.spline_filter1d(dgm._desc(big), dgm._desc(big_out), 0, 5, False, _lib.FLAG_EXACT, stream)
+        call(out2, _lib.FLAG_GRID_STAYS)
+        stream_obj.synchronize()
+    assert torch.equal(out1, out2)

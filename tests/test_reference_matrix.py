@@ -112,21 +112,21 @@ def test_crop_3d():
 
 
 def test_crop_rotate_zoom():
-    """full[crop] == cropped for every rotate / zoom / affine combination (:121-133)."""
-    X = RNG.random((100, 100))
-    displacement = RNG.standard_normal((2, 3, 3)) * 10
+    """full[crop] == cropped for EVERY rotate / zoom / affine combination, as the reference asserts it (:121-133): the
+    crop keeps the centre of the output where it was ((10 + 90) / 2 == (20 + 80) / 2 == 50), and rotate / zoom act
+    about the centre of the (cropped) output (deform_grid.py:401-438), so the transform commutes with this crop."""
     crop = (slice(10, 90), slice(20, 80))
     for rotate in (-30, 0, 30, None):
-        for zoom in (0.5, 1, 1.5, None):
+        for zoom in (0.5, 1.0, 1.5, None):
             for affine in (None, np.eye(3)):
+                X = RNG.random((100, 100))
+                displacement = RNG.standard_normal((2, 3, 3)) * 3
                 kw = dict(rotate=rotate, zoom=zoom, affine=affine)
                 full = elasticdeform.deform_grid(X, displacement, **kw)
                 part = elasticdeform.deform_grid(X, displacement, crop=crop, **kw)
                 assert part.shape == (80, 60)
-                if rotate in (0, None) and zoom in (1, None):
-                    # rotation / zoom are about the centre of the (cropped) output, so only the
-                    # identity transform commutes with cropping
-                    np.testing.assert_allclose(full[crop], part, rtol=1e-5, atol=1e-8)
+                np.testing.assert_allclose(full[crop], part, rtol=1e-5, atol=1e-8,
+                                           err_msg="rotate=%r zoom=%r affine=%s" % (rotate, zoom, affine is not None))
 
 
 def test_multi_2d():

@@ -18,26 +18,24 @@ import os
 root, commit = sys.argv[1], sys.argv[2]
 
 
-def kernel_sources_sha16():
-    """Hash of the sources the two measured kernels are built from: bench.py reports `traffic` only while it
-    matches the tree it runs in (a stamp that cannot go stale unnoticed)."""
-    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for f in ("deform_hot.hip", "ed_tile.h", "ed_device.h"):
-        with open(os.path.join(here, "elasticdeform_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_sha16      # noqa: E402  (one list of files for the stamp and for its check)
 
 
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+                                 "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
             vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/time_k12.py (the bench workload: "
                "256^3 float32, order 3, mirror, sigma 5), mean per dispatch, KB -> bytes",
        "algorithmic_bytes_per_launch": 134217728, "kernel_sources_sha16": kernel_sources_sha16(), "kernels": {}}
-for tag, key in (("K1", "hot_fwd_kernel<3, false, 0,"), ("K2", "hot_grad_kernel<3, false")):
+def mean(c, k):
+    return sum(c[k]) / len(c[k]) if c.get(k) else None
+
+
+for tag, key in (("K1", "k1_fwd_kernel<3, false"), ("K2", "hot_grad_kernel<3, false")):
     for name, c in vals.items():
         if key in name and c.get("FETCH_SIZE") and c.get("WRITE_SIZE"):
             fkb = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
@@ -46,4 +44,21 @@ for tag, key in (("K1", "hot_fwd_kernel<3, false, 0,"), ("K2", "hot_grad_kernel<
             out["kernels"][tag] = {"kernel": name, "fetch_kb": round(fkb), "fetch_correction_kb": corr,
                                    "write_kb": round(wkb),
                                    "bytes_per_launch": int((fkb + corr + wkb) * 1024), "commit": commit}
+            # busy fractions: GRBM_GUI_ACTIVE is summed over the 8 XCDs -> cycles of the launch = / 8;
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, SQ_LDS_IDX_ACTIVE cycles over the 256 CUs
+            gui = mean(c, "GRBM_GUI_ACTIVE")
+            if gui:
+                cyc = gui / 8.0
+                k = out["kernels"][tag]
+                k["launch_cycles"] = round(cyc)
+                if mean(c, "SQ_ACTIVE_INST_VALU"):
+                    k["valu_busy"] = round(mean(c, "SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / cyc, 3)
+                if mean(c, "SQ_LDS_IDX_ACTIVE"):
+                    k["lds_busy"] = round(mean(c, "SQ_LDS_IDX_ACTIVE") / 256.0 / cyc, 3)
+                    if mean(c, "SQ_LDS_BANK_CONFLICT"):
+                        k["lds_conflict_share"] = round(mean(c, "SQ_LDS_BANK_CONFLICT") / mean(c, "SQ_LDS_IDX_ACTIVE"), 3)
+                for nm, cn in (("valu_per_64_voxels", "SQ_INSTS_VALU"), ("salu_per_64_voxels", "SQ_INSTS_SALU"),
+                               ("lds_per_64_voxels", "SQ_INSTS_LDS")):
+                    if mean(c, cn):
+                        k[nm] = round(mean(c, cn) / 262144.0, 1)
 print(json.dumps(out, indent=1))
