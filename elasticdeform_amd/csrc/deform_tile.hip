@@ -306,8 +306,10 @@ __device__ __forceinline__ void strip_prologue(const GridGeom& g, const IOView& 
         const int r = tid >> 2;
         const int oz = min(sp.tz * kT + (r >> 3), tg.out_len[0] - 1);
         const int oy = min(sp.ty * kT + (r & 7), tg.out_len[1] - 1);
-        const double* src = tg.q_global + (int64_t)sp.sample * tg.q_bstride +
-                            ((int64_t)oz * tg.out_len[1] + oy) * rowlen;
+        // (wide control grids: Q is laid out per x-strip, tg.ncpx = q_win columns each -- TileGeom::q_win)
+        const int64_t qrow_id = tg.q_win ? ((int64_t)oz * tg.out_len[1] + oy) * tg.q_strips + (sp.tx0 * kT) / tg.q_strip_vox
+                                         : (int64_t)oz * tg.out_len[1] + oy;
+        const double* src = tg.q_global + (int64_t)sp.sample * tg.q_bstride + qrow_id * rowlen;
         double* dst = sQ + r * rowlen;
         for (int k = tid & 3; k < rowlen; k += 4)
             dst[k] = src[k];
@@ -986,7 +988,9 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_direct_kernel(const GridG
             if (oz >= tg.out_len[0])
                 continue;
             const int o[3] = {oz, oy, ox};
-            const double* qrow0 = qs + ((int64_t)oz * tg.out_len[1] + oy) * 4 * tg.ncpx;
+            const int64_t qrow_id = tg.q_win ? ((int64_t)oz * tg.out_len[1] + oy) * tg.q_strips + (tx * kT) / tg.q_strip_vox
+                                             : (int64_t)oz * tg.out_len[1] + oy;
+            const double* qrow0 = qs + qrow_id * 4 * tg.ncpx;
             // coordinates (same arithmetic as voxel_coords, tables read from global memory)
             int ci[3];
             T fr[3];
@@ -1335,13 +1339,18 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // because the level-2 kernel stages Q rows like the others.  256^3, 16^3 grid, order 5 on the row kernel:
     // forward 4.7 ms, gradient 83 ms)
     constexpr bool kWaveOrder = std::is_same<T, float>::value && ORDER >= 4;
-    const bool wide_wave = wide && kWaveOrder;
+    const bool wide_wave = wide && kWaveOrder && tg.in_stride[2] == 1 && tg.out_stride[2] == 1 && !ed_env("EDHIP_NO_HOT") &&
+                           !ed_env("EDHIP_WAVE");
+    // (round 5: the general kernels read the per-strip layout too -- float64 volumes and layouts without unit stride along x
+    // no longer fall to the row kernel: 256^3 float64, 16^3 grid, order 3 gradient 22.3 ms -> see profiles/r05_bench_misc.txt)
+    bool wide_hot = false;       // the level-1 kernels of deform_hot.hip / deform_k1.hip / deform_wave.hip take the call
     if (wide) {
-        if constexpr (!(std::is_same<T, float>::value && ORDER >= 1))
+        if constexpr (!(std::is_floating_point<T>::value && ORDER >= 1))
             return hipErrorNotSupported;
-        if (nb != 1 || tg.in_stride[2] != 1 || tg.out_stride[2] != 1 || ed_env("EDHIP_NO_HOT") || ed_env("EDHIP_WAVE") ||
-            ed_env("EDHIP_RECORDS"))
+        if (nb != 1 || ed_env("EDHIP_RECORDS"))
             return hipErrorNotSupported;
+        wide_hot = std::is_same<T, float>::value && tg.in_stride[2] == 1 && tg.out_stride[2] == 1 && !ed_env("EDHIP_NO_HOT") &&
+                   !ed_env("EDHIP_WAVE");
         if (!wide_wave) {
             const int win = wide_window(g);
             const int64_t strips = (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT);
@@ -1383,7 +1392,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     tg.nstrips = (int)nstrips;
     tg.ntiles = (int)ntiles;
     tg.q_bstride = (long long)(q_global_bytes(g) / 8);
-    tg.ncpx = (int)g.ncp[2];
+    // (wide grids: the kernels see a grid of q_win columns, the strip's window)
+    const size_t qcols = tg.q_win ? (size_t)tg.q_win : (size_t)g.ncp[2];
+    tg.ncpx = (int)qcols;
     // LDS: head | Q | overlay (box | D, P).  K1 float32 odd orders: two shifted copies of 4096
     // elements; otherwise one copy (6144 x 4 bytes or 4096 x 8 bytes)
     size_t box;
@@ -1399,8 +1410,26 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         tg.box_cap = sizeof(T) == 4 ? (ORDER >= 4 ? 8192 : 6144) : 4096;
         box = (size_t)tg.box_cap * sizeof(T);
     }
+    tg.off_ov = (int)(kOffQ + ((8 * (size_t)(kT * kT * 4) * qcols + 15) & ~(size_t)15));
+    if (tg.off_ov + box > (size_t)64 * 1024) {
+        // the Q rows of a wide window leave less than the standard box inside the 64 KiB a block may ask for
+        const size_t room = (size_t)64 * 1024 - tg.off_ov;
+        if (room < (size_t)16 * 1024)
+            return hipErrorNotSupported;
+        if (GRAD) {
+            tg.box_cap = (int)(((room - 64) / sizeof(T)) & ~(size_t)15);
+            box = (size_t)tg.box_cap * sizeof(T) + 64;
+        } else if (PAIR) {
+            size_t cap = room / (2 * sizeof(T));
+            cap = ((cap - 56) / 64) * 64 + 56;
+            tg.box_cap = (int)cap;
+            box = 2 * cap * sizeof(T);
+        } else {
+            tg.box_cap = (int)((room / sizeof(T)) & ~(size_t)15);
+            box = (size_t)tg.box_cap * sizeof(T);
+        }
+    }
     size_t overlay = (box + 15) & ~(size_t)15;
-    tg.off_ov = (int)(kOffQ + ((q_bytes(g) + 15) & ~(size_t)15));
     size_t lds = tg.off_ov + overlay;
     if (const char* pad = ed_env("EDHIP_LDS_PAD"))
         lds += (size_t)atoi(pad);
@@ -1686,8 +1715,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, false);
                     hg.hint = sh ? tg.hint : nullptr;
                 }
-                if ((v.out16 || (wide && !wide_wave)) && !hlds)
+                if (v.out16 && !hlds)
                     return hipErrorNotSupported;        // (nothing has been launched yet)
+                // (a wide grid whose window leaves no room for a hot box: the general kernels below, same tables)
                 hg.lds_grp = (int)((hlds + 15) & ~(size_t)15);
                 // EDHIP_FLAG_KEEP_BOXES / USE_BOXES: the forward kernel's tile boxes -- and, orders 1-3, its
                 // per-voxel coordinate records -- live in a buffer of their own (nothing else writes it) under
@@ -2035,9 +2065,12 @@ bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)
     // unit stride along x go to the level-1 kernels on per-strip Q tables (launch_tile), everything else to the
     // row kernel of deform_fast.hip
     if (wide_grid(g)) {
-        if (v.in_dtype != EDHIP_F32 || v.order < 1 || v.in_stride[2] != 4 || v.out_stride[2] != 4)
+        if (v.order < 1)
             return false;
-        if (v.order <= 3 &&
+        // float32 orders 4 / 5 with unit stride along x: the one-wave kernels, plain tables, any width; everything else
+        // on per-strip tables, whose window has to fit
+        const bool wave = v.in_dtype == EDHIP_F32 && v.order >= 4 && v.in_stride[2] == 4 && v.out_stride[2] == 4;
+        if (!wave &&
             (wide_window(g) > kWideMaxWin || (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT) > 256))
             return false;
     }

@@ -315,6 +315,32 @@ def test_wide_control_grids_run_on_the_tile_kernels(points):
     g64 = ed.deform_grid(X.astype(np.float64), disp, **kw)
     np.testing.assert_allclose(g32, g64, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(g64, orc.deform_grid(X.astype(np.float64), disp, **kw), rtol=1e-11, atol=1e-11)
+    # round 5: float64 volumes (and float32 layouts without unit stride along x) run on the GENERAL tile kernels with the
+    # same per-strip tables instead of the row kernel (256^3 float64, 16^3 grid, order 3 gradient: 22.3 ms there) --
+    # every order, crop + affine, and the level-1 timing hook fires
+    for order in (1, 2, 3, 5):
+        for mode, extra in (("mirror", {}), ("nearest", dict(crop=(slice(3, 30), slice(0, 70), slice(20, 141)))),
+                            ("constant", dict(affine=np.eye(3, 4) + rng.standard_normal((3, 4)) * 0.03))):
+            X = rng.random(shape)
+            disp = rng.standard_normal((3,) + points) * 1.5
+            kw = dict(order=order, mode=mode, cval=0.25, **extra)
+            L.edhip_profile_dominant(1)
+            try:
+                got = ed.deform_grid(X, disp, **kw)
+                hot_us = L.edhip_profile_last_us()
+            finally:
+                L.edhip_profile_dominant(0)
+            np.testing.assert_allclose(got, orc.deform_grid(X, disp, **kw), rtol=1e-11, atol=1e-11)
+            assert hot_us > 0, "float64: the level-1 tile kernel did not run"
+            dY = rng.random(got.shape)
+            gw = orc.deform_grid_gradient(dY, disp, X_shape=shape, **kw)
+            gg = ed.deform_grid_gradient(dY, disp, X_shape=shape, **kw)
+            np.testing.assert_allclose(gg, gw, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(gw).max()))
+    # float32, channels last: no unit stride along x -> general kernels, per-strip tables
+    Xcl = np.ascontiguousarray(rng.random(shape + (2,)).astype(np.float32))
+    disp = rng.standard_normal((3,) + points) * 1.5
+    kw = dict(order=3, mode="mirror", axis=(0, 1, 2))
+    np.testing.assert_allclose(ed.deform_grid(Xcl, disp, **kw), orc.deform_grid(Xcl, disp, **kw), **F32_TOL)
 
 
 def test_integer_gradient_is_bit_exact():
