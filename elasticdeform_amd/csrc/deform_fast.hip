@@ -760,6 +760,301 @@ __global__ __launch_bounds__(kBlock) void deform_fast2_grad_kernel(const GridGeo
     }
 }
 
+// ================================================================================================
+// Four deformed axes, gradient (round 5; the reference takes any number of axes in one loop,
+// _deform_grid.c:158-175, deform.c:953-995): deform_fast2_grad_kernel's scheme with two more axes.  A block owns a
+// tile of 4 x 4 x 4 x 4 output voxels (a tile of 2 x 2 x 4 x 16 has a box of 10 x 10 x 12 x 25 cells under a field
+// whose gradient is 0.3: every axis of the box grows with the LONGEST edge of the tile; measured 1.8 ms for 32^4, all
+// of it the direct fallback), finds the 4-D box of its tap windows, scatters the
+// (order + 1)^4 taps of a voxel into fixed-point LDS cells (integer atomics: 256 per voxel at order 3, where the row
+// kernel and the exact kernel issue 256 GLOBAL float atomics) and flushes every touched source element with one
+// global atomic, mirror-mapped as deform.c:795-813 maps the taps of a window that sticks out.  The per-block scale
+// (2^31 - 2^10) / (w_max^4 * sum |dY|) cannot overflow.  Blocks whose box does not fit and non-finite gradients fall
+// back to direct global atomics.  Control grids of up to 6 points along x (the lanes of a wave contract the 64
+// taps of the three slow axes, one element of E at a time); larger ones stay where they were.
+// ================================================================================================
+constexpr int kT4A = 4, kT4B = 4, kT4C = 4, kT4X = 4;       // tile: 64 rows x 4 voxels along x
+constexpr int kBoxBytes4 = 40 * 1024;
+constexpr int kMaxE4 = 24;                                  // 4 * ncp_x doubles of E per row
+
+template <typename T, int ORDER>
+__global__ __launch_bounds__(kBlock) void deform_fast4_grad_kernel(const GridGeom g, const IOView v,
+                                                                   const FastView<4> fv, const int xblocks,
+                                                                   const int tiles_b, const int tiles_c, const int dbg)
+{
+    constexpr int NT = ORDER + 1;
+    constexpr int kRows4 = kT4A * kT4B * kT4C;
+    typedef typename Fixed<T>::acc_t acc_t;
+    typedef typename Fixed<T>::uacc_t uacc_t;
+    constexpr int kCap = kBoxBytes4 / (int)sizeof(acc_t);
+    __shared__ double s_w[kRows4][3][4];           // displacement weights of the slow axes per row
+    __shared__ int s_i[kRows4][3][4];
+    __shared__ double s_E[kRows4][kMaxE4];         // per-row contraction of the grid over the slow axes
+    __shared__ int s_red[8];                       // lo[4], hi[4]
+    __shared__ T s_sum[kWaves];
+    __shared__ __attribute__((aligned(16))) acc_t s_box[kCap];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xb = blockIdx.x % xblocks;
+    int tt = blockIdx.x / xblocks;
+    const int tc = tt % tiles_c;
+    tt /= tiles_c;
+    const int tb = tt % tiles_b;
+    const int ta = tt / tiles_b;
+    const int64_t ncpx = g.ncp[3];
+    const int nE = 4 * (int)ncpx;                  // <= kMaxE4 (host)
+
+    auto row_index = [&](int rr, int k) -> int64_t {       // output index of row rr of the tile along slow axis k
+        return k == 0 ? (int64_t)ta * kT4A + (rr >> 4) : (k == 1 ? (int64_t)tb * kT4B + ((rr >> 2) & 3) : (int64_t)tc * kT4C + (rr & 3));
+    };
+    for (int t = tid; t < kRows4 * 3; t += kBlock) {
+        const int rr = t / 3, k = t - rr * 3;
+        const int64_t ok = min(row_index(rr, k), g.out_len[k] - 1);
+        const double cp = control_coordinate(g.ncp[k], ok + g.off[k], g.in_len[k]);
+        const int64_t start = window_start(cp, 3);
+        const bool edge = start < 0 || start + 3 >= g.ncp[k];
+        double w[4];
+        spline_weights(cp, 3, w);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            s_w[rr][k][l] = w[l];
+            s_i[rr][k][l] = (int)(edge ? mirror_index(start + l, g.ncp[k]) : start + l);
+        }
+    }
+    if (tid < 8)
+        s_red[tid] = tid < 4 ? 0x7fffffff : (int)0x80000000;
+    __syncthreads();
+    // E of the wave's 16 rows: the 64 taps of the three slow axes are the 64 lanes, a butterfly sum per element
+    for (int q = 0; q < kRows4 / kWaves; ++q) {
+        const int rr = wave * (kRows4 / kWaves) + q;
+        const int l0 = lane >> 4, l1 = (lane >> 2) & 3, l2 = lane & 3;
+        const int64_t offs = g.disp_stride[1] * s_i[rr][0][l0] + g.disp_stride[2] * s_i[rr][1][l1] + g.disp_stride[3] * s_i[rr][2][l2];
+        const double wprod = s_w[rr][0][l0] * s_w[rr][1][l1] * s_w[rr][2][l2];
+        double mine = 0.0;
+        for (int e0 = 0; e0 < nE; e0 += 4) {
+            double a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u < nE ? e0 + u : nE - 1;
+                const int h = e / (int)ncpx, j = e - h * (int)ncpx;
+                a[u] = load_as_double(g.disp + g.disp_stride[0] * h + g.disp_stride[4] * j + offs, g.disp_dtype) * wprod;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    a[u] += __shfl_xor(a[u], m);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                mine = lane == e0 + u ? a[u] : mine;
+        }
+        if (lane < nE)
+            s_E[rr][lane] = mine;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- this lane's voxel: row tid / 4 of the tile (its wave made that row's E), x = tid % 4 ---------------------
+    const int rr = tid >> 2;
+    int64_t o[4];
+    o[0] = row_index(rr, 0);
+    o[1] = row_index(rr, 1);
+    o[2] = row_index(rr, 2);
+    o[3] = (int64_t)xb * kT4X + (tid & 3);
+    const bool valid = o[0] < g.out_len[0] && o[1] < g.out_len[1] && o[2] < g.out_len[2] && o[3] < g.out_len[3];
+    int st[4] = {0, 0, 0, 0};
+    T fr[4] = {0, 0, 0, 0};
+    bool act = false;
+    int64_t obase = 0;
+    int lo[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    int hi[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    if (valid) {
+        double wx[4];
+        int ix[4];
+        {
+            const double cp = control_coordinate(ncpx, o[3] + g.off[3], g.in_len[3]);
+            const int64_t start = window_start(cp, 3);
+            const bool edge = start < 0 || start + 3 >= ncpx;
+            spline_weights(cp, 3, wx);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                ix[l] = (int)(edge ? mirror_index(start + l, ncpx) : start + l);
+        }
+        bool constant = false;
+        double cc[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            double d = 0.0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                d += wx[l] * s_E[rr][h * (int)ncpx + ix[l]];
+            double c;
+            if (g.has_affine) {
+                c = g.affine[h * 5 + 4];
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    c += g.affine[h * 5 + l] * (double)o[l];
+            } else {
+                c = (double)o[h];
+            }
+            c = map_coordinate(c + (double)g.off[h] + d, g.in_len[h], v.mode);
+            constant = constant || !(c > -1.0);
+            cc[h] = c;
+        }
+        if (!constant) {
+            act = true;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const double fl = floor((ORDER & 1) ? cc[h] : cc[h] + 0.5);
+                st[h] = (int)fl - ORDER / 2;
+                fr[h] = (T)(cc[h] - fl);
+                lo[h] = st[h];
+                hi[h] = st[h] + ORDER;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            obase += fv.out_stride[k] * o[k];
+    }
+    // ---- the block's box ---------------------------------------------------------------------------------------
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        int l = lo[h], u = hi[h];
+        for (int m = 32; m >= 1; m >>= 1) {
+            l = min(l, __shfl_xor(l, m));
+            u = max(u, __shfl_xor(u, m));
+        }
+        if (lane == 0) {
+            atomicMin(&s_red[h], l);
+            atomicMax(&s_red[4 + h], u);
+        }
+    }
+    __syncthreads();
+    const bool any = s_red[4] >= s_red[0];
+    if (!any)
+        return;                                    // nothing to scatter (uniform)
+    int b0[4], ext[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        b0[h] = s_red[h];
+        ext[h] = s_red[4 + h] - s_red[h] + 1;
+    }
+    const int pitch = ext[3] | 1;                  // odd: neighbouring rows spread over the banks
+    bool fits = true;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        fits = fits && ext[h] > 0 && ext[h] < 1024;
+    const int nrows = fits ? ext[0] * ext[1] * ext[2] : 0;
+    fits = fits && (int64_t)nrows * pitch <= kCap;
+    const int nbox = fits ? nrows * pitch : 0;
+
+    T* dx = reinterpret_cast<T*>(const_cast<char*>(v.in));
+    const T* __restrict__ dy = reinterpret_cast<const T*>(v.out);
+    constexpr double kW1 = ORDER == 1 ? 1.0 : ORDER == 2 ? 0.75 : 2.0 / 3.0;
+    T w[4][NT];
+    if (act) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            weights_from_frac2<T, ORDER>(fr[h], w[h]);
+    }
+    // taps of the two slow axes picked with select chains inside rolled loops (fully unrolled: 256 registers)
+    auto pick = [&](int h, int l) {
+        T r = w[h][0];
+#pragma unroll
+        for (int q = 1; q < NT; ++q)
+            r = l == q ? w[h][q] : r;
+        return r;
+    };
+
+    for (int64_t ss = 0; ss < v.nsteps; ++ss) {
+        int64_t in_off = 0, out_off = 0;
+        {
+            int64_t r = ss;
+            for (int l = 0; l < v.nstep; ++l) {
+                const int64_t q = r / v.step_len[l];
+                const int64_t c = r - q * v.step_len[l];
+                in_off += v.in_step_stride[l] * c;
+                out_off += v.out_step_stride[l] * c;
+                r = q;
+            }
+        }
+        T* dst = dx + in_off;
+        if (ss > 0)
+            __syncthreads();                       // previous step's flush is done with the box
+        for (int e = tid; e < nbox; e += kBlock)
+            s_box[e] = 0;
+        T gval = act ? dy[out_off + obase] : (T)0;
+        const bool finite = fabs((double)gval) <= 1.7976931348623157e308 && gval == gval;
+        if ((!fits || !finite) && gval != (T)0) {
+            // direct global atomics: blocks without a box, inf / NaN gradients
+#pragma unroll 1
+            for (int t = 0; t < NT * NT * NT * NT; ++t) {
+                const int l3 = t % NT, l2 = (t / NT) % NT, l1 = (t / (NT * NT)) % NT, l0 = t / (NT * NT * NT);
+                const int64_t a0 = mirror_index(st[0] + l0, g.in_len[0]), a1 = mirror_index(st[1] + l1, g.in_len[1]);
+                const int64_t a2 = mirror_index(st[2] + l2, g.in_len[2]), a3 = mirror_index(st[3] + l3, g.in_len[3]);
+                atomic_add(dst + (a0 * fv.in_stride[0] + a1 * fv.in_stride[1] + a2 * fv.in_stride[2] + a3 * fv.in_stride[3]),
+                           gval * pick(0, l0) * pick(1, l1) * pick(2, l2) * pick(3, l3));
+            }
+            gval = 0;
+        }
+        if (!fits || !finite)
+            gval = 0;
+        T gm = fabs(gval);
+        for (int m = 32; m >= 1; m >>= 1)
+            gm += __shfl_xor(gm, m);
+        if (lane == 0)
+            s_sum[wave] = gm;
+        __syncthreads();                           // box zeroed, sums known
+        const T gtot = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        if (!fits || gtot == (T)0)
+            continue;                              // (uniform)
+        const T scale = (T)(Fixed<T>::kRange / (kW1 * kW1 * kW1 * kW1 * 1.001 * (double)gtot));
+        const T inv_scale = (T)1 / scale;
+        if (gval != (T)0 && !ED_DBG(dbg, 1)) {       // (ablation 1: no scatter)
+            acc_t* bp = s_box + ((((st[0] - b0[0]) * ext[1] + (st[1] - b0[1])) * ext[2] + (st[2] - b0[2])) * pitch + (st[3] - b0[3]));
+            const T gs = gval * scale;
+#pragma unroll 1
+            for (int l0 = 0; l0 < NT; ++l0) {
+                const T g0 = gs * pick(0, l0);
+#pragma unroll 1
+                for (int l1 = 0; l1 < NT; ++l1) {
+                    const T g1 = g0 * pick(1, l1);
+                    acc_t* p1 = bp + (l0 * ext[1] + l1) * ext[2] * pitch;
+#pragma unroll
+                    for (int l2 = 0; l2 < NT; ++l2) {
+                        const T g2 = g1 * w[2][l2];
+#pragma unroll
+                        for (int l3 = 0; l3 < NT; ++l3)
+                            atomicAdd(reinterpret_cast<uacc_t*>(p1 + l2 * pitch + l3), (uacc_t)Fixed<T>::round(g2 * w[3][l3]));
+                    }
+                }
+            }
+        }
+        __syncthreads();                           // all contributions are in
+        // flush: 16 lanes per box row
+        {
+            const int grp = tid >> 4, sub = tid & 15;
+            const float inv2 = 1.0f / (float)ext[2], inv1 = 1.0f / (float)ext[1];
+            for (int row = grp; row < nrows; row += kBlock / 16) {
+                const int t1 = (int)(((float)row + 0.5f) * inv2), r2 = row - t1 * ext[2];
+                const int r0 = (int)(((float)t1 + 0.5f) * inv1), r1 = t1 - r0 * ext[1];
+                const int64_t base = mirror_index(b0[0] + r0, g.in_len[0]) * fv.in_stride[0] +
+                                     mirror_index(b0[1] + r1, g.in_len[1]) * fv.in_stride[1] +
+                                     mirror_index(b0[2] + r2, g.in_len[2]) * fv.in_stride[2];
+                for (int xr = sub; xr < ext[3]; xr += 16) {
+                    const acc_t a = s_box[row * pitch + xr];
+                    if (ED_DBG(dbg, 2) ? a == (acc_t)0x7ffffff1 : a != 0)       // (ablation 2: no flush atomics)
+                        atomic_add(dst + (base + mirror_index(b0[3] + xr, g.in_len[3]) * fv.in_stride[3]), (T)a * inv_scale);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int NAXIS, int ORDER>
 hipError_t launch_typed(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream)
 {
@@ -795,6 +1090,20 @@ hipError_t launch_typed(const GridGeom& g, const IOView& v, int gradient, hipStr
                 return hipErrorInvalidValue;
             hipLaunchKernelGGL((deform_fast2_grad_kernel<T, ORDER>), dim3((unsigned)nblk2), dim3(kBlock), 0,
                                stream, g, ve, fv, nrows, (int)xblocks);
+            return hipGetLastError();
+        }
+    }
+    // (order 1: 16 taps per voxel -- the row kernel's 16 global atomics are faster, 0.32 against 0.72 ms for 32^4)
+    if constexpr (NAXIS == 4 && ORDER >= 2 && ORDER <= 3) {
+        if (gradient && 4 * g.ncp[3] <= kMaxE4 && !ed_env("EDHIP_4D_DIRECT_GRAD")) {
+            const int64_t ta = (g.out_len[0] + kT4A - 1) / kT4A, tb = (g.out_len[1] + kT4B - 1) / kT4B,
+                          tc = (g.out_len[2] + kT4C - 1) / kT4C, xb4 = (g.out_len[3] + kT4X - 1) / kT4X;
+            const int64_t nblk4 = ta * tb * tc * xb4;
+            if (nblk4 > 0x7fffffffLL || tb > 0x7fffffffLL || tc > 0x7fffffffLL)
+                return hipErrorInvalidValue;
+            const int dbg4 = ed_env("EDHIP_4D_DBG") ? atoi(ed_env("EDHIP_4D_DBG")) : 0;
+            hipLaunchKernelGGL((deform_fast4_grad_kernel<T, ORDER>), dim3((unsigned)nblk4), dim3(kBlock), 0, stream, g, ve,
+                               fv, (int)xb4, (int)tb, (int)tc, dbg4);
             return hipGetLastError();
         }
     }
@@ -847,9 +1156,10 @@ bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient)
 {
     if (g.naxis < 1 || g.naxis > 4 || (g.naxis == 4 && v.order > 3))
         return false;
-    // (four axes, order 3, gradient: 256 global atomics per voxel on either kernel -- 32^4 float32: 8.0 ms here against
-    // 7.1 ms on the exact kernel, which stays in charge; orders 0-2 are faster here)
-    if (g.naxis == 4 && gradient && v.order == 3)
+    // (four axes, order 3, gradient: the LDS-accumulating kernel of round 5 for control grids of up to 6 points along x;
+    // beyond that 256 global atomics per voxel on either kernel -- 32^4 float32: 8.0 ms here against 7.1 ms on the exact
+    // kernel, which stays in charge)
+    if (g.naxis == 4 && gradient && v.order == 3 && 4 * g.ncp[3] > 24)
         return false;
     if (v.in_dtype != v.out_dtype)
         return false;

@@ -259,11 +259,32 @@ def test_four_deformed_axes_on_the_fast_kernel(dtype):
             want = orc.deform_grid(X, disp, **kw)
             got = ed.deform_grid(X, disp, **kw)
             np.testing.assert_allclose(got, want, rtol=eps, atol=eps)
-            if order in (1, 3) and mode in ("mirror", "wrap"):
+            if order in (1, 2, 3):
+                # round 5: the gradient of four deformed axes accumulates in fixed-point LDS cells (deform_fast4_grad_kernel,
+                # tiles of 2 x 2 x 4 x 16 voxels); every mode, partial tiles on every axis, a channel axis
                 dY = rng.random(want.shape).astype(dtype)
                 gw = orc.deform_grid_gradient(dY, disp, X_shape=X.shape, prefilter=False, **kw)
                 gg = ed.deform_grid_gradient(dY, disp, X_shape=X.shape, prefilter=False, **kw)
                 np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * max(1.0, np.abs(gw).max()))
+    # an affine map, a displacement that folds the volume (boxes that do not fit: direct atomics), inf / NaN gradients
+    aff = np.eye(4, 5)
+    aff[:, :4] += rng.standard_normal((4, 4)) * 0.04
+    for sigma, extra in ((2.0, dict(affine=aff)), (25.0, {})):
+        X4 = rng.random((9, 12, 10, 40)).astype(dtype)
+        disp = rng.standard_normal((4, 3, 2, 3, 4)) * sigma
+        kw = dict(order=3, mode="mirror", prefilter=False, **extra)
+        dY = rng.random(X4.shape).astype(dtype)
+        gw = orc.deform_grid_gradient(dY, disp, **kw)
+        gg = ed.deform_grid_gradient(dY, disp, **kw)
+        np.testing.assert_allclose(gg, gw, rtol=eps, atol=eps * max(1.0, np.abs(gw).max()))
+    dY = rng.random((9, 12, 10, 40)).astype(dtype)
+    dY[3, 4, 5, 6] = np.inf
+    disp = rng.standard_normal((4, 3, 2, 3, 4)) * 2.0
+    gw = orc.deform_grid_gradient(dY, disp, order=1, mode="mirror")
+    gg = ed.deform_grid_gradient(dY, disp, order=1, mode="mirror")
+    fin = np.isfinite(gw)
+    assert np.array_equal(fin, np.isfinite(gg))
+    np.testing.assert_allclose(gg[fin], gw[fin], rtol=eps, atol=eps * 10)
 
 
 @pytest.mark.parametrize("points", [(3, 4, 16), (6, 20, 31), (14, 14, 14), (2, 2, 40)])
