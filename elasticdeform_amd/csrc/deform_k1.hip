@@ -797,12 +797,22 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             double d[3];
-            if (ED_DBG(hg.dbg, 1 << 19)) {     // (ablation: no displacement -- no table reads, no fp64 sums)
-                d[0] = d[1] = d[2] = 0.25;
-            } else if (i == 0)
+            if (i == 0)
                 k1_disp<0>(smem, xe, d);
             else
                 k1_disp<ROW1>(smem, xe, d);
+            if (ED_DBG(hg.dbg, 1 << 19)) {     // (sensitivity: the displacement -- table reads + fp64 sums -- a second time)
+                XEnt x2 = xe;
+                asm volatile("" : "+v"(x2.qa[0]), "+v"(x2.qa[1]), "+v"(x2.qa[2]), "+v"(x2.qa[3]));
+                double d2[3];
+                if (i == 0)
+                    k1_disp<0>(smem, x2, d2);
+                else
+                    k1_disp<ROW1>(smem, x2, d2);
+#pragma unroll
+                for (int h = 0; h < 3; ++h)
+                    d[h] = (d[h] + d2[h]) * 0.5;
+            }
             ED_NO_DS_MERGE();          // (the backend pairs the two voxels' reads into ds_read2st64_b64: 16 LDS cycles each)
             int rz, ry, rx;
             if constexpr (GEN) {
@@ -892,8 +902,14 @@ __global__ __launch_bounds__(kBlock, 4) void k1_fwd_kernel(const HotGeom hg)
                     float val = hg.cval;
                     if (ED_DBG(hg.dbg, 1 << 17))           // (ablation: no gather)
                         val = cur.frac[i][0] + cur.frac[i][1] + cur.frac[i][2] + __int_as_float(cur.addr[i]);
-                    else if (!GEN || (cur.flg & (1 << i)))
+                    else if (!GEN || (cur.flg & (1 << i))) {
                         val = gather(cur.addr[i], cur.frac[i], pitch, plane);
+                        if (ED_DBG(hg.dbg, 1 << 23)) {     // (sensitivity: weights + gather a second time)
+                            int a2 = cur.addr[i];
+                            asm volatile("" : "+v"(a2));
+                            val = (val + gather(a2, cur.frac[i], pitch, plane)) * 0.5f;
+                        }
+                    }
                     if (ED_DBG(hg.dbg, 1 << 20) && val != -12345.678f)      // (ablation: no stores)
                         continue;
                     // streaming store (a tile writes 32-byte row segments)
