@@ -15,8 +15,8 @@ python bench.py --steps 20 --warmup 5 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 python bench.py --workload cfg4 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 python bench.py --workload cfg5 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg5.json 2> $O/bench_cfg5.err
 python bench.py --dtype bf16 > $O/bench_bf16.json 2> $O/bench_bf16.err
-EDHIP_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload cfg5 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_2ranks_gloo.json 2> $O/bench_2r.err
-EDHIP_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload cfg5 --batch 8 --steps 5 --warmup 2 --collective > $O/bench_cfg5_collective_gloo.json 2> $O/bench_coll.err
+EDHIP_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload cfg5 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline 2> $O/bench_2r.err | grep '^{' > $O/bench_cfg5_2ranks_gloo.json
+EDHIP_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload cfg5 --batch 8 --steps 5 --warmup 2 --collective 2> $O/bench_coll.err | grep '^{' > $O/bench_cfg5_collective_gloo.json
 cd /tmp && rocprofv3 --kernel-trace --stats -d $O/prof -o r05 --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress > $O/prof.log 2>&1
 cd $R; python tools/kernel_stats_csv.py $O/prof/r05_kernel_stats.csv > $O/kernel_stats.txt
 cd /tmp
