@@ -406,10 +406,18 @@ ED_UNROLL(ED_K2_U2)
                 const int rslot = tid / FL;
                 const float inv_by = 1.f / (float)by;
                 const int nr = (ED_DBG(hg.dbg, 64) || direct_tile) ? 0 : nrows;
+                // A lane walks the box rows rslot, rslot + FR, ...: (z, y) of its row and the row's offset in the
+                // volume move by the same uniform step every time, with one wrap of y.  (The offset used to be
+                // rebuilt per touched row from the row number -- a float division and three 32-bit multiplies, which
+                // issue at a quarter of the rate: ~24 issue slots per row where ~6 do.)
+                const int dz8 = (int)(((float)FR + 0.5f) * inv_by), dy8 = FR - dz8 * by;
+                const int step8 = dz8 * hg.vol_sz + dy8 * hg.vol_sy, wrapfix = hg.vol_sz - by * hg.vol_sy;
                 for (int xo = 0; xo < ext[2]; xo += FL) {
                     const int xi = xo + sub;
                     const bool xin = xi < ext[2];
                     const int xs = interior ? xi : mirror_i32(b0[2] + xi, hg.in_len[2]);
+                    int zr = (int)(((float)rslot + 0.5f) * inv_by), yr = rslot - zr * by;
+                    int rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
                     for (int r0 = rslot; r0 < nr; r0 += FU * FR) {
                         int acc[FU];
 #pragma unroll
@@ -423,15 +431,20 @@ ED_UNROLL(ED_K2_U2)
 #pragma unroll
                         for (int k = 0; k < FU; ++k) {
                             if (ED_DBG(hg.dbg, 4096) ? acc[k] == 0x7ffffff1 : acc[k] != 0) {     // (4096: timing without the atomics)
-                                const int r = r0 + k * FR;
-                                const int zr = (int)(((float)r + 0.5f) * inv_by), yr = r - zr * by;
-                                int rowoff;
-                                if (interior)
-                                    rowoff = (b0[0] + zr) * hg.vol_sz + (b0[1] + yr) * hg.vol_sy + b0[2];
-                                else
-                                    rowoff = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
-                                             mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
-                                unsafeAtomicAdd(dst + (rowoff + xs), (float)acc[k] * inv_scale);
+                                int off = rowoff;
+                                if (!interior)
+                                    off = mirror_i32(b0[0] + zr, hg.in_len[0]) * hg.vol_sz +
+                                          mirror_i32(b0[1] + yr, hg.in_len[1]) * hg.vol_sy;
+                                unsafeAtomicAdd(dst + (off + xs), (float)acc[k] * inv_scale);
+                            }
+                            // the next row of this lane
+                            yr += dy8;
+                            zr += dz8;
+                            rowoff += step8;
+                            if (yr >= by) {
+                                yr -= by;
+                                zr += 1;
+                                rowoff += wrapfix;
                             }
                         }
                     }

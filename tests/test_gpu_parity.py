@@ -535,6 +535,54 @@ def test_fast_prefilter_kernels():
                                                atol=tol * np.abs(want).max())
 
 
+def test_float64_orders_4_5_run_on_the_tile_prefilter():
+    """float64 volumes, orders 4 / 5 (round 5): the two-pole filter as a cascade of two one-pole passes on the whole-line
+    tile kernels, the large pole with a 48-sample warm-up (|z_1|^48 = 3e-18).  Against SciPy and the oracle's transpose to
+    1e-13 of the result's scale -- forward and transposed, in place, vector and scalar tiles, lines whose last block is
+    partial, lines of exactly 64 samples -- and NOT bit-equal to the exact kernel (the route check: the sequential
+    recursion rounds differently)."""
+    import importlib
+    import scipy.ndimage
+    from elasticdeform_amd import _lib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rng = np.random.default_rng(77)
+    for shape in ((128, 64, 96), (64, 65, 79), (3, 100, 66), (97, 80), (256, 256, 8)):
+        x = rng.standard_normal(shape)
+        xd = torch.from_numpy(x).to(dev)
+        for order in (4, 5):
+            for axis in range(len(shape)):
+                if shape[axis] < 64:
+                    continue
+                want = scipy.ndimage.spline_filter1d(x, order=order, axis=axis)
+                wt = np.zeros(shape)
+                orc.spline_filter1d_grad(x, wt, axis, order)
+                for transpose, w in ((0, want), (1, wt)):
+                    out = torch.empty_like(xd)
+                    _lib.spline_filter1d(dgm._desc(xd), dgm._desc(out), axis, order, transpose, _lib.FLAG_AUTO, stream)
+                    np.testing.assert_allclose(out.cpu().numpy(), w, rtol=0, atol=1e-13 * np.abs(w).max())
+                    buf = xd.clone()
+                    _lib.spline_filter1d(dgm._desc(buf), dgm._desc(buf), axis, order, transpose, _lib.FLAG_AUTO, stream)
+                    assert torch.equal(buf, out)
+                    if shape == (128, 64, 96):
+                        ex = torch.empty_like(xd)
+                        _lib.spline_filter1d(dgm._desc(xd), dgm._desc(ex), axis, order, transpose, _lib.FLAG_EXACT,
+                                             stream)
+                        assert not torch.equal(ex, out), "the exact kernel answered a default-arithmetic call"
+    # an impulse at each end of a transposed line: the folded tails reach past the first / last block of 32 outputs
+    for n in (64, 96, 100):
+        for pos in (0, 1, n - 2, n - 1, 40):
+            x = np.zeros((n, 64))
+            x[pos] = 1.0
+            wt = np.zeros_like(x)
+            orc.spline_filter1d_grad(x, wt, 0, 5)
+            xd = torch.from_numpy(x).to(dev)
+            out = torch.empty_like(xd)
+            _lib.spline_filter1d(dgm._desc(xd), dgm._desc(out), 0, 5, 1, _lib.FLAG_AUTO, stream)
+            np.testing.assert_allclose(out.cpu().numpy(), wt, rtol=0, atol=1e-14)
+
+
 def test_raw_displacement_flag_equals_explicit_prefilter():
     """EDHIP_FLAG_RAW_DISPLACEMENT (one-launch prefilter of the control grid inside edhip_deform)
     must equal the per-axis prefilter bit for bit, including the per-axis rounding to the grid's
