@@ -535,12 +535,11 @@ def test_fast_prefilter_kernels():
                                                atol=tol * np.abs(want).max())
 
 
-def test_float64_orders_4_5_run_on_the_tile_prefilter():
-    """float64 volumes, orders 4 / 5 (round 5): the two-pole filter as a cascade of two one-pole passes on the whole-line
-    tile kernels, the large pole with a 48-sample warm-up (|z_1|^48 = 3e-18).  Against SciPy and the oracle's transpose to
-    1e-13 of the result's scale -- forward and transposed, in place, vector and scalar tiles, lines whose last block is
-    partial, lines of exactly 64 samples -- and NOT bit-equal to the exact kernel (the route check: the sequential
-    recursion rounds differently)."""
+def test_float64_two_pole_prefilter_every_line_shape():
+    """float64 volumes, orders 4 / 5 in default arithmetic (served by the exact line-tile kernel: a cascade of two
+    one-pole passes on the whole-line tiles was built in round 5 and measured slower, profiles/r05_time_filter_f64.txt).
+    Against SciPy and the oracle's transpose to 1e-13 of the result's scale -- forward and transposed, in place, lines
+    whose last block is partial, lines of exactly 64 samples -- and impulses next to both ends of a transposed line."""
     import importlib
     import scipy.ndimage
     from elasticdeform_amd import _lib
@@ -564,13 +563,8 @@ def test_float64_orders_4_5_run_on_the_tile_prefilter():
                     np.testing.assert_allclose(out.cpu().numpy(), w, rtol=0, atol=1e-13 * np.abs(w).max())
                     buf = xd.clone()
                     _lib.spline_filter1d(dgm._desc(buf), dgm._desc(buf), axis, order, transpose, _lib.FLAG_AUTO, stream)
-                    assert torch.equal(buf, out)
-                    if shape == (128, 64, 96):
-                        ex = torch.empty_like(xd)
-                        _lib.spline_filter1d(dgm._desc(xd), dgm._desc(ex), axis, order, transpose, _lib.FLAG_EXACT,
-                                             stream)
-                        assert not torch.equal(ex, out), "the exact kernel answered a default-arithmetic call"
-    # an impulse at each end of a transposed line: the folded tails reach past the first / last block of 32 outputs
+                    np.testing.assert_allclose(buf.cpu().numpy(), w, rtol=0, atol=1e-13 * np.abs(w).max())
+    # an impulse next to each end of a transposed line
     for n in (64, 96, 100):
         for pos in (0, 1, n - 2, n - 1, 40):
             x = np.zeros((n, 64))
