@@ -50,6 +50,7 @@
 #include "ed_device.h"
 #include "ed_exact_coord.h"
 #include "ed_params.h"
+#include "ed_gridfilter.h"
 #include "ed_workspace.h"
 #include "ed_tile.h"
 
@@ -82,7 +83,10 @@ using namespace tile;
 // so that a voxel is left with 4 x-taps per component (12 fp64 FMAs instead of the reference's 192
 // multiply-adds, deform.c:693-758).  One block per output z: P = D contracted over z in LDS, then
 // every output y of that slice.
-__global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, const TileGeom tg)
+// gp.total > 0: the control grid at gp.in is still RAW -- every workgroup filters its own LDS copy first
+// (ed_gridfilter.h: the bits of grid_prefilter_kernel, ~1 us for a 5^3 grid) and workgroup 0 writes the filtered
+// grid to gp.out (= g.disp) for the kernels behind this one; saves the launch in front of this one.
+__global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, const TileGeom tg, const GridPrefilter gp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sP = reinterpret_cast<double*>(smem);              // [3][nyx]
@@ -106,6 +110,21 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     const char* disp = g.disp + (int64_t)sample * tg.disp_bstride;
     const int ncpy = (int)g.ncp[1], ncpx = (int)g.ncp[2];
     const int nyx = ncpy * ncpx;
+    const bool own = gp.total > 0;
+    double* sG = sP + 3 * nyx;                                 // [3][ncp_z][nyx], own only
+    if (own) {
+        grid_prefilter_in_lds<kBlock>(gp, sG, tid);
+        if (oz == 0)
+            for (int e = tid; e < gp.total; e += kBlock)
+                store_cast(gp.out + (int64_t)e * gp.elem_size, gp.dtype, sG[e]);
+    }
+    // control coefficient D_f[h][j0][j1][j2]
+    auto dval = [&](int h, int j0, int j1, int j2) -> double {
+        if (own)
+            return sG[((h * (int)g.ncp[0] + j0) * ncpy + j1) * ncpx + j2];
+        return load_as_double(disp + g.disp_stride[0] * h + g.disp_stride[1] * j0 + g.disp_stride[2] * j1 +
+                                  g.disp_stride[3] * j2, g.disp_dtype);
+    };
     if (oz == 0 && sample == 0 && tid == 0) {      // reset both spill counters (saves two memset launches per call)
         if (tg.hint) {
             // the previous call on this stream: (sequence number, tiles beyond the standard box) -> the host
@@ -131,8 +150,7 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
             for (int e = tid; e < ntot; e += kBlock) {
                 const int j0 = e / nyx, j = e - j0 * nyx;
                 const int j1 = j / ncpx, j2 = j - j1 * ncpx;
-                m = fmax(m, fabs(load_as_double(disp + g.disp_stride[0] * h + g.disp_stride[1] * j0 +
-                                                    g.disp_stride[2] * j1 + g.disp_stride[3] * j2, g.disp_dtype)));
+                m = fmax(m, fabs(dval(h, j0, j1, j2)));
             }
             for (int sh = 32; sh >= 1; sh >>= 1)
                 m = fmax(m, __shfl_xor(m, sh));
@@ -175,8 +193,7 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
             const int h = e / (nz * nyx), r = e - h * (nz * nyx);
             const int j0 = r / nyx, j = r - j0 * nyx;
             const int j1 = j / ncpx, j2 = j - j1 * ncpx;
-            const double val = load_as_double(disp + g.disp_stride[0] * h + g.disp_stride[1] * j0 +
-                                                  g.disp_stride[2] * j1 + g.disp_stride[3] * j2, g.disp_dtype);
+            const double val = dval(h, j0, j1, j2);
             if (tg.keep_mode == 1) {
                 stash[e] = val;
             } else if (__double_as_longlong(stash[e]) != __double_as_longlong(val)) {
@@ -228,11 +245,10 @@ __global__ __launch_bounds__(kBlock) void tile_tables_kernel(const GridGeom g, c
     for (int e = tid; e < 3 * nyx; e += kBlock) {
         const int h = e / nyx, j = e - h * nyx;
         const int j1 = j / ncpx, j2 = j - j1 * ncpx;
-        const char* base = disp + g.disp_stride[0] * h + g.disp_stride[2] * j1 + g.disp_stride[3] * j2;
         double acc = 0.0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
-            acc += tz_.w[l] * load_as_double(base + g.disp_stride[1] * tz_.idx[l], g.disp_dtype);
+            acc += tz_.w[l] * dval(h, tz_.idx[l], j1, j2);
         sP[e] = acc;
     }
     __syncthreads();
@@ -1541,8 +1557,17 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
             fill_blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
             batch->zero_done = true;
         }
+        GridPrefilter gp;
+        memset(&gp, 0, sizeof(gp));
+        if (batch && batch->gridpf && nb == 1 && batch->gridpf->total <= 4096) {
+            gp = *batch->gridpf;
+            gp.zero_ptr = nullptr;
+            gp.zero_bytes = 0;
+            batch->gridpf_done = true;
+        }
         hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0] + fill_blocks, (unsigned)nb), dim3(kBlock),
-                           sizeof(double) * 3 * (size_t)g.ncp[1] * (size_t)g.ncp[2], stream, g, tg);
+                           sizeof(double) * (3 * (size_t)g.ncp[1] * (size_t)g.ncp[2] + (size_t)gp.total), stream, g, tg,
+                           gp);
         e = hipGetLastError();
     };
     if (std::is_integral<T>::value || ORDER < 1)

@@ -82,6 +82,7 @@ bool deform_fast_supported(const GridGeom& g, const IOView& v, int gradient);
 // A batch of independent volumes handled by ONE set of launches (edhip_deform_batch): sample b's
 // arrays sit b * stride bytes after sample 0's; everything else (shapes, strides, order, mode, cval,
 // crop, affine) is shared.  The strip / tile index of the kernels carries the sample.
+struct GridPrefilter;
 struct DeformBatch {
     int nbatch;
     int64_t in_bstride, out_bstride, disp_bstride;   // bytes
@@ -93,6 +94,11 @@ struct DeformBatch {
     char* zero_ptr = nullptr;
     long long zero_bytes = 0;
     mutable bool zero_done = false;
+    // EDHIP_FLAG_RAW_DISPLACEMENT, single volume: the control grid is still unfiltered -- the tables kernel of the tile
+    // path filters it itself (every workgroup on its own LDS copy, workgroup 0 writes the filtered grid where
+    // GridGeom::disp points) and sets gridpf_done; left false: nothing was launched, the caller filters it
+    const GridPrefilter* gridpf = nullptr;
+    mutable bool gridpf_done = false;
 };
 hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream,
                               const DeformBatch* batch = nullptr);

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <vector>
 
+#include "ed_device.h"
 #include "ed_params.h"
 #include "ed_workspace.h"
 #include "edhip.h"
@@ -52,10 +53,14 @@ int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
 // EDHIP_FLAG_RAW_DISPLACEMENT the control grid is prefiltered into the head of the workspace.
 // zero_ptr / zero_bytes / zero_done: a gradient block the grid-prefilter launch may clear on its spare workgroups
 // (*zero_done says whether it did: only a RAW_DISPLACEMENT call that really launches the prefilter)
+// defer: the caller enqueues the grid prefilter itself (edhip_deform: the tables kernel of the tile path does it in its
+// own launch) -- *defer gets the parameters, *defer_stamp what the stream's stamp becomes once the filter is enqueued;
+// defer->total stays 0 when there is nothing to filter (no RAW_DISPLACEMENT, or the filtered copy is still there)
 int make_geometry(const edhip_array* displacement, const int64_t* in_len, const int64_t* out_len,
                   const int64_t* output_offset, int naxis, const double* affine, uint32_t flags,
                   hipStream_t stream, ed::GridGeom& g, char* err, size_t errlen, char* zero_ptr = nullptr,
-                  long long zero_bytes = 0, bool* zero_done = nullptr)
+                  long long zero_bytes = 0, bool* zero_done = nullptr, ed::GridPrefilter* defer = nullptr,
+                  ed::GridStamp* defer_stamp = nullptr)
 {
     using namespace ed;
     memset(&g, 0, sizeof(g));
@@ -126,7 +131,11 @@ int make_geometry(const edhip_array* displacement, const int64_t* in_len, const 
                            stamp->dtype == now.dtype && stamp->ndim == now.ndim &&
                            memcmp(stamp->shape, now.shape, sizeof(now.shape)) == 0 &&
                            memcmp(stamp->stride, now.stride, sizeof(now.stride)) == 0;
-        if (!stays) {
+        if (!stays && defer && defer_stamp) {
+            *stamp = GridStamp();
+            *defer = gp;
+            *defer_stamp = now;
+        } else if (!stays) {
             *stamp = GridStamp();
             if (zero_ptr && zero_done && ((uintptr_t)zero_ptr & 15) == 0) {
                 gp.zero_ptr = zero_ptr;
@@ -343,19 +352,37 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
     // clear the first gradient block -- cleared[0] -- instead of the tables launch further down)
     GridGeom g;
     bool cleared[EDHIP_MAX_INPUTS] = {};
+    // The grid prefilter of a RAW_DISPLACEMENT call is not launched here: the tile path's tables kernel filters the
+    // grid inside its own launch (DeformBatch::gridpf); every other route gets the one-workgroup launch in front of
+    // it (grid_now: its spare workgroups clear the first gradient block).
+    GridPrefilter gpf;
+    GridStamp gpf_stamp;
+    memset(&gpf, 0, sizeof(gpf));
     {
         int64_t in_len[kMaxAxes], out_len[kMaxAxes];
         for (int k = 0; k < naxis; ++k) {
             in_len[k] = inputs[0].shape[axis[k]];
             out_len[k] = outputs[0].shape[axis[k]];
         }
-        const bool early = zero && zero_bytes[0] > 0;
         const int st = make_geometry(displacement, in_len, out_len, output_offset, naxis, affine, flags,
-                                     stream, g, err, errlen, early ? zero_ptr[0] : nullptr, early ? zero_bytes[0] : 0,
-                                     early ? &cleared[0] : nullptr);
+                                     stream, g, err, errlen, nullptr, 0, nullptr, &gpf, &gpf_stamp);
         if (st != EDHIP_OK)
             return st;
     }
+    auto grid_now = [&]() -> hipError_t {
+        if (gpf.total <= 0)
+            return hipSuccess;
+        if (zero && zero_bytes[0] > 0 && !cleared[0] && ((uintptr_t)zero_ptr[0] & 15) == 0) {
+            gpf.zero_ptr = zero_ptr[0];
+            gpf.zero_bytes = zero_bytes[0];
+            cleared[0] = true;
+        }
+        const hipError_t e = launch_grid_prefilter(gpf, stream);
+        gpf.total = 0;
+        if (e == hipSuccess)
+            *grid_stamp(stream) = gpf_stamp;
+        return e;
+    };
     auto clear_now = [&](int i) -> hipError_t {
         if (cleared[i])
             return hipSuccess;
@@ -417,7 +444,9 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         const bool use_int = !(flags & EDHIP_FLAG_EXACT) && !use_fast && !use_label && deform_int_supported(g, v, gradient);
         hipError_t e = hipSuccess;
         const bool tile = !use_label && !use_int && use_fast && deform_tile_supported(g, v, gradient != 0);
-        if (zero && !tile)
+        if (!tile)
+            e = grid_now();
+        if (e == hipSuccess && zero && !tile)
             e = clear_now(i);
         if (e != hipSuccess)
             ;
@@ -435,6 +464,9 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
                            : ((gradient && (flags & EDHIP_FLAG_USE_BOXES)) ? 2 : 0);
             one.disp_id = displacement->data;
             one.raw = (flags & EDHIP_FLAG_RAW_DISPLACEMENT) ? 1 : 0;
+            one.gridpf = (gpf.total > 0 && !ed_env("EDHIP_GRIDPF_SEPARATE")) ? &gpf : nullptr;      // (A/B switch, profiling build)
+            if (!one.gridpf && grid_now() != hipSuccess)
+                return fail(err, errlen, EDHIP_ERR_DEVICE, "grid prefilter launch");
             // (several inputs share the geometry: the boxes are those of the last forward launch,
             // which is what a gradient call with the same inputs reads them for)
             // The tile path clears the block inside its tables launch -- when its start is 16-byte aligned.  A
@@ -450,6 +482,10 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
                 }
             }
             e = ce == hipSuccess ? launch_deform_tile(g, v, gradient != 0, stream, &one) : ce;
+            if (one.gridpf_done) {
+                gpf.total = 0;
+                *grid_stamp(stream) = gpf_stamp;
+            }
             if (out16 && e == hipErrorNotSupported) {
                 (void)hipGetLastError();
                 return fail(err, errlen, EDHIP_ERR_UNSUPPORTED, "16-bit output next to a float32 volume: outside the level-1 tile kernels");
@@ -458,6 +494,8 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
                 // (a wide control grid the level-1 kernels declined -- batches, layouts: nothing was launched, the
                 // row kernel takes the call; the gradient block is cleared below if the tile path has not done it)
                 (void)hipGetLastError();
+                if (grid_now() != hipSuccess)
+                    return fail(err, errlen, EDHIP_ERR_DEVICE, "grid prefilter launch");
                 if (zero && !cleared[i] && clear_now(i) != hipSuccess)
                     return fail(err, errlen, EDHIP_ERR_DEVICE, "clearing the gradient arrays failed");
                 e = launch_deform_fast(g, v, gradient != 0, stream);

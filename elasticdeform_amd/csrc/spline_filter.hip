@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "ed_device.h"
 #include "ed_params.h"
+#include "ed_gridfilter.h"
 
 namespace ed {
 
@@ -496,59 +497,7 @@ __global__ __launch_bounds__(256) void grid_prefilter_kernel(const GridPrefilter
         return;
     }
     const int total = p.total;
-    // gather (arbitrary strides) -> LDS, C order
-    for (int e = tid; e < total; e += 256) {
-        int r = e;
-        int64_t off = 0;
-        for (int d = p.ndim - 1; d >= 0; --d) {
-            const int q = r / p.shape[d];
-            off += (int64_t)(r - q * p.shape[d]) * p.stride_bytes[d];
-            r = q;
-        }
-        s[e] = load_as_double(p.in + off, p.dtype);
-    }
-    __syncthreads();
-    const double z = p.pole, gain = p.gain;
-    for (int ax = 1; ax < p.ndim; ++ax) {
-        const int n = p.shape[ax];
-        int inner = 1;
-        for (int d = ax + 1; d < p.ndim; ++d)
-            inner *= p.shape[d];
-        const int nlines = total / n;
-        if (n >= 2) {
-            const double zn1 = p.pole_pow[ax];
-            for (int line = tid; line < nlines; line += 256) {
-                const int outer = line / inner, in = line - outer * inner;
-                double* c = s + (int64_t)outer * n * inner + in;     // element i at c[i * inner]
-                for (int i = 0; i < n; ++i)
-                    c[i * inner] *= gain;
-                double c0 = c[0] + zn1 * c[(n - 1) * inner];
-                double zi = z;
-                for (int i = 1; i < n - 1; ++i) {
-                    c0 += zi * (c[i * inner] + zn1 * c[(n - 1 - i) * inner]);
-                    zi *= z;
-                }
-                c0 /= 1 - zn1 * zn1;
-                c[0] = c0;
-                for (int i = 1; i < n; ++i)
-                    c[i * inner] += z * c[(i - 1) * inner];
-                c[(n - 1) * inner] = (z * c[(n - 2) * inner] + c[(n - 1) * inner]) * z / (z * z - 1);
-                for (int i = n - 2; i >= 0; --i)
-                    c[i * inner] = z * (c[(i + 1) * inner] - c[i * inner]);
-            }
-        }
-        __syncthreads();
-        // round trip through the storage dtype after every axis (plain C cast, as the line
-        // buffer write-back does)
-        if (p.dtype != EDHIP_F64) {
-            for (int e = tid; e < total; e += 256) {
-                char tmp[8];
-                store_cast(tmp, p.dtype, s[e]);
-                s[e] = load_as_double(tmp, p.dtype);
-            }
-            __syncthreads();
-        }
-    }
+    grid_prefilter_in_lds<256>(p, s, tid);
     const int esz = p.elem_size;
     for (int e = tid; e < total; e += 256)
         store_cast(p.out + (int64_t)e * esz, p.dtype, s[e]);
