@@ -355,52 +355,6 @@ __device__ __forceinline__ float k1_gather(const float* bp, int plane, const flo
 {
     constexpr int NT = ORDER + 1;
     constexpr int NTX = NT + (NT & 1);
-    if constexpr (SPLIT >= 2) {
-        // Two box rows of taps at a time, their reads issued in REVERSE order of use: LDS reads return in order, so
-        // the first use -- of the read issued last -- waits for the whole group with one s_waitcnt and the others
-        // need none (issued in order of use, every read gets an s_waitcnt of its own in front of its
-        // multiply-adds: 32 per voxel, and every instruction costs the wave an issue slot).  The next group's
-        // reads are in flight while a group is accumulated.  (A whole plane per group: 26 spilled registers.)
-        constexpr int GR = (SPLIT == 3 || NT % 2) ? NT : 2;      // rows per group (a plane: order 2; SPLIT 3, profiling build)
-        constexpr int NG = NT * NT / GR;               // groups per voxel
-        static_assert(NT % GR == 0, "groups do not straddle planes");
-        float2 t[2][GR][NTX / 2];
-        auto rd = [&](int g) {
-            const int row0 = g * GR;
-            const float* pp = bp + (row0 / NT) * plane + (row0 % NT) * PITCH;
-#pragma unroll
-            for (int r = GR - 1; r >= 0; --r) {
-#pragma unroll
-                for (int p = NTX / 2 - 1; p >= 0; --p) {
-                    t[g & 1][r][p] = *reinterpret_cast<const float2*>(pp + r * PITCH + 2 * p);
-                    ED_NO_DS_MERGE();
-                }
-            }
-        };
-        rd(0);
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG)
-                rd(g + 1);
-#pragma unroll
-            for (int r = 0; r < GR; ++r) {
-                const int l1 = (g * GR + r) % NT;
-                float a2 = 0.f;
-#pragma unroll
-                for (int p = 0; p < NTX / 2; ++p) {
-                    a2 = fmaf(w2[2 * p], t[g & 1][r][p].x, a2);
-                    a2 = fmaf(w2[2 * p + 1], t[g & 1][r][p].y, a2);
-                }
-                a1 = fmaf(w1[l1], a2, a1);
-                if (l1 == NT - 1) {
-                    a0 = fmaf(w0[(g * GR + r) / NT], a1, a0);
-                    a1 = 0.f;
-                }
-            }
-        }
-        return a0;
-    } else {
     float a0 = 0.f;
 #pragma unroll
     for (int l0 = 0; l0 < NT; ++l0) {
@@ -423,7 +377,6 @@ __device__ __forceinline__ float k1_gather(const float* bp, int plane, const flo
         a0 = fmaf(w0[l0], a1, a0);
     }
     return a0;
-    }
 }
 
 // Voxels the tile loop did not (or may not have) served, straight from global memory, behind the loop: every
@@ -951,17 +904,14 @@ template <int ORDER>
 hipError_t launch_k1_order(const HotGeom& hg, unsigned nblk, size_t lds, hipStream_t stream)
 {
     // reads of the gather: 1 = in order of use, kept apart (shipped); the profiling build also has 0 = as the backend
-    // fuses them (ds_read2_b64: +25 %), 2 / 3 = two rows / a plane at a time in reverse order of use (one s_waitcnt
-    // per group instead of one per read, but a group's first multiply-add waits for its last read: +16 %)
+    // fuses them (ds_read2_b64: +25 %).  (Two rows / a plane at a time in reverse order of use -- one s_waitcnt per
+    // group instead of one per read, but a group's first multiply-add waits for its last read -- measured +16 %,
+    // profiles/r05_ablate_k1.txt; that variant lived until commit 7c13be2.)
     [[maybe_unused]] const int split = ed_env("EDHIP_K1_SPLIT") ? atoi(ed_env("EDHIP_K1_SPLIT")) : 1;
 #ifdef EDHIP_EXPERIMENTS
 #define ED_K1_GO(A, O16)                                                                                              \
     do {                                                                                                              \
-        if (split == 2)                                                                                               \
-            hipLaunchKernelGGL((k1_fwd_kernel<ORDER, A, O16, 2>), dim3(nblk), dim3(kBlock), lds, stream, hg);         \
-        else if (split == 3 && ORDER != 2)                                                                            \
-            hipLaunchKernelGGL((k1_fwd_kernel<ORDER, A, O16, (ORDER == 2 ? 2 : 3)>), dim3(nblk), dim3(kBlock), lds, stream, hg); \
-        else if (split == 1)                                                                                          \
+        if (split != 0)                                                                                               \
             hipLaunchKernelGGL((k1_fwd_kernel<ORDER, A, O16, 1>), dim3(nblk), dim3(kBlock), lds, stream, hg);         \
         else                                                                                                          \
             hipLaunchKernelGGL((k1_fwd_kernel<ORDER, A, O16, 0>), dim3(nblk), dim3(kBlock), lds, stream, hg);         \

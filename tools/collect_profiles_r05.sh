@@ -53,7 +53,6 @@ TAG="displacement twice (1<<19)             " EDHIP_TILE_DBG=524288 ITERS=30 T 2
 TAG="weights + gather twice (1<<23)         " EDHIP_TILE_DBG=8388608 ITERS=30 T 256 3 5
 TAG="every tile on general coordinates (1<<16)" EDHIP_TILE_DBG=65536 ITERS=30 T 256 3 5
 TAG="gather reads merged by the backend (split 0)" EDHIP_K1_SPLIT=0 ITERS=30 T 256 3 5
-TAG="gather reads two rows at a time, reverse order (split 2)" EDHIP_K1_SPLIT=2 ITERS=30 T 256 3 5
 TAG="3 workgroups per CU (52 KB)            " EDHIP_HOT_FWD_KB=52 ITERS=30 T 256 3 5
 TAG="2 workgroups per CU (64 KB)            " EDHIP_HOT_FWD_KB=64 ITERS=30 T 256 3 5
 TAG="strips of 2 tiles                      " EDHIP_STRIP=2 ITERS=30 T 256 3 5
@@ -67,6 +66,16 @@ TAG="pitch 32 (1<<22)                                " EDHIP_TILE_DBG=4194304 IT
 TAG="16 consecutive x + pitch 32                     " EDHIP_TILE_DBG=6291456 ITERS=30 T 256 3 5
 TAG="shipped, no flush (64)                          " EDHIP_TILE_DBG=64 ITERS=30 T 256 3 5
 TAG="shipped, no scatter (128)                       " EDHIP_TILE_DBG=128 ITERS=30 T 256 3 5
+} > $O/k2_lane_maps.txt 2>&1
+{
+echo "# raw control grid filtered inside the tables launch (shipped) against a launch of its own in front of it (EDHIP_GRIDPF_SEPARATE=1), profiling build, one box"
+for rep in 1 2; do
+TAG="grid filter inside the tables launch" ITERS=30 T 256 3 5; TAG="grid filter inside the tables launch" ITERS=30 T 64 3 5
+TAG="grid filter as a launch of its own  " EDHIP_GRIDPF_SEPARATE=1 ITERS=30 T 256 3 5; TAG="grid filter as a launch of its own  " EDHIP_GRIDPF_SEPARATE=1 ITERS=30 T 64 3 5
+done
+} > $O/gridpf_ab.txt 2>&1
+{
+true
 } > $O/k2_lane_maps.txt 2>&1
 cp tools/libedhip_stats.so elasticdeform_amd/libedhip.so
 {
