@@ -1125,10 +1125,25 @@ inline int wide_window(const GridGeom& g)
 // x table + the per-sample margins of K1's sampled boxes (TileGeom::slack) behind it
 inline size_t xt_only_bytes(const GridGeom& g) { return (sizeof(AxTab) * (size_t)g.out_len[2] + 63) & ~(size_t)63; }
 inline size_t xt_block_bytes(const GridGeom& g, int nbatch) { return xt_only_bytes(g) + (((size_t)nbatch * 32 + 63) & ~(size_t)63); }
-inline size_t q_global_bytes(const GridGeom& g)
+// float64 volumes (round 5): the per-strip layout also where the whole grid would still fit next to a box -- with 9 to 14
+// control columns the Q rows take 18-29 KB of LDS, the level-2 kernel is left with half a box of 8-byte cells and a
+// rough deformation sends most tiles to the direct kernel (256^3, 13^3 grid, order 3 gradient: 8.0 ms, of which 6.8 in
+// float64 global atomics; per-strip tables of 7 columns: see profiles/r05_bench_misc.txt).  Worth it when the window is
+// narrower than the grid.
+inline bool wide_optional(const GridGeom& g)
+{
+    if (wide_grid(g))
+        return false;
+    const int win = wide_window(g);
+    const int64_t strips = (g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT);
+    if (win + 2 > g.ncp[2] || win > kWideMaxWin || strips > 256)
+        return false;
+    return 8.0 * (double)g.out_len[0] * (double)g.out_len[1] * 4.0 * (double)(strips * win) <= (double)((size_t)512 << 20);
+}
+inline size_t q_global_bytes(const GridGeom& g, bool wide_opt = false)
 {
     size_t cols = (size_t)g.ncp[2];
-    if (wide_grid(g)) {
+    if (wide_grid(g) || (wide_opt && wide_optional(g))) {
         // Q[o_z][o_y][strip][window][4] (TileGeom::q_win)
         const size_t strips = (size_t)((g.out_len[2] + kWideStripTiles * kT - 1) / (kWideStripTiles * kT));
         const size_t per_strip = strips * (size_t)wide_window(g);
@@ -1347,7 +1362,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // Wide control grid: the level-1 kernels of deform_hot.hip on per-strip Q tables, in self-serve form, or nothing
     // (hipErrorNotSupported before anything is launched: the row kernel of deform_fast.hip then takes the call --
     // at 24.7 ms for the gradient of a 256^3 volume with a 16^3 grid, where this route takes 0.x ms)
-    const bool wide = wide_grid(g);
+    const bool wide_opt = sizeof(T) == 8 && std::is_floating_point<T>::value && ORDER >= 1 && nb == 1 &&
+                          !ed_env("EDHIP_RECORDS") && !ed_env("EDHIP_NO_WIDE64") && wide_optional(g);
+    const bool wide = wide_grid(g) || wide_opt;
     tg.q_win = tg.q_strip_vox = 0;
     tg.q_strips = 1;
     // (orders 4 / 5: the one-wave kernels of deform_wave.hip read their Q columns from global memory as they walk --
@@ -1407,7 +1424,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         return hipErrorInvalidValue;
     tg.nstrips = (int)nstrips;
     tg.ntiles = (int)ntiles;
-    tg.q_bstride = (long long)(q_global_bytes(g) / 8);
+    tg.q_bstride = (long long)(q_global_bytes(g, wide_opt) / 8);
     // (wide grids: the kernels see a grid of q_win columns, the strip's window)
     const size_t qcols = tg.q_win ? (size_t)tg.q_win : (size_t)g.ncp[2];
     tg.ncpx = (int)qcols;
@@ -1456,7 +1473,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // scratch: first-level spill list | second-level spill list | x table | Q
     const size_t list_bytes = (sizeof(int) * ((size_t)ntiles * nb + 1) + 63) & ~(size_t)63;
     const size_t xt_bytes = xt_block_bytes(g, nb);
-    const size_t q_all = ((q_global_bytes(g) * (size_t)nb) + 63) & ~(size_t)63;
+    const size_t q_all = ((q_global_bytes(g, wide_opt) * (size_t)nb) + 63) & ~(size_t)63;
     hipError_t e = hipSuccess;
     // (edhip_deform reserved deform_tile_workspace_bytes() up front, so this does not move the
     // prefiltered control grid that may sit in the head of the workspace)
@@ -2052,7 +2069,7 @@ double tile_profile_last_us()
     return (double)ms * 1e3;
 }
 
-size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch)
+size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch, bool f64)
 {
     if (g.naxis != 3)
         return kWorkspaceGridBytes;
@@ -2061,7 +2078,7 @@ size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch)
         ntiles *= (g.out_len[k] + kT - 1) / kT;
     const size_t list_bytes = (sizeof(int) * ((size_t)ntiles * nbatch + 1) + 63) & ~(size_t)63;
     const size_t xt_bytes = xt_block_bytes(g, nbatch);
-    const size_t q = q_global_bytes(g);
+    const size_t q = q_global_bytes(g, f64 && nbatch == 1);       // (float64 volumes may take the per-strip layout)
     if (q > ((size_t)512 << 20))
         return kWorkspaceGridBytes;
     return kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + ((q * (size_t)nbatch + 63) & ~(size_t)63) +

@@ -103,7 +103,7 @@ struct DeformBatch {
 hipError_t launch_deform_tile(const GridGeom& g, const IOView& v, int gradient, hipStream_t stream,
                               const DeformBatch* batch = nullptr);
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient);
-size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch = 1);   // scratch the tile path will ask for
+size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch = 1, bool f64 = false);   // scratch the tile path will ask for (f64: a float64 volume is among the inputs)
 
 // order-0 resampling of label maps (any dtype, 3 deformed axes, forward): bit-equal to the exact
 // kernel (fast coordinates, exact re-evaluation of near-tie voxels), see deform_tile.hip

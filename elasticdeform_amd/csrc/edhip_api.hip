@@ -60,7 +60,7 @@ int make_geometry(const edhip_array* displacement, const int64_t* in_len, const 
                   const int64_t* output_offset, int naxis, const double* affine, uint32_t flags,
                   hipStream_t stream, ed::GridGeom& g, char* err, size_t errlen, char* zero_ptr = nullptr,
                   long long zero_bytes = 0, bool* zero_done = nullptr, ed::GridPrefilter* defer = nullptr,
-                  ed::GridStamp* defer_stamp = nullptr)
+                  ed::GridStamp* defer_stamp = nullptr, bool f64_volumes = false)
 {
     using namespace ed;
     memset(&g, 0, sizeof(g));
@@ -93,7 +93,7 @@ int make_geometry(const edhip_array* displacement, const int64_t* in_len, const 
         // reserve everything this call can need now: a later, larger request would move the buffer
         // and lose the grid
         hipError_t e = hipSuccess;
-        void* ws = workspace_reserve(stream, deform_tile_workspace_bytes(g), &e);
+        void* ws = workspace_reserve(stream, deform_tile_workspace_bytes(g, 1, f64_volumes), &e);
         if (!ws)
             return hip_fail(err, errlen, e, "scratch allocation");
         GridPrefilter gp;
@@ -364,8 +364,11 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
             in_len[k] = inputs[0].shape[axis[k]];
             out_len[k] = outputs[0].shape[axis[k]];
         }
+        bool f64_volumes = false;
+        for (int i = 0; i < ninputs; ++i)
+            f64_volumes = f64_volumes || inputs[i].dtype == EDHIP_F64;
         const int st = make_geometry(displacement, in_len, out_len, output_offset, naxis, affine, flags,
-                                     stream, g, err, errlen, nullptr, 0, nullptr, &gpf, &gpf_stamp);
+                                     stream, g, err, errlen, nullptr, 0, nullptr, &gpf, &gpf_stamp, f64_volumes);
         if (st != EDHIP_OK)
             return st;
     }

@@ -287,7 +287,7 @@ def test_four_deformed_axes_on_the_fast_kernel(dtype):
     np.testing.assert_allclose(gg[fin], gw[fin], rtol=eps, atol=eps * 10)
 
 
-@pytest.mark.parametrize("points", [(3, 4, 16), (6, 20, 31), (14, 14, 14), (2, 2, 40)])
+@pytest.mark.parametrize("points", [(3, 4, 16), (6, 20, 31), (14, 14, 14), (2, 2, 40), (5, 9, 11)])
 def test_wide_control_grids_run_on_the_tile_kernels(points):
     """Control grids with more columns than a strip's Q rows can hold in LDS (more than 13 along x) used to fall to the
     row kernel (a 256^3 gradient with a 16^3 grid: 24.7 ms).  float32 volumes of orders 1-3 now run on the level-1

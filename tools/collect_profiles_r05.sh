@@ -67,16 +67,6 @@ TAG="16 consecutive x + pitch 32                     " EDHIP_TILE_DBG=6291456 IT
 TAG="shipped, no flush (64)                          " EDHIP_TILE_DBG=64 ITERS=30 T 256 3 5
 TAG="shipped, no scatter (128)                       " EDHIP_TILE_DBG=128 ITERS=30 T 256 3 5
 } > $O/k2_lane_maps.txt 2>&1
-{
-echo "# raw control grid filtered inside the tables launch (shipped) against a launch of its own in front of it (EDHIP_GRIDPF_SEPARATE=1), profiling build, one box"
-for rep in 1 2; do
-TAG="grid filter inside the tables launch" ITERS=30 T 256 3 5; TAG="grid filter inside the tables launch" ITERS=30 T 64 3 5
-TAG="grid filter as a launch of its own  " EDHIP_GRIDPF_SEPARATE=1 ITERS=30 T 256 3 5; TAG="grid filter as a launch of its own  " EDHIP_GRIDPF_SEPARATE=1 ITERS=30 T 64 3 5
-done
-} > $O/gridpf_ab.txt 2>&1
-{
-true
-} > $O/k2_lane_maps.txt 2>&1
 cp tools/libedhip_stats.so elasticdeform_amd/libedhip.so
 {
 echo "# K1 tile classes and redone windows (counters build, tools/k1_stats.py: side order sigma [control points] [mode])"
