@@ -1252,57 +1252,6 @@ __global__ __launch_bounds__(kBlock) void deform_tile3_label_kernel(const GridGe
     }
 }
 
-// the near-tie voxels of the label kernel, in the reference's evaluation order (deform.c:650-758,
-// 771-813; ed_exact_coord.h).  If the list overflowed (adversarial inputs: every coordinate a
-// half-integer) every voxel is redone this way -- correct, at the exact kernel's speed.
-template <typename W>
-__global__ __launch_bounds__(kBlock) void deform_tile3_label_tie_kernel(const GridGeom g, const IOView v,
-                                                                        const TileGeom tg)
-{
-    const W* inp = reinterpret_cast<const W*>(v.in);
-    W* outp = reinterpret_cast<W*>(v.out);
-    const int count = tg.label_list[0];
-    const bool all = count > tg.label_cap;
-    const int64_t n = all ? (int64_t)tg.out_len[0] * tg.out_len[1] * tg.out_len[2] : count;
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
-        int id = all ? (int)e : tg.label_list[1 + e];
-        int64_t o64[3];
-        o64[2] = id % tg.out_len[2];
-        id /= tg.out_len[2];
-        o64[1] = id % tg.out_len[1];
-        o64[0] = id / tg.out_len[1];
-        double displ[3];
-        eval_displacement<3>(g, o64, displ);
-        int src_idx = 0;
-        bool cst = false;
-#pragma unroll
-        for (int h = 0; h < 3; ++h) {
-            const double c = map_coordinate(raw_coordinate<3>(g, o64, h, displ[h]), g.in_len[h], tg.mode);
-            if (!cst && c > -1.0) {
-                const int64_t st = window_start(c, 0);
-                const bool edge = st < 0 || st >= g.in_len[h];
-                src_idx += (int)(edge ? mirror_index(st, g.in_len[h]) : st) * tg.in_stride[h];
-            } else {
-                cst = true;
-            }
-        }
-        const int obase = (int)o64[0] * tg.out_stride[0] + (int)o64[1] * tg.out_stride[1] +
-                          (int)o64[2] * tg.out_stride[2];
-        for (int64_t ss = 0; ss < v.nsteps; ++ss) {
-            int64_t in_off, out_off;
-            step_offsets(v, ss, in_off, out_off);
-            if (cst)
-                store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype, v.cval);
-            else if (sizeof(W) == 8)
-                store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype,
-                              load_as_double(reinterpret_cast<const char*>(inp + (in_off + src_idx)),
-                                             v.in_dtype));
-            else
-                outp[out_off + obase] = inp[in_off + src_idx];
-        }
-    }
-}
-
 // edhip_profile_*: HIP events around the level-1 launch only (the dominant kernel of a call),
 // recorded on the stream the kernel is launched on.  Off unless bench.py asks for it.
 std::atomic<int> g_profile{0};
@@ -1649,8 +1598,13 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         if (e == hipSuccess) {
             const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
             hipLaunchKernelGGL(deform_tile3_label_kernel<T>, dim3(nblk), dim3(kBlock), 0, stream, g, ve, tg);
-            hipLaunchKernelGGL(deform_tile3_label_tie_kernel<T>, dim3(1024), dim3(kBlock), 0, stream, g, ve, tg);
             e = hipGetLastError();
+            // the near-tie voxels, in the reference's evaluation order: the exact kernel's list form (control grid in
+            // LDS; it leaves at once when the list is empty).  A kernel of this file used to do it with the grid in
+            // global memory: its handful of voxels sat in ONE wave that walked 192 dependent loads -- 50 us behind a
+            // 29 us label kernel (128^3 uint8).
+            if (e == hipSuccess)
+                e = launch_deform_exact_list(g, v, tg.label_list, tg.label_cap, stream);
         }
         return e;
     } else {
@@ -2179,20 +2133,20 @@ bool deform_int_supported(const GridGeom& g, const IOView& v, int gradient)
     return true;
 }
 
-hipError_t launch_deform_int(const GridGeom& g, const IOView& v, hipStream_t stream)
+// (batch: nullptr, or a single-volume DeformBatch that carries the raw control grid for the tables kernel to filter)
+hipError_t launch_deform_int(const GridGeom& g, const IOView& v, hipStream_t stream, const DeformBatch* batch)
 {
     if (!deform_int_supported(g, v, 0))
         return hipErrorNotSupported;
     switch (label_elem_size(v.in_dtype)) {
-    case 1: return launch_tile<uint8_t, 0, false, false>(g, v, stream, nullptr);
-    case 2: return launch_tile<uint16_t, 0, false, false>(g, v, stream, nullptr);
-    default: return launch_tile<uint32_t, 0, false, false>(g, v, stream, nullptr);
+    case 1: return launch_tile<uint8_t, 0, false, false>(g, v, stream, batch);
+    case 2: return launch_tile<uint16_t, 0, false, false>(g, v, stream, batch);
+    default: return launch_tile<uint32_t, 0, false, false>(g, v, stream, batch);
     }
 }
 
-hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream)
+hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream, const DeformBatch* batch)
 {
-    const DeformBatch* batch = nullptr;
     if (!deform_label_supported(g, v, 0))
         return hipErrorNotSupported;
     switch (label_elem_size(v.in_dtype)) {

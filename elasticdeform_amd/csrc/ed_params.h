@@ -107,11 +107,11 @@ size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch = 1, bool f64 =
 
 // order-0 resampling of label maps (any dtype, 3 deformed axes, forward): bit-equal to the exact
 // kernel (fast coordinates, exact re-evaluation of near-tie voxels), see deform_tile.hip
-hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream);
+hipError_t launch_deform_label(const GridGeom& g, const IOView& v, hipStream_t stream, const DeformBatch* batch = nullptr);
 bool deform_label_supported(const GridGeom& g, const IOView& v, int gradient);
 // 8- / 16-bit integer volumes with spline orders 1-5 (forward): bit-equal to the exact kernel (fast
 // coordinates and fp64 taps; voxels near a rounding tie or a coordinate boundary re-evaluated exactly)
-hipError_t launch_deform_int(const GridGeom& g, const IOView& v, hipStream_t stream);
+hipError_t launch_deform_int(const GridGeom& g, const IOView& v, hipStream_t stream, const DeformBatch* batch = nullptr);
 bool deform_int_supported(const GridGeom& g, const IOView& v, int gradient);
 void tile_profile_enable(int enable);                    // edhip_profile_dominant
 double tile_profile_last_us();                           // edhip_profile_last_us

@@ -447,16 +447,26 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         const bool use_int = !(flags & EDHIP_FLAG_EXACT) && !use_fast && !use_label && deform_int_supported(g, v, gradient);
         hipError_t e = hipSuccess;
         const bool tile = !use_label && !use_int && use_fast && deform_tile_supported(g, v, gradient != 0);
-        if (!tile)
+        // (label maps and the integer fast path run the tables kernel of the tile path as well: it filters a raw grid)
+        DeformBatch lone;
+        lone.nbatch = 1;
+        lone.in_bstride = lone.out_bstride = lone.disp_bstride = 0;
+        lone.gridpf = (gpf.total > 0 && (use_label || use_int) && !ed_env("EDHIP_GRIDPF_SEPARATE")) ? &gpf : nullptr;
+        if (!tile && !lone.gridpf)
             e = grid_now();
         if (e == hipSuccess && zero && !tile)
             e = clear_now(i);
         if (e != hipSuccess)
             ;
-        else if (use_label)
-            e = launch_deform_label(g, v, stream);
-        else if (use_int)
-            e = launch_deform_int(g, v, stream);
+        else if (use_label || use_int) {
+            e = use_label ? launch_deform_label(g, v, stream, &lone) : launch_deform_int(g, v, stream, &lone);
+            if (lone.gridpf_done) {
+                gpf.total = 0;
+                *grid_stamp(stream) = gpf_stamp;
+            } else if (lone.gridpf && e == hipSuccess) {
+                e = hipErrorUnknown;       // (cannot happen: every route of the label / integer paths starts with the tables launch)
+            }
+        }
         else if (!use_fast)
             e = launch_deform_exact(g, v, gradient != 0, stream);
         else if (tile) {
