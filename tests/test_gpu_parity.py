@@ -598,6 +598,43 @@ def test_raw_displacement_flag_equals_explicit_prefilter():
                                **F32_TOL)
 
 
+def test_raw_grid_filtered_inside_the_tables_launch_gives_the_same_bits():
+    """Round 5: on the tile path a RAW control grid is filtered by the tables kernel itself (every workgroup on its own
+    LDS copy, ed_gridfilter.h) instead of by a launch in front of it.  The forward result must equal, bit for bit, the
+    same call on a grid that was prefiltered axis by axis with the exact kernels (no RAW flag) -- float64 and float32
+    grids (the latter rounds to float32 after every axis), 3 to 9 control points per axis, a label map in the same
+    geometry, and a second call with EDHIP_FLAG_GRID_STAYS that must find the filtered grid in the workspace."""
+    import importlib
+    from elasticdeform_amd import _lib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rng = np.random.default_rng(515)
+    shape = (40, 48, 72)
+    X = torch.from_numpy(rng.random(shape, dtype=np.float32)).to(dev)
+    Lb = torch.from_numpy((rng.random(shape) * 200).astype(np.uint8)).to(dev)
+    for ddt in (np.float64, np.float32):
+        for pts in ((3, 3, 3), (5, 5, 5), (4, 9, 6)):
+            disp = torch.from_numpy((rng.standard_normal((3,) + pts) * 2.5).astype(ddt)).to(dev)
+            ed.set_arithmetic("exact")
+            try:
+                df = disp
+                for ax in (1, 2, 3):        # one axis at a time, each result stored in the grid's dtype (deform_grid.py:166-169)
+                    df = dgm._filter_axes(df, [ax], 3, False, dev)
+            finally:
+                ed.set_arithmetic("auto")
+            for vol, order in ((X, 3), (X, 1), (Lb, 0)):
+                outs = []
+                for grid, flag in ((df, 0), (disp, _lib.FLAG_RAW_DISPLACEMENT),
+                                   (disp, _lib.FLAG_RAW_DISPLACEMENT | _lib.FLAG_GRID_STAYS)):
+                    out = torch.empty_like(vol)
+                    _lib.deform(0, [dgm._desc(vol)], dgm._desc(grid), None, [dgm._desc(out)], [(0, 1, 2)], [order], [3],
+                                [0.0], None, _lib.FLAG_AUTO | flag, stream)
+                    outs.append(out)
+                assert torch.equal(outs[0], outs[1]), (ddt, pts, order)
+                assert torch.equal(outs[0], outs[2]), (ddt, pts, order, "GRID_STAYS")
+
+
 # ---- crop-aware prefilter (SURVEY.md 8(f) rank 1) ------------------------------------------------
 
 @pytest.mark.parametrize("mode", ["constant", "nearest", "mirror", "wrap"])
