@@ -4,7 +4,7 @@
 * device-side crop window (edhip_source_window + windowed filter passes), forced to engage whatever the volume's size:
   float32 / float64 volumes with lines of 64..200 samples, random crops, all five modes, affine maps, a channel axis,
   several inputs per call -- forward against the oracle, gradient against the exact gradient (fp64 oracle);
-* wide control grids (14..47 columns along x) on the per-strip Q tables, any shape / crop / affine map, orders 1-5;
+* wide control grids (14..47 columns along x; float64 volumes from 8) on the per-strip Q tables, any shape / crop / affine map, orders 1-5;
 * 16-bit float volumes that stay in 16 bits (set_reduced_precision): forward bit-equal to the float32 pipeline narrowed
   by a cast, gradient within half a 16-bit ulp of it -- and equal with the direct route switched off."""
 import importlib
@@ -87,7 +87,9 @@ for case in range(ncases):
         elif kind == "wide":
             # control grids too wide for a strip's Q rows in LDS: per-strip tables (TileGeom::q_win), or the row kernel
             shape = tuple(int(rng.integers(20, 120)) for _ in range(3))
-            pts = (int(rng.integers(2, 20)), int(rng.integers(2, 20)), int(rng.integers(14, 48)))
+            # (float64 volumes take the per-strip tables from 8-9 columns on: wide_optional() of deform_tile.hip)
+            f64 = rng.integers(0, 3) == 0
+            pts = (int(rng.integers(2, 20)), int(rng.integers(2, 20)), int(rng.integers(8 if f64 else 14, 48)))
             order = int(rng.integers(1, 6))      # 1-3: per-strip tables; 4 / 5: the one-wave kernels on plain tables
             kw["order"] = order
             if rng.integers(0, 3) == 0:
@@ -99,10 +101,23 @@ for case in range(ncases):
             if rng.integers(0, 3) == 0:
                 kw["affine"] = np.eye(3, 4) + rng.standard_normal((3, 4)) * 0.05
             kw["prefilter"] = bool(rng.integers(0, 2))
-            desc = "case %d wide shape=%s pts=%s o%d %s sigma=%g %s" % (
-                case, shape, pts, order, mode, sigma, {k: v for k, v in kw.items() if k in ("crop", "prefilter")})
+            desc = "case %d wide%s shape=%s pts=%s o%d %s sigma=%g %s" % (
+                case, " float64" if f64 else "", shape, pts, order, mode, sigma,
+                {k: v for k, v in kw.items() if k in ("crop", "prefilter")})
             disp = rng.standard_normal((3,) + pts) * min(sigma, 3.0)
             dd = torch.from_numpy(disp).to(dev)
+            if f64:
+                X = rng.random(shape)
+                want = orc.deform_grid(X, disp, **kw)
+                got = ed.deform_grid(torch.from_numpy(X).to(dev), dd, **kw).cpu().numpy()
+                err = float(np.abs(got - want).max()) if want.size else 0.0
+                assert err <= 1e-10, "float64 forward max abs err %.3e" % err
+                dY = rng.random(want.shape)
+                gg = ed.deform_grid_gradient(torch.from_numpy(dY).to(dev), dd, X_shape=shape, **kw).cpu().numpy()
+                truth = orc.deform_grid_gradient(dY, disp, X_shape=shape, **kw)
+                gs = max(1.0, float(np.abs(truth).max()))
+                assert float(np.abs(gg - truth).max()) <= 1e-10 * gs, "float64 gradient"
+                continue
             X = rng.random(shape).astype(np.float32)
             want = orc.deform_grid(X, disp, **kw)
             got = ed.deform_grid(torch.from_numpy(X).to(dev), dd, **kw).cpu().numpy()
