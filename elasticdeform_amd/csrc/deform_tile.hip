@@ -2109,6 +2109,11 @@ bool deform_label_supported(const GridGeom& g, const IOView& v, int gradient)
         return false;
     if (q_global_bytes(g) > ((size_t)512 << 20) || 24 * (size_t)g.ncp[1] * (size_t)g.ncp[2] > 48 * 1024)
         return false;
+    // wide control grids (per-strip Q tables) are a float route: label maps and the integer fast path stay on whole-grid
+    // tables, beyond them the exact kernels take the volume.  (This test was missing: launch_tile declined such a call
+    // AFTER the route had been chosen and edhip_deform failed with "operation not supported" -- found by fuzz_api.py.)
+    if (wide_grid(g))
+        return false;
     return true;
 }
 

@@ -364,6 +364,28 @@ def test_wide_control_grids_run_on_the_tile_kernels(points):
     np.testing.assert_allclose(ed.deform_grid(Xcl, disp, **kw), orc.deform_grid(Xcl, disp, **kw), **F32_TOL)
 
 
+def test_integer_volumes_and_label_maps_with_wide_control_grids():
+    """Integer volumes and label maps keep to whole-grid tables: with more control columns than those hold (15 and up
+    along x) the exact kernels take them -- bit-equal to the reference, in the same call as a float channel that runs on
+    the per-strip tables.  (Until round 5 such a call FAILED: the label / integer route was chosen and its launcher then
+    declined the wide grid; found by tests/fuzz/fuzz_api.py.)"""
+    rng = np.random.default_rng(9706)
+    shape = (41, 23, 90)
+    for pts in ((16, 21, 17), (3, 4, 15), (5, 5, 40)):
+        disp = rng.standard_normal((3,) + pts) * 1.5
+        for dtype in (np.int16, np.uint8, np.int32):
+            X = (rng.random(shape) * 50).astype(dtype)
+            for order in (0, 1, 2, 3):
+                kw = dict(order=order, mode="mirror")
+                np.testing.assert_array_equal(ed.deform_grid(X, disp, **kw), orc.deform_grid(X, disp, **kw))
+        img = rng.random(shape).astype(np.float32)
+        lab = (rng.random(shape) * 5).astype(np.uint8)
+        got = ed.deform_grid([img, lab], disp, order=[3, 0], mode="nearest")
+        want = orc.deform_grid([img, lab], disp, order=[3, 0], mode="nearest")
+        np.testing.assert_allclose(got[0], want[0], **F32_TOL)
+        np.testing.assert_array_equal(got[1], want[1])
+
+
 def test_integer_gradient_is_bit_exact():
     """*(T*)p += (T)t accumulates in the array dtype (deform.c:309-312): integer atomics are
     associative, so even the scatter-add is bit-reproducible for integer gradients."""

@@ -13,6 +13,7 @@ timeout 600 python tools/time_matrix.py 2>&1 | grep -v amdgpu.ids > $O/time_matr
 timeout 300 python tools/time_big_grid.py 2>&1 | grep -v amdgpu.ids > $O/big_grid.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 timeout 1800 python -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1; tail -3 $O/tests.txt
+{ timeout 400 python tests/fuzz/fuzz_api.py 9706 300; timeout 400 python tests/fuzz/fuzz_api.py 9806 300; timeout 400 python tests/fuzz/fuzz_int.py 9807 200; } 2>&1 | grep -v amdgpu.ids | grep -A2 "cases\|FAIL" > $O/fuzz_api.txt; cat $O/fuzz_api.txt
 python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r05final/bench.json').read())
