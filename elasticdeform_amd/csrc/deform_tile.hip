@@ -1163,41 +1163,16 @@ inline size_t q_global_bytes(const GridGeom& g, bool wide_opt = false)
 // ~1e-11 of that, so every other voxel decides identically: the output is bit-equal to the exact
 // kernel's at ~20x its speed (a few voxels per million take the slow path).
 // ================================================================================================
-// INLINE: the near-tie voxels are redone by the kernel itself, in the reference's evaluation order (deform.c:650-758,
-// 771-813; ed_exact_coord.h) -- the first tile of a workgroup that has one stages the control grid in LDS (<= 4096
-// coefficients) and the affected lanes evaluate their voxel again; adversarial inputs (every coordinate a half-integer)
-// run at the exact kernel's speed.  Otherwise (larger grids) they are appended to a list for deform_exact_list_kernel.
-// (launch bounds: four workgroups per CU -- the rare exact evaluation is what the compiler spills, not the per-voxel path)
-template <typename W, bool INLINE>
-__global__ __launch_bounds__(kBlock, 4) void deform_tile3_label_kernel(const GridGeom g, const IOView v,
+template <typename W>
+__global__ __launch_bounds__(kBlock) void deform_tile3_label_kernel(const GridGeom g, const IOView v,
                                                                     const TileGeom tg)
 {
-    extern __shared__ double sgrid[];        // INLINE: the control grid as doubles (stage_grid_lds)
     const W* inp = reinterpret_cast<const W*>(v.in);
     W* outp = reinterpret_cast<W*>(v.out);
     const int ntile_total = tg.tiles[0] * tg.tiles[1] * tg.tiles[2];
     const int tid = threadIdx.x;
     const int xx = tid & 7, yy = (tid >> 3) & 7, zq = tid >> 6;
     constexpr double kEps = 1e-6;
-    bool staged = false;
-    int per = 0;
-    auto put = [&](int obase, bool cst, int src_idx) {
-        for (int64_t ss = 0; ss < v.nsteps; ++ss) {
-            int64_t in_off, out_off;
-            step_offsets(v, ss, in_off, out_off);
-            if (cst)
-                store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype, v.cval);
-            else if (sizeof(W) == 8)
-                // 64-bit integers: the reference takes every value through a double and the
-                // rounding / clamping store (deform.c:863-887,906-919), which changes labels
-                // beyond 2^53 and near the type's limits -- reproduce that round trip
-                store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype,
-                              load_as_double(reinterpret_cast<const char*>(inp + (in_off + src_idx)),
-                                             v.in_dtype));
-            else
-                __builtin_nontemporal_store(inp[in_off + src_idx], outp + (out_off + obase));
-        }
-    };
     for (int s = blockIdx.x; s < ntile_total; s += gridDim.x) {
         int t = s;
         const int tx = t % tg.tiles[2];
@@ -1205,13 +1180,13 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_label_kernel(const Gri
         const int ty = t % tg.tiles[1];
         const int tz = t / tg.tiles[1];
         const int ox = tx * kT + xx, oy = ty * kT + yy;
-        const bool vxy = ox < tg.out_len[2] && oy < tg.out_len[1];
-        const AxTab tx_ = tg.xt_global[vxy ? ox : 0];
-        unsigned ties = 0;
+        if (ox >= tg.out_len[2] || oy >= tg.out_len[1])
+            continue;
+        const AxTab tx_ = tg.xt_global[ox];
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
             const int oz = tz * kT + zq + 4 * i;
-            if (!vxy || oz >= tg.out_len[0])
+            if (oz >= tg.out_len[0])
                 continue;
             const int o[3] = {oz, oy, ox};
             const double* qrow0 = tg.q_global + ((int64_t)oz * tg.out_len[1] + oy) * 4 * tg.ncpx;
@@ -1241,13 +1216,10 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_label_kernel(const Gri
                       !(raw[h] == raw[h]);
             }
             if (tie) {
-                if (INLINE) {
-                    ties |= 1u << i;       // redone below, in the reference's own arithmetic
-                } else {
-                    const int slot = atomicAdd(&tg.label_list[0], 1);
-                    if (slot < tg.label_cap)
-                        tg.label_list[1 + slot] = (oz * tg.out_len[1] + oy) * tg.out_len[2] + ox;
-                }
+                // left to the tie kernel (the reference's own arithmetic for this voxel)
+                const int slot = atomicAdd(&tg.label_list[0], 1);
+                if (slot < tg.label_cap)
+                    tg.label_list[1 + slot] = (oz * tg.out_len[1] + oy) * tg.out_len[2] + ox;
                 continue;
             }
             int src_idx = 0;
@@ -1260,39 +1232,21 @@ __global__ __launch_bounds__(kBlock, 4) void deform_tile3_label_kernel(const Gri
                 const int st = (int)floor(c + 0.5);
                 src_idx += mirror_i32(cst ? 0 : st, tg.in_len[h]) * tg.in_stride[h];
             }
-            put(o[0] * tg.out_stride[0] + o[1] * tg.out_stride[1] + o[2] * tg.out_stride[2], cst, src_idx);
-        }
-        if constexpr (INLINE) {
-            // (block-uniform: every thread of the workgroup gets here once per tile)
-            if (__syncthreads_or(ties != 0)) {
-                if (!staged) {
-                    per = stage_grid_lds<3>(g, sgrid);
-                    staged = true;
-                    __syncthreads();
-                }
-#pragma unroll 1
-                for (int i = 0; i < 2; ++i) {
-                    if (!((ties >> i) & 1u))
-                        continue;
-                    const int64_t o64[3] = {tz * kT + zq + 4 * i, oy, ox};
-                    double displ[3];
-                    eval_displacement_lds<3>(g, sgrid, per, o64, displ);
-                    int src_idx = 0;
-                    bool cst = false;
-#pragma unroll
-                    for (int h = 0; h < 3; ++h) {
-                        const double c = map_coordinate(raw_coordinate<3>(g, o64, h, displ[h]), g.in_len[h], tg.mode);
-                        if (!cst && c > -1.0) {
-                            const int64_t st = window_start(c, 0);
-                            const bool edge = st < 0 || st >= g.in_len[h];
-                            src_idx += (int)(edge ? mirror_index(st, g.in_len[h]) : st) * tg.in_stride[h];
-                        } else {
-                            cst = true;
-                        }
-                    }
-                    put((int)o64[0] * tg.out_stride[0] + (int)o64[1] * tg.out_stride[1] + (int)o64[2] * tg.out_stride[2],
-                        cst, src_idx);
-                }
+            const int obase = o[0] * tg.out_stride[0] + o[1] * tg.out_stride[1] + o[2] * tg.out_stride[2];
+            for (int64_t ss = 0; ss < v.nsteps; ++ss) {
+                int64_t in_off, out_off;
+                step_offsets(v, ss, in_off, out_off);
+                if (cst)
+                    store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype, v.cval);
+                else if (sizeof(W) == 8)
+                    // 64-bit integers: the reference takes every value through a double and the
+                    // rounding / clamping store (deform.c:863-887,906-919), which changes labels
+                    // beyond 2^53 and near the type's limits -- reproduce that round trip
+                    store_forward(reinterpret_cast<char*>(outp + (out_off + obase)), v.out_dtype,
+                                  load_as_double(reinterpret_cast<const char*>(inp + (in_off + src_idx)),
+                                                 v.in_dtype));
+                else
+                    __builtin_nontemporal_store(inp[in_off + src_idx], outp + (out_off + obase));
             }
         }
     }
@@ -1643,21 +1597,14 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         }
         if (e == hipSuccess) {
             const unsigned nblk = (unsigned)(ntiles < (1 << 20) ? ntiles : (1 << 20));
-            // the near-tie voxels, in the reference's evaluation order: by the label kernel itself when the control
-            // grid fits its LDS (<= 4096 coefficients; 128^3 uint8: one launch of 29 us), otherwise listed for the
-            // exact kernel's list form.  (A kernel of this file used to walk the list with the grid in global memory:
-            // its handful of voxels sat in ONE wave and 192 dependent loads -- 50 us behind the label kernel.)
-            const size_t points = 3 * (size_t)g.ncp[0] * (size_t)g.ncp[1] * (size_t)g.ncp[2];
-            if (points <= 4096 && !ed_env("EDHIP_LABEL_LIST")) {
-                hipLaunchKernelGGL((deform_tile3_label_kernel<T, true>), dim3(nblk), dim3(kBlock), points * sizeof(double),
-                                   stream, g, ve, tg);
-                e = hipGetLastError();
-            } else {
-                hipLaunchKernelGGL((deform_tile3_label_kernel<T, false>), dim3(nblk), dim3(kBlock), 0, stream, g, ve, tg);
-                e = hipGetLastError();
-                if (e == hipSuccess)
-                    e = launch_deform_exact_list(g, v, tg.label_list, tg.label_cap, stream);
-            }
+            hipLaunchKernelGGL(deform_tile3_label_kernel<T>, dim3(nblk), dim3(kBlock), 0, stream, g, ve, tg);
+            e = hipGetLastError();
+            // the near-tie voxels, in the reference's evaluation order: the exact kernel's list form (control grid in
+            // LDS; it leaves at once when the list is empty).  A kernel of this file used to do it with the grid in
+            // global memory: its handful of voxels sat in ONE wave that walked 192 dependent loads -- 50 us behind a
+            // 29 us label kernel (128^3 uint8).
+            if (e == hipSuccess)
+                e = launch_deform_exact_list(g, v, tg.label_list, tg.label_cap, stream);
         }
         return e;
     } else {
