@@ -1149,7 +1149,21 @@ inline size_t q_global_bytes(const GridGeom& g, bool wide_opt = false)
         const size_t per_strip = strips * (size_t)wide_window(g);
         cols = per_strip > cols ? per_strip : cols;
     }
-    return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 4 * cols;
+    const size_t q = 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 4 * cols;
+    // (the forward route of deform_k1z.hip keeps R[o_y][o_x][ncp_z][4] in the same region instead: one of the two
+    // tables per call)
+    const size_t r = k1z_supported(g) ? k1z_r_bytes(g) : 0;
+    return q > r ? q : r;
+}
+// z table + tile records of deform_k1z.hip, behind the label list
+constexpr size_t kK1zMaxSteps = 4096;
+inline size_t k1z_zt_bytes(const GridGeom& g) { return (sizeof(AxTab) * (size_t)g.out_len[0] + 63) & ~(size_t)63; }
+inline size_t k1z_extra_bytes(const GridGeom& g, int64_t ntiles, int nbatch)
+{
+    // z table | tile records (32 bytes each) | one flag per strip (at most one strip per tile) | step offsets
+    // (+ the strip summaries and the two work lists: one int per strip each)
+    // (the lists are dealt per XCD, entry k of XCD x at slot 8 k + x: 8 slots per strip each, in case one XCD gets them all)
+    return k1z_supported(g) ? k1z_zt_bytes(g) + (((size_t)ntiles * (size_t)nbatch * 104 + 63) & ~(size_t)63) + kK1zMaxSteps * 16 : 0;
 }
 
 // ================================================================================================
@@ -1427,7 +1441,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // (edhip_deform reserved deform_tile_workspace_bytes() up front, so this does not move the
     // prefiltered control grid that may sit in the head of the workspace)
     void* ws = workspace_reserve(stream, kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q_all +
-                                             label_list_bytes(g), &e);
+                                             label_list_bytes(g) + k1z_extra_bytes(g, ntiles, nb), &e);
     if (!ws)
         return e;
     ws = (char*)ws + kWorkspaceGridBytes;
@@ -1681,7 +1695,57 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 // build can still run the kernel it replaced (EDHIP_K1_OLD)
                 [[maybe_unused]] const bool k1_new = !GRAD && ORDER <= 3 && tg.strip_tiles <= 8 && !ed_env("EDHIP_K1_OLD") &&
                                                      !ed_env("EDHIP_RECORDS");
-                if (k1_new) {
+                // round 6: strips along z on R tables (deform_k1z.hip) for every grid its geometry kernel holds in LDS
+                const bool k1z = k1_new && !wide && k1z_supported(g) && ve.nsteps <= (int64_t)kK1zMaxSteps && !ed_env("EDHIP_K1_R5");
+                ZGeom zg;
+                memset(&zg, 0, sizeof(zg));
+                SideLane* zside = nullptr;
+                if (k1z) {
+                    (void)k1z_lds_bytes(&hg.small_cap, false);
+                    hlds = k1z_lds_bytes(&hg.box_cap, large_boxes);
+                    hg.off_box = 0;
+                    hg.hint = sh ? tg.hint : nullptr;
+                    double r2 = 0.0;
+                    for (int k = 0; k < 3; ++k) {
+                        const double r = g.in_len[k] > 1 ? (double)(g.ncp[k] - 1) / (double)(g.in_len[k] - 1) : 0.0;
+                        r2 += r * r;
+                    }
+                    zg.slack_scale = 0.15 * 1.125 * 4.0 * r2;
+                    zg.r = tg.q_global;
+                    zg.r_bstride = tg.q_bstride;
+                    char* zx = (char*)ws + 2 * list_bytes + xt_bytes + q_all + label_list_bytes(g);
+                    zg.zt = (const AxTab*)zx;
+                    zg.recs = (int*)(zx + k1z_zt_bytes(g));
+                    zg.missed = zg.recs + (size_t)ntiles * nb * 8;
+                    zg.sinfo = zg.missed + (size_t)ntiles * nb;
+                    zg.list_g = zg.sinfo + (size_t)ntiles * nb;
+                    zg.list_f = zg.list_g + (size_t)ntiles * nb * 8;
+                    zg.steps = (long long*)(zx + k1z_zt_bytes(g) + (((size_t)ntiles * nb * 104 + 63) & ~(size_t)63));
+                    // the lists' counters: 32 ints in the (cleared) tail of the workspace head, in front of the hint words
+                    zg.ctl = (int*)((char*)ws - 512);
+                    zside = side_lane(stream);
+                    zg.parity = zside ? (int)(zside->parity & 1) : 0;
+                    zg.disp_bstride = tg.disp_bstride;
+                    zg.ncpz = (int)g.ncp[0];
+                    zg.order = ORDER;
+                    zg.strip_tiles = 4;
+                    while (zg.strip_tiles > 1 &&
+                           (int64_t)nb * tg.tiles[1] * tg.tiles[2] * ((tg.tiles[0] + zg.strip_tiles - 1) / zg.strip_tiles) < 1024)
+                        zg.strip_tiles >>= 1;
+#ifdef EDHIP_EXPERIMENTS
+                    if (const char* st = ed_env("EDHIP_ZSTRIP"))
+                        zg.strip_tiles = atoi(st) >= 1 ? atoi(st) : zg.strip_tiles;
+#endif
+                    zg.nstrips = tg.tiles[1] * tg.tiles[2] * ((tg.tiles[0] + zg.strip_tiles - 1) / zg.strip_tiles);
+                    zg.total_strips = zg.nstrips * nb;
+                    zg.hint = hg.hint;
+                    zg.hint_host = tg.hint_host;
+                    zg.hint_seq = tg.hint_seq;
+#ifdef EDHIP_EXPERIMENTS
+                    if (const char* pp = ed_env("EDHIP_DEBUG_PTR"))
+                        hg.dbgbuf = (unsigned long long*)strtoull(pp, nullptr, 16);
+#endif
+                } else if (k1_new) {
                     int off_small = 0;
                     (void)k1_lds_bytes(hot_cols, &hg.small_cap, &off_small, false);
                     if (large_boxes)
@@ -1805,7 +1869,24 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         }
                     }
                 }
-                launch_tables();
+                if (k1z && e == hipSuccess) {
+                    // the geometry kernel in place of the tables kernel: R, the z table, tile records (and boxes)
+                    GridPrefilter gp;
+                    memset(&gp, 0, sizeof(gp));
+                    const bool own = batch && batch->gridpf && nb == 1 && batch->gridpf->total <= 4096;
+                    if (own) {
+                        gp = *batch->gridpf;
+                        gp.zero_ptr = nullptr;
+                        gp.zero_bytes = 0;
+                    }
+                    e = launch_k1z_geo(g, hg, zg, gp, nb, stream);
+                    if (e == hipSuccess && zside)
+                        ++zside->parity;       // (the launch is in the stream: the next call uses the other counters)
+                    if (own && e == hipSuccess)
+                        batch->gridpf_done = true;
+                    tables_done = true;
+                } else
+                    launch_tables();
                 if (rec_route && e == hipSuccess) {
                     // gradient from records: (1) K1 in records-only form -- its workgroups leave at once for the
                     // samples whose records the forward call made from these very grid values -- (2) the
@@ -1911,11 +1992,12 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 if (wide_wave && !wave_done && e == hipSuccess)
                     e = hipErrorNotSupported;        // (no other level-1 kernel can take a grid this wide)
                 if (hlds && !wave_done && !hot_done && e == hipSuccess) {
-                    const hipError_t he = k1_new ? launch_k1_level1(hg, ORDER, nblk, hlds, stream)
-                                                 : launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream);
+                    const hipError_t he = k1z ? launch_k1z(hg, zg, ORDER, hlds, stream, zside)
+                                          : (k1_new ? launch_k1_level1(hg, ORDER, nblk, hlds, stream)
+                                                    : launch_hot_level1(hg, ORDER, GRAD, nblk, hlds, stream));
                     if (he == hipSuccess) {
                         hot_done = true;
-                        served_all = hg.self_serve != 0;
+                        served_all = hg.self_serve != 0 || k1z;
                         if (!GRAD && hg.boxes && key)
                             *key = cur;
                     } else if (he != hipErrorNotSupported || v.out16 || wide)
@@ -2036,7 +2118,7 @@ size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch, bool f64)
     if (q > ((size_t)512 << 20))
         return kWorkspaceGridBytes;
     return kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + ((q * (size_t)nbatch + 63) & ~(size_t)63) +
-           label_list_bytes(g);
+           label_list_bytes(g) + k1z_extra_bytes(g, ntiles, nbatch);
 }
 
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)

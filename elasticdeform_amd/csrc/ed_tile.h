@@ -4,6 +4,7 @@
 
 #include "ed_device.h"
 #include "ed_params.h"
+#include "ed_workspace.h"
 
 namespace ed {
 namespace tile {
@@ -458,6 +459,41 @@ hipError_t launch_hot_grad2(const HotGeom& hg, int order, unsigned nblk, size_t 
 // most 4 tiles; hipErrorNotSupported (nothing launched) otherwise
 size_t k1_lds_bytes(int ncpx, int* box_cap, int* off_box, bool large = false);
 hipError_t launch_k1_level1(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream);
+
+// ---- K1 of round 6 (deform_k1z.hip): strips along z, displacement contracted over y and x ------------------------
+// Second argument block of k1z_fwd_kernel / k1z_geo_kernel, next to HotGeom.
+struct ZGeom {
+    const double* r;          // [sample][O_y][O_x][ncp_z][4]: displacement contracted over y and x (component padded to 4)
+    const AxTab* zt;          // [O_z]: cubic weights / control-plane byte offsets (x 32) along z
+    int* recs;                // [sample * ntiles + tile][8]: tile records, written by the geometry kernel
+    int* missed;              // [sample * nstrips + strip]: the fast kernel saw a window outside its sampled box
+    long long* steps;         // [nsteps][2]: element offsets (volume, image) of every index of the step axes
+    int* sinfo;               // [sample * nstrips + strip]: 3 bits per tile of the strip (class, beyond the standard box)
+    // work lists of strips: G = general tiles (geometry kernel), F = tiles that do not fit (geometry kernel) or a window
+    // outside its sampled box (tile kernels).  ctl[parity] / ctl[2 + parity] = their counts for this call; the geometry
+    // kernel clears the other parity's for the next call on the stream (the workspace head is cleared when allocated)
+    int* list_g;
+    int* list_f;
+    int* ctl;
+    int parity;
+    long long r_bstride;      // doubles between consecutive samples of r
+    long long disp_bstride;   // bytes between the control grids of consecutive samples
+    int ncpz;
+    int order;
+    int strip_tiles;          // tiles per strip (along z)
+    int nstrips;              // strips per sample
+    int total_strips;
+    double slack_scale;       // margin of the sampled boxes = clamp(slack_scale * max |D_f[h]|, 0.02, 0.75)
+    int* hint;                // spill feedback (TileGeom::hint): reset / reported by the geometry kernel, counted by K1
+    unsigned long long* hint_host;
+    unsigned hint_seq;
+};
+size_t k1z_lds_bytes(int* box_cap, bool large = false);
+bool k1z_supported(const GridGeom& g);
+size_t k1z_r_bytes(const GridGeom& g);
+hipError_t launch_k1z_geo(const GridGeom& g, const HotGeom& hg, const ZGeom& zg, const GridPrefilter& gp, int nbatch,
+                          hipStream_t stream);
+hipError_t launch_k1z(const HotGeom& hg, const ZGeom& zg, int order, size_t lds, hipStream_t stream, ed::SideLane* side);
 
 // one-wavefront-per-tile kernels (deform_wave.hip): same argument block; `strip_tiles`, `strips_x`,
 // `nstrips`, `total_strips` describe the strips of the 64-thread workgroups, `box_cap` the floats /

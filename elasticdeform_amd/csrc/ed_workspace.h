@@ -65,6 +65,18 @@ GridStamp* grid_stamp(hipStream_t stream);
 // counts the times the stream's workspace buffer was freed or replaced (a stamp from an earlier generation is void)
 unsigned long long workspace_generation(hipStream_t stream);
 
+// A second stream per (device, stream) with the two events that fork it from / join it to the caller's stream, for the
+// forward route of deform_k1z.hip: the general-tile kernel runs next to the class-A kernel.  `parity` alternates
+// between the calls of that route (which pair of work-list counters in the workspace head the call uses).  nullptr:
+// no second stream could be made (the caller launches everything on its own stream).  Callers hold the StreamGuard.
+struct SideLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    unsigned parity = 0;
+    bool usable = false;
+};
+SideLane* side_lane(hipStream_t stream);
+
 // Drains the devices that own scratch and frees every cached buffer.
 void workspace_release_all();
 

@@ -34,6 +34,11 @@ struct HintSlot {
     bool tried = false;
 };
 std::map<std::pair<int, hipStream_t>, HintSlot> g_hints;      // (std::map: addresses are stable)
+struct SideSlot {
+    SideLane lane;
+    bool tried = false;
+};
+std::map<std::pair<int, hipStream_t>, SideSlot> g_sides;      // (std::map: addresses are stable; never erased)
 // one host-side lock per (device, stream); entries are never erased, so the pointers stay valid
 std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::recursive_mutex>> g_stream_locks;
 }  // namespace
@@ -127,6 +132,35 @@ void* workspace_reserve(hipStream_t stream, size_t bytes, hipError_t* err)
     // host: leftover memory must not pass for a report (SpillHint::absorb matches small sequence numbers)
     (void)hipMemsetAsync(b.ptr, 0, want < (size_t)65536 ? want : (size_t)65536, stream);
     return b.ptr;
+}
+
+SideLane* side_lane(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    SideSlot& sl = g_sides[std::make_pair(dev, stream)];
+    if (!sl.tried) {
+        sl.tried = true;
+        hipStream_t s2 = nullptr;
+        hipEvent_t e1 = nullptr, e2 = nullptr;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) {
+            sl.lane.stream = s2;
+            sl.lane.fork = e1;
+            sl.lane.join = e2;
+            sl.lane.usable = true;
+        } else {
+            (void)hipGetLastError();
+            if (e1)
+                (void)hipEventDestroy(e1);
+            if (s2)
+                (void)hipStreamDestroy(s2);
+        }
+    }
+    return &sl.lane;
 }
 
 void* keep_reserve(hipStream_t stream, size_t bytes, KeepKey** key, hipError_t* err)

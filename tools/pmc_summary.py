@@ -8,7 +8,7 @@ def main(root):
             agg[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print("==", f)
         for k, cs in agg.items():
-            if not any(t in k for t in ("deform_", "prefilter", "hot_", "wave_", "k1_", "k2_")): continue
+            if not any(t in k for t in ("deform_", "prefilter", "hot_", "wave_", "k1_", "k2_", "k1z_")): continue
             print("  ", k)
             for c, v in cs.items():
                 print("      %-24s n=%-4d mean=%.4g" % (c, len(v), sum(v) / len(v)))
