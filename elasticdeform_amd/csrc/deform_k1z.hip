@@ -112,17 +112,36 @@ typedef const __attribute__((address_space(4))) long long* cll_p;
     "v_max_i32_dpp %3, %3, %3 " CTRL "\n\t"                \
     "v_max_i32_dpp %4, %4, %4 " CTRL "\n\t"                \
     "v_max_i32_dpp %5, %5, %5 " CTRL "\n\t"
-// min of lo[3] / max of hi[3] over the wave's 64 lanes (all active), result in lane 63
-__device__ __forceinline__ void zwave_box63(int (&lo)[3], int (&hi)[3])
+// min of lo[3] / max of hi[3] over each ROW of 16 lanes (all 64 active): afterwards every lane holds its row's result
+__device__ __forceinline__ void zrow_box(int (&lo)[3], int (&hi)[3])
 {
     asm volatile("s_nop 1\n\t"
                  ED_RED6("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
                  ED_RED6("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
                  ED_RED6("row_half_mirror row_mask:0xf bank_mask:0xf")
                  ED_RED6("row_mirror row_mask:0xf bank_mask:0xf")
-                 ED_RED6("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 ED_RED6("row_bcast:31 row_mask:0xc bank_mask:0xf")
                  : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
+}
+// The four rows are the four sampled z slices of a tile (0, 2, 4, 7): ranges of the whole tile, of its low half
+// (slices 0-3: the samples at 0, 2 and 4 -- the sample at 4 bounds slice 3 by interpolation) and of its high half
+// (slices 4-7: the samples at 4 and 7).  part 0 whole, 1 low, 2 high; scalar results.
+__device__ __forceinline__ void zparts(const int (&lo)[3], const int (&hi)[3], int (&plo)[3][3], int (&phi)[3][3])
+{
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        int l[4], u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            l[r] = __builtin_amdgcn_readlane(lo[h], 16 * r);
+            u[r] = __builtin_amdgcn_readlane(hi[h], 16 * r);
+        }
+        plo[1][h] = min(min(l[0], l[1]), l[2]);
+        phi[1][h] = max(max(u[0], u[1]), u[2]);
+        plo[2][h] = min(l[2], l[3]);
+        phi[2][h] = max(u[2], u[3]);
+        plo[0][h] = min(plo[1][h], l[3]);
+        phi[0][h] = max(phi[1][h], u[3]);
+    }
 }
 #undef ED_RED6
 __device__ __forceinline__ int zuni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -179,8 +198,8 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
     double* sMax = reinterpret_cast<double*>(sAx + 16);       // [3][waves] partial maxima
     AxTab* sZ = reinterpret_cast<AxTab*>(sMax + 3 * kGeoWaves);
     int* sCls = reinterpret_cast<int*>(sZ + 4 * hg.tiles[0]);        // [tiles_z]: class of every tile of the column
-    int* sBox = sCls + hg.tiles[0];                                  // [tiles_z][16]: reduced sample ranges
-    int* sCnt = sBox + 16 * hg.tiles[0];                             // [4]          // [tiles_z][4]: z entries of the sampled slices
+    int* sBox = sCls + hg.tiles[0];                                  // [tiles_z][3 parts][16]: reduced sample ranges
+    int* sCnt = sBox + 48 * hg.tiles[0];                             // [4]          // [tiles_z][4]: z entries of the sampled slices
     const int ty = blockIdx.x / hg.tiles[2], tx = blockIdx.x - ty * hg.tiles[2];
     if (ED_DBG(hg.dbg, 1 << 23))
         return;
@@ -342,16 +361,15 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
             lo[h] = (int)floor(cr - slack[h]);
             hi[h] = (int)floor(cr + slack[h]);
         }
-        zwave_box63(lo, hi);
-        int rlo[3], rhi[3];
+        zrow_box(lo, hi);
+        int rlo[3][3], rhi[3][3];          // [part][axis]: raw ranges
+        zparts(lo, hi, rlo, rhi);
         // fast: a full tile whose every coordinate, margin included, is one coord_axis_fast accepts
         bool fast = nz == kT && ny == kT && nx == kT;
 #pragma unroll
-        for (int h = 0; h < 3; ++h) {
-            rlo[h] = __builtin_amdgcn_readlane(lo[h], 63);
-            rhi[h] = __builtin_amdgcn_readlane(hi[h], 63);
-            fast = fast && rlo[h] >= ((order & 1) ? 0 : 1) && rhi[h] <= hg.in_len[h] - 2;
-        }
+        for (int h = 0; h < 3; ++h)
+            fast = fast && rlo[0][h] >= ((order & 1) ? 0 : 1) && rhi[0][h] <= hg.in_len[h] - 2;
+        int mlo[3][3], mhi[3][3];          // mapped ranges (general tiles)
         if (!fast) {
             // general tile: the range of the MAPPED coordinate over the samples (a sample that maps to the constant has
             // no window); where the raw range straddles an end of the array, the end itself is included below
@@ -373,18 +391,22 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
                     hi[h] = (int)0x80000000;
                 }
             }
-            zwave_box63(lo, hi);
+            zrow_box(lo, hi);
+            zparts(lo, hi, mlo, mhi);
         }
         if (lane == 63) {
-            int* dst = sBox + tz * 16;
 #pragma unroll
-            for (int h = 0; h < 3; ++h) {
-                dst[h] = lo[h];
-                dst[4 + h] = hi[h];
-                dst[8 + h] = rlo[h];
-                dst[12 + h] = rhi[h];
+            for (int part = 0; part < 3; ++part) {
+                int* dst = sBox + (tz * 3 + part) * 16;
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    dst[h] = fast ? rlo[part][h] : mlo[part][h];
+                    dst[4 + h] = fast ? rhi[part][h] : mhi[part][h];
+                    dst[8 + h] = rlo[part][h];
+                    dst[12 + h] = rhi[part][h];
+                }
+                dst[3] = fast ? 1 : 0;
             }
-            dst[3] = fast ? 1 : 0;
         }
     }
     __syncthreads();
@@ -392,71 +414,93 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
     // ---- tile records: one THREAD per tile of the column (the derivation is a chain of ~100 scalar steps: as lane 63
     //      of the sampling wave it cost every tile a wave's issue slots) --------------------------------------------
     for (int tz = tid; tz < hg.tiles[0] && !ED_DBG(hg.dbg, 1 << 27); tz += kGeoBlock) {
-        const int* sb = sBox + tz * 16;
-        const bool fast = sb[3] != 0;
-        int blo[3], bhi[3];
-        bool any = true;
-#pragma unroll
-        for (int h = 0; h < 3; ++h) {
-            int lo = sb[h], hi = sb[4 + h];
-            const int rlo = sb[8 + h], rhi = sb[12 + h];
-            if (!fast) {
-                any = any && hi >= lo;
-                // the lowest / highest floor a coordinate that stays in (or is folded / clamped back into) the array can
-                // have, wherever the raw range reaches beyond what coord_axis_fast accepts
-                const int lowfold = hg.mode == EDHIP_MODE_REFLECT ? -1 : 0;
-                if (rlo < ((order & 1) ? 0 : 1) && rhi >= lowfold)
-                    lo = min(lo, lowfold);
-                if (rhi > hg.in_len[h] - 2 && rlo <= hg.in_len[h] - 1)
-                    hi = max(hi, hg.in_len[h] - 1);
-            }
-            blo[h] = lo - H;
-            bhi[h] = hi - H + order + (h == 2 ? kPadX : 0);
-        }
-        if (!any) {          // every sample maps to the constant
-            blo[0] = blo[1] = blo[2] = 0;
-            bhi[0] = bhi[1] = bhi[2] = -1;
-        }
-        any = bhi[0] >= blo[0] && bhi[1] >= blo[1] && bhi[2] >= blo[2];
-        unsigned ext[3];
-#pragma unroll
-        for (int h = 0; h < 3; ++h)
-            ext[h] = (unsigned)bhi[h] - (unsigned)blo[h] + 1u;
-        const int pitch = ext[2] <= 16u ? 16 : (ext[2] <= 48u ? 48 : 0);
-        const bool sane = any && ext[0] < 1024u && ext[1] < 1024u;
-        const int nrows = sane ? (int)(ext[0] * ext[1]) : 0;
-        const bool fits = sane && pitch > 0 && nrows * pitch <= hg.box_cap;
-        const bool dma = fits && blo[2] >= 0 && blo[2] + pitch + 1 <= hg.in_len[2];
-        const bool xin = fits && blo[2] >= 0 && blo[2] + (int)ext[2] <= hg.in_len[2];
-        const bool zyin = fits && blo[0] >= 0 && blo[0] + (int)ext[0] <= hg.in_len[0] && blo[1] >= 0 &&
-                          blo[1] + (int)ext[1] <= hg.in_len[1];
-        // class A (k1z_fast_kernel): full tile, coordinates inside the array, box inside the array, LDS-DMA rows.
-        // Everything else that fits is a general tile (k1z_gen_kernel); a tile that is fast but whose box touches the
-        // array's ends has raw == mapped coordinates, so its box is a general tile's box as it stands.
-        const bool fastA = fast && fits && dma && zyin;
-        const int flags = (any ? kZAny : 0) | (fits ? kZStaged : 0) | (fastA ? kZFast : kZGen) | (dma ? kZDma : 0) |
-                          (xin ? kZXin : 0) | (zyin ? kZZYin : 0) | (any && !fits ? kZUnfit : 0);
-        const bool hintf = any && !(sane && pitch > 0 && nrows * pitch <= hg.small_cap);
         const int tile_id = sample * hg.ntiles + (tz * hg.tiles[1] + ty) * hg.tiles[2] + tx;
-        ZSTAT((flags & kZUnfit) ? 5 : ((flags & kZFast) ? 3 : 4), 1);
-        // class of the tile for the strip summary: 1 class A, 2 general, 3 does not fit; + 4: beyond the standard box
-        sCls[tz] = ((flags & kZUnfit) ? 3 : ((flags & kZFast) ? 1 : 2)) | (hintf ? 4 : 0);
-        int4* dst = reinterpret_cast<int4*>(zg.recs + (size_t)tile_id * 8);
-        dst[0] = make_int4(blo[0], blo[1], blo[2], flags | (pitch << 8) | (hintf ? 1 << 16 : 0));
-        dst[1] = make_int4(sane ? (int)(ext[0] | (ext[1] << 10) | (ext[2] << 20)) : 0,
-                           (dma && zyin) ? blo[0] * hg.vol_sz + blo[1] * hg.vol_sy + blo[2] : 0, 0, 0);
-        if (hg.boxes) {
-            int* bx = hg.boxes + (size_t)tile_id * 8;
+        int cls = 0;
+        bool hint0 = false, half_fit[2] = {false, false};
+        // part 0: the whole tile; parts 1 / 2: its halves along z (the lane's first / second voxel), used when the whole
+        // tile's box does not fit LDS
+#pragma unroll 1
+        for (int part = 0; part < 3; ++part) {
+            const int* sb = sBox + (tz * 3 + part) * 16;
+            const bool fast = sb[3] != 0;
+            int blo[3], bhi[3];
+            bool any = true;
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                bx[h] = blo[h];
-                bx[3 + h] = bhi[h] - ((h == 2 && any) ? kPadX : 0);      // (without the forward gather's padding tap)
+                int lo = sb[h], hi = sb[4 + h];
+                const int rlo = sb[8 + h], rhi = sb[12 + h];
+                if (!fast) {
+                    any = any && hi >= lo;
+                    // the lowest / highest floor a coordinate that stays in (or is folded / clamped back into) the array
+                    // can have, wherever the raw range reaches beyond what coord_axis_fast accepts
+                    const int lowfold = hg.mode == EDHIP_MODE_REFLECT ? -1 : 0;
+                    if (rlo < ((order & 1) ? 0 : 1) && rhi >= lowfold)
+                        lo = min(lo, lowfold);
+                    if (rhi > hg.in_len[h] - 2 && rlo <= hg.in_len[h] - 1)
+                        hi = max(hi, hg.in_len[h] - 1);
+                }
+                blo[h] = lo - H;
+                bhi[h] = hi - H + order + (h == 2 ? kPadX : 0);
+            }
+            if (!any) {          // every sample maps to the constant
+                blo[0] = blo[1] = blo[2] = 0;
+                bhi[0] = bhi[1] = bhi[2] = -1;
+            }
+            any = bhi[0] >= blo[0] && bhi[1] >= blo[1] && bhi[2] >= blo[2];
+            unsigned ext[3];
+#pragma unroll
+            for (int h = 0; h < 3; ++h)
+                ext[h] = (unsigned)bhi[h] - (unsigned)blo[h] + 1u;
+            const int pitch = ext[2] <= 16u ? 16 : (ext[2] <= 48u ? 48 : 0);
+            const bool sane = any && ext[0] < 1024u && ext[1] < 1024u;
+            const int nrows = sane ? (int)(ext[0] * ext[1]) : 0;
+            const bool fits = sane && pitch > 0 && nrows * pitch <= hg.box_cap;
+            const bool dma = fits && blo[2] >= 0 && blo[2] + pitch + 1 <= hg.in_len[2];
+            const bool xin = fits && blo[2] >= 0 && blo[2] + (int)ext[2] <= hg.in_len[2];
+            const bool zyin = fits && blo[0] >= 0 && blo[0] + (int)ext[0] <= hg.in_len[0] && blo[1] >= 0 &&
+                              blo[1] + (int)ext[1] <= hg.in_len[1];
+            // class A (k1z_fast_kernel): full tile, coordinates inside the array, box inside the array, LDS-DMA rows.
+            // Everything else that fits is a general tile (k1z_gen_kernel); a tile that is fast but whose box touches
+            // the array's ends has raw == mapped coordinates, so its box is a general tile's box as it stands.
+            const bool fastA = part == 0 && fast && fits && dma && zyin;
+            const int flags = (any ? kZAny : 0) | (fits ? kZStaged : 0) | (fastA ? kZFast : kZGen) | (dma ? kZDma : 0) |
+                              (xin ? kZXin : 0) | (zyin ? kZZYin : 0) | (any && !fits ? kZUnfit : 0);
+            const int4 w0 = make_int4(blo[0], blo[1], blo[2], flags | (pitch << 8));
+            const int4 w1 = make_int4(sane ? (int)(ext[0] | (ext[1] << 10) | (ext[2] << 20)) : 0,
+                                      (dma && zyin) ? blo[0] * hg.vol_sz + blo[1] * hg.vol_sy + blo[2] : 0, 0, 0);
+            if (part == 0) {
+                hint0 = any && !(sane && pitch > 0 && nrows * pitch <= hg.small_cap);
+                cls = (flags & kZUnfit) ? 3 : ((flags & kZFast) ? 1 : 2);
+                int4* dst = reinterpret_cast<int4*>(zg.recs + (size_t)tile_id * 8);
+                dst[0] = w0;
+                dst[1] = w1;
+                if (hg.boxes) {
+                    int* bx = hg.boxes + (size_t)tile_id * 8;
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        bx[h] = blo[h];
+                        bx[3 + h] = bhi[h] - ((h == 2 && any) ? kPadX : 0);      // (without the forward gather's padding tap)
+                    }
+                }
+                if (cls != 3)
+                    break;               // (the halves matter only where the whole tile does not fit)
+            } else {
+                // a half without windows (every sample constant) "fits": its voxels store the constant
+                half_fit[part - 1] = fits || !any;
+                int4* dst = reinterpret_cast<int4*>(zg.recs_half + ((size_t)tile_id * 2 + (part - 1)) * 8);
+                dst[0] = w0;
+                dst[1] = w1;
             }
         }
+        const bool split = cls == 3 && half_fit[0] && half_fit[1];
+        ZSTAT(cls == 3 ? (split ? 6 : 5) : (cls == 1 ? 3 : 4), 1);
+        // class of the tile for the strip summary: 1 class A, 2 general, 3 does not fit; + 4: does not fit but its halves
+        // do (taken by the general kernel half by half); + 8: beyond the standard box
+        sCls[tz] = cls | (split ? 4 : 0) | (hint0 ? 8 : 0);
     }
     __syncthreads();
     ZTICK(7);
-    // ---- strip summaries (3 bits per tile: class, beyond the standard box), the "missed" flags, and the two work lists:
+    // ---- strip summaries (4 bits per tile: class, halves fit, beyond the standard box), the "missed" flags, the work lists:
     //      G = strips with general tiles (k1z_gen_kernel), F = strips with tiles that do not fit (k1z_fix_kernel; the
     //      tile kernels append the strips in which a window fell outside its sampled box).  One atomic per list and
     //      column.  The counters of THIS call (parity p) were cleared by the previous call's geometry kernel; this one
@@ -472,9 +516,9 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
             bool g = false, f = false;
             for (int k = 0; k < zg.strip_tiles && tid * zg.strip_tiles + k < hg.tiles[0]; ++k) {
                 const int c = sCls[tid * zg.strip_tiles + k];
-                info |= c << (3 * k);
-                g = g || (c & 3) == 2;
-                f = f || (c & 3) == 3;
+                info |= c << (4 * k);
+                g = g || (c & 3) == 2 || (c & 7) == 7;
+                f = f || (c & 7) == 3;
             }
             const size_t sid = (size_t)sample * zg.nstrips + ((size_t)tid * hg.tiles[1] + ty) * hg.tiles[2] + tx;
             sidv = (int)sid;
@@ -668,7 +712,9 @@ struct ZFast {
     const double* r;
     const AxTab* zt;
     const int* recs;
+    const int* recs_half;     // [tile][2][8]: z halves of the tiles whose whole box does not fit
     int* missed;              // [strip]: bit 0: a window of a class-A tile was not inside its sampled box
+    int* hint;                // spill feedback: count of the tiles that do not fit the standard box (or nullptr)
     const int* sinfo;         // [strip]: tile classes (geometry kernel)
     const int* list_g;        // strips with general tiles (geometry kernel); count in ctl[parity]
     int* list_f;              // strips for the fix-up kernel; count in ctl[2 + parity]
@@ -703,9 +749,15 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_fast_kernel(const ZFast a)
     crec_p rec0 = (crec_p)(const void*)a.recs + ((size_t)sp.sample * a.ntiles + ((size_t)sp.tz0 * a.tiles_y + sp.ty) * a.tiles_x + sp.tx);
     // the strip's summary (geometry kernel): 3 bits per tile -- class 1 = A, 2 = general, 3 = does not fit
     const int sinfo = ((cint_p)(const void*)a.sinfo)[sp.id];
+    if (a.hint && tid == 0) {
+        // spill feedback: the strip's tiles that do not fit the standard box (this kernel visits every strip)
+        const int nh = __builtin_popcount((unsigned)sinfo & 0x88888888u);
+        if (nh)
+            atomicAdd(a.hint, nh);
+    }
     auto next_fast = [&](int t) {
         for (++t; t < ntile; ++t)
-            if (((sinfo >> (3 * t)) & 3) == 1)
+            if (((sinfo >> (4 * t)) & 3) == 1)
                 break;
         return t;
     };
@@ -849,7 +901,6 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_fast_kernel(const ZFast a)
             const int xcd = (int)(blockIdx.x & 7);
             a.list_f[(size_t)atomicAdd(a.ctl + zctl(a.parity, 1, xcd), 1) * 8 + xcd] = sp.id;
         }
-        ZSTAT(6, 1);
     }
 }
 
@@ -943,11 +994,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
         const int ntile = sp.ntile;
         crec_p rec0 = (crec_p)(const void*)a.recs + ((size_t)sp.sample * a.ntiles + ((size_t)sp.tz0 * a.tiles_y + sp.ty) * a.tiles_x + sp.tx);
         const int sinfo = ((cint_p)(const void*)a.sinfo)[sp.id];
-        int nhint = 0;
-        for (int t = 0; t < ntile; ++t)
-            nhint += (sinfo >> (3 * t + 2)) & 1;
-        if (nhint && zn.hint && tid == 0)
-            atomicAdd(zn.hint, nhint);             // spill feedback: tiles that do not fit the standard box
+        crec_p rech0 = (crec_p)(const void*)a.recs_half + ((size_t)sp.sample * a.ntiles + ((size_t)sp.tz0 * a.tiles_y + sp.ty) * a.tiles_x + sp.tx) * 2;
         if (tid == 0)
             ZSTAT(7, 1);
         if (work != (int)(blockIdx.x >> 3))
@@ -994,33 +1041,55 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
                 // the taps of a window that sticks out (deform.c:791-813)
                 const int nrows = rc.ez * rc.ey;
                 const float inv_by = __frcp_rn((float)by);
-                const bool xin = (flags & kZXin) != 0;
                 const int sub = tid & 7;
-                for (int r = tid >> 3; r < nrows; r += kBlock / 8) {
-                    const int zrow = (int)(((float)r + 0.5f) * inv_by), yr = r - zrow * by;
-                    const int zs = mirror_i32(rc.b0z + zrow, zn.in_len[0]);
-                    const int ys = mirror_i32(rc.b0y + yr, zn.in_len[1]);
-                    const float* rowp = src + (zs * vol_sz + ys * vol_sy);
-                    float* d0 = box0 + r * pitch;
-                    float* d1 = box1 + r * pitch;
-                    for (int xi = sub; xi < rc.ex; xi += 8) {
-                        const int xs = xin ? rc.b0x + xi : mirror_i32(rc.b0x + xi, zn.in_len[2]);
-                        const float val = rowp[xs];
-                        d0[xi] = val;
-                        if (xi > 0)
-                            d1[xi - 1] = val;
+                // (four rows of a thread in flight: one row at a time every load waited for the one before -- the boxes of
+                // the columns on the x faces took ~10 us each)
+                for (int rb = tid >> 3; rb < nrows; rb += 4 * (kBlock / 8)) {
+                    for (int x0 = sub; x0 < rc.ex; x0 += 16) {
+                        float val[4][2];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            // (addresses clamped instead of loads predicated: a predicated load lands in a basic block
+                            // of its own and is waited for right there)
+                            const int r = min(rb + u * (kBlock / 8), nrows - 1);
+                            const int zrow = (int)(((float)r + 0.5f) * inv_by), yr = r - zrow * by;
+                            const int zs = mirror_i32(rc.b0z + zrow, zn.in_len[0]);
+                            const int ys = mirror_i32(rc.b0y + yr, zn.in_len[1]);
+                            const float* rowp = src + (zs * vol_sz + ys * vol_sy);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int xi = min(x0 + 8 * j, rc.ex - 1);
+                                const int xs = mirror_i32(rc.b0x + xi, zn.in_len[2]);
+                                val[u][j] = rowp[xs];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = rb + u * (kBlock / 8);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int xi = x0 + 8 * j;
+                                if (r < nrows && xi < rc.ex) {
+                                    box0[r * pitch + xi] = val[u][j];
+                                    if (xi > 0)
+                                        box1[r * pitch + xi - 1] = val[u][j];
+                                }
+                            }
+                        }
                     }
                 }
             }
         };
         // ---- general coordinates of the lane's two voxels of a tile, constant and valid flags -------------------
         int bad = 0;
-        auto tile_coords = [&](int t, const ZRecU& rc, ZVox& vs) {
+        auto tile_coords = [&](int t, int mask, const ZRecU& rc, ZVox& vs) {
             const int ez = rc.ez - NT, ey = rc.ey - NT, ex = rc.ex - NTX;
             const bool staged = (rc.flags & kZStaged) != 0;
             vs.flg = 0;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                if (!(mask & (1 << i)))
+                    continue;               // (a half of a split tile: the other voxel belongs to the other half)
                 const int oz = (sp.tz0 + t) * kT + wave + 4 * i;
                 double zw[4];
                 k1z_slice(zt, rcol, min(oz, zn.out_len[0] - 1), tp, zw);
@@ -1045,28 +1114,42 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
                 vs.addr[i] = __mul24(off & 1, odd_shift) + off * 4;
             }
         };
-        // ---- the general tiles of the strip, software-pipelined like the class-A loop ---------------------------
+        // ---- the general tiles of the strip, software-pipelined like the class-A loop.  A work item is a general tile,
+        //      or one z half of a tile whose whole box does not fit LDS but whose halves do: the lane's first voxels
+        //      (z + 0 .. 3) with the low half's box, then its second voxels with the high half's ------------------------
         {
-            auto next_gen = [&](int t) {
-                for (++t; t < ntile; ++t)
-                    if (((sinfo >> (3 * t)) & 3) == 2)
+            // item = 2 * tile + half (a general tile: half 0 only, both voxels)
+            auto next_item = [&](int it) {
+                int t = it >> 1;
+                if (it >= 0 && (it & 1) == 0 && ((sinfo >> (4 * t)) & 7) == 7)
+                    return it + 1;
+                for (++t; t < ntile; ++t) {
+                    const int c = (sinfo >> (4 * t)) & 7;
+                    if ((c & 3) == 2 || c == 7)
                         break;
-                return t;
+                }
+                return 2 * t;
             };
+            auto item_rec = [&](int it) {
+                const int t = it >> 1;
+                const bool split = ((sinfo >> (4 * t)) & 7) == 7;
+                return zrec_load(split ? rech0 + ((size_t)t * tile_step * 2 + (it & 1)) : rec0 + (size_t)t * tile_step);
+            };
+            auto item_mask = [&](int it) { return ((sinfo >> (4 * (it >> 1))) & 7) == 7 ? 1 << (it & 1) : 3; };
             ZVox cur, nxt;
-            int ti = next_gen(-1);
-            ZRecU rc = zrec_load(rec0 + (size_t)(ti < ntile ? ti : 0) * tile_step), rn = rc;
-            if (ti < ntile)
-                tile_coords(ti, rc, cur);
-            while (ti < ntile) {
+            int it = next_item(-2);
+            ZRecU rc = item_rec(it < 2 * ntile ? it : 0), rn = rc;
+            if (it < 2 * ntile)
+                tile_coords(it >> 1, item_mask(it), rc, cur);
+            while (it < 2 * ntile) {
                 stage(rc, vol + (STEPS ? steps[0] : 0));
-                const int tn = next_gen(ti);
-                if (tn < ntile) {
-                    rn = zrec_load(rec0 + (size_t)tn * tile_step);
-                    tile_coords(tn, rn, nxt);
+                const int in = next_item(it);
+                if (in < 2 * ntile) {
+                    rn = item_rec(in);
+                    tile_coords(in >> 1, item_mask(in), rn, nxt);
                 }
                 const bool staged = (rc.flags & kZStaged) != 0;
-                const long long ozoff = (long long)((sp.tz0 + ti) * kT + wave) * img_sz + obase;
+                const long long ozoff = (long long)((sp.tz0 + (it >> 1)) * kT + wave) * img_sz + obase;
                 for (int ss = 0; ss < nsteps; ++ss) {
                     if (STEPS && ss > 0)
                         stage(rc, vol + steps[2 * ss]);
@@ -1086,7 +1169,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
                 }
                 cur = nxt;
                 rc = rn;
-                ti = tn;
+                it = in;
             }
         }
         if (__any(bad < 0) && lane == 0) {
@@ -1139,6 +1222,7 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, const ZG
         }
         const int ntile = sp.ntile;
         crec_p rec0 = (crec_p)(const void*)a.recs + ((size_t)sp.sample * a.ntiles + ((size_t)sp.tz0 * a.tiles_y + sp.ty) * a.tiles_x + sp.tx);
+        crec_p rech0 = (crec_p)(const void*)a.recs_half + ((size_t)sp.sample * a.ntiles + ((size_t)sp.tz0 * a.tiles_y + sp.ty) * a.tiles_x + sp.tx) * 2;
         const int sinfo = ((cint_p)(const void*)a.sinfo)[sp.id];
         const bool missed = (((cint_p)(const void*)a.missed)[sp.id] & 1) != 0;
         if (!STEPS && false)
@@ -1159,13 +1243,16 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, const ZG
             if (missed && lane == 0)
                 ZSTAT(0, 1);
             for (int ti = 0; ti < ntile; ++ti) {
-                const int cls = (sinfo >> (3 * ti)) & 3;
-                const bool whole = cls == 3;
+                const int c4 = (sinfo >> (4 * ti)) & 7;
+                const int cls = c4 & 3;
+                const bool split = c4 == 7;
+                const bool whole = cls == 3 && !split;
                 if (!whole && !missed)
                     continue;
-                const ZRecU rc = zrec_load(rec0 + (size_t)ti * tile_step);
 #pragma unroll 1
                 for (int i = 0; i < 2; ++i) {
+                    // (a split tile's voxel i worked with the box of half i)
+                    const ZRecU rc = zrec_load(split ? rech0 + ((size_t)ti * tile_step * 2 + i) : rec0 + (size_t)ti * tile_step);
                     const int oz = (sp.tz0 + ti) * kT + wave + 4 * i;
                     if (oz >= zn.out_len[0])
                         continue;                   // (uniform)
@@ -1189,7 +1276,7 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, const ZG
                         // A class-A tile's voxels worked with the RAW window start (no range test), a general tile's
                         // with the mapped one; the loop served the voxel iff that window lay inside the box (a constant
                         // voxel of a general tile needs no window).
-                        const bool gen = cls == 2;
+                        const bool gen = cls != 1;
                         if (gen && cst)
                             continue;
                         const int rz = (gen ? st[0] : raw[0]) - rc.b0z, ry = (gen ? st[1] : raw[1]) - rc.b0y,
@@ -1311,7 +1398,7 @@ size_t k1z_lds_bytes(int* box_cap, bool large)
 size_t k1z_geo_lds_bytes(const GridGeom& g, const HotGeom& hg)
 {
     const size_t ngrid = 3 * (size_t)g.ncp[0] * (size_t)g.ncp[1] * (size_t)g.ncp[2];
-    return 8 * ngrid + 8 * 64 * 3 * (size_t)g.ncp[0] + 16 * sizeof(AxTab) + 3 * kGeoWaves * 8 + (sizeof(AxTab) * 4 + 4 + 64) * (size_t)hg.tiles[0] + 16;
+    return 8 * ngrid + 8 * 64 * 3 * (size_t)g.ncp[0] + 16 * sizeof(AxTab) + 3 * kGeoWaves * 8 + (sizeof(AxTab) * 4 + 4 + 192) * (size_t)hg.tiles[0] + 16;
 }
 
 size_t k1z_r_bytes(const GridGeom& g) { return 8 * (size_t)g.out_len[1] * (size_t)g.out_len[2] * 4 * (size_t)g.ncp[0]; }
@@ -1321,7 +1408,7 @@ bool k1z_supported(const GridGeom& g)
     const size_t ngrid = 3 * (size_t)g.ncp[0] * (size_t)g.ncp[1] * (size_t)g.ncp[2];
     const size_t tiles_z = (size_t)((g.out_len[0] + kT - 1) / kT);
     return ngrid <= 4096 && g.ncp[0] <= 16 &&
-           8 * ngrid + 8 * 64 * 3 * (size_t)g.ncp[0] + 16 * sizeof(AxTab) + 3 * kGeoWaves * 8 + (sizeof(AxTab) * 4 + 4 + 64) * tiles_z + 16 <= 60 * 1024;
+           8 * ngrid + 8 * 64 * 3 * (size_t)g.ncp[0] + 16 * sizeof(AxTab) + 3 * kGeoWaves * 8 + (sizeof(AxTab) * 4 + 4 + 192) * tiles_z + 16 <= 60 * 1024;
 }
 
 hipError_t launch_k1z_geo(const GridGeom& g, const HotGeom& hg, const ZGeom& zg, const GridPrefilter& gp, int nbatch,
@@ -1341,7 +1428,9 @@ hipError_t launch_k1z(const HotGeom& hg, const ZGeom& zg, int order, size_t lds,
     zf.r = zg.r;
     zf.zt = zg.zt;
     zf.recs = zg.recs;
+    zf.recs_half = zg.recs_half;
     zf.missed = zg.missed;
+    zf.hint = hg.hint;
     zf.sinfo = zg.sinfo;
     zf.list_g = zg.list_g;
     zf.list_f = zg.list_f;

@@ -466,7 +466,8 @@ struct ZGeom {
     const double* r;          // [sample][O_y][O_x][ncp_z][4]: displacement contracted over y and x (component padded to 4)
     const AxTab* zt;          // [O_z]: cubic weights / control-plane byte offsets (x 32) along z
     int* recs;                // [sample * ntiles + tile][8]: tile records, written by the geometry kernel
-    int* missed;              // [sample * nstrips + strip]: the fast kernel saw a window outside its sampled box
+    int* recs_half;           // [tile][2][8]: records of the z halves of the tiles whose whole box does not fit LDS
+    int* missed;              // [sample * nstrips + strip]: a tile kernel saw a window outside its sampled box
     long long* steps;         // [nsteps][2]: element offsets (volume, image) of every index of the step axes
     int* sinfo;               // [sample * nstrips + strip]: 3 bits per tile of the strip (class, beyond the standard box)
     // work lists of strips: G = general tiles (geometry kernel), F = tiles that do not fit (geometry kernel) or a window

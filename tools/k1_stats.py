@@ -33,9 +33,9 @@ y = ed.deform_grid(X, disp, order=order, mode=mode, prefilter=False)
 torch.cuda.synchronize()
 L.edhip_debug_k1_stats(st)
 L.edhip_debug_k1z_stats(sz)
-if sz[3] + sz[4] + sz[5]:
-    print("n=%d order=%d sigma=%g ncp=%d %s (k1z): class-A tiles %d, general %d, unfit %d; strips flagged by the fast kernel %d, rest "
-          "workgroups with work %d, waves in the fix-up for a miss %d, voxels redone %d, unfit voxels %d"
-          % (n, order, sigma, ncp, mode, sz[3], sz[4], sz[5], sz[6], sz[7], sz[0], sz[1], sz[2]))
+if sz[3] + sz[4] + sz[5] + sz[6]:
+    print("n=%d order=%d sigma=%g ncp=%d %s (k1z): class-A tiles %d, general %d, taken as two z halves %d, unfit %d; strips on the "
+          "general kernel's list %d, waves in the fix-up for a miss %d, voxels redone %d, unfit voxels %d"
+          % (n, order, sigma, ncp, mode, sz[3], sz[4], sz[6], sz[5], sz[7], sz[0], sz[1], sz[2]))
 print("n=%d order=%d sigma=%g ncp=%d %s: fast tiles %d, general %d, unfit %d; waves with a miss %d, voxels redone %d, unfit voxels %d"
       % (n, order, sigma, ncp, mode, st[3], st[4], st[5], st[0], st[1], st[2]))
