@@ -174,6 +174,19 @@ __device__ __forceinline__ void zaxis_entry(const GridGeom& g, int a, int oi, do
         idx[l] = edge ? mirror_i32((int)start + l, (int)g.ncp[a]) : (int)start + l;
 }
 
+// What general coordinates, the mirror-mapped staging paths and the fix-up read on top of ZFast: written to the workspace
+// by the geometry kernel and read from there on demand (constant address space: scalar loads where they are used) -- as
+// a by-value kernel argument its 30 doubles were preloaded into scalar registers and spilled (150 SGPR spills).
+struct ZGen {
+    int in_len[3], out_len[3], off[3];
+    int mode;
+    float cval;
+    int* hint;                // spill feedback: tiles that do not fit the standard box
+    double period[3], inv_period[3];
+    double aff[12], offd[3];  // the affine map as the general kernels apply it (crop offset added per voxel)
+};
+typedef const __attribute__((address_space(4))) ZGen* czgen_p;
+
 constexpr int kGeoBlock = 256;            // (4 waves: the records of a column's tiles are a latency chain per tile)
 constexpr int kGeoWaves = kGeoBlock / 64;
 // ================================================================================================
@@ -277,6 +290,22 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
             zg.steps[2 * ss] = vol_off;
             zg.steps[2 * ss + 1] = img_off;
         }
+    }
+    if (blockIdx.x == 0 && sample == 0 && tid == 0) {
+        ZGen* zn = reinterpret_cast<ZGen*>(zg.zgen);
+        for (int h = 0; h < 3; ++h) {
+            zn->in_len[h] = hg.in_len[h];
+            zn->out_len[h] = hg.out_len[h];
+            zn->off[h] = hg.off[h];
+            zn->period[h] = hg.period[h];
+            zn->inv_period[h] = hg.inv_period[h];
+            zn->offd[h] = (double)hg.off[h];
+        }
+        for (int k = 0; k < 12; ++k)
+            zn->aff[k] = hg.affine[k];
+        zn->mode = hg.mode;
+        zn->cval = hg.cval;
+        zn->hint = hg.hint;
     }
     if (blockIdx.x == 0 && sample == 0) {
         AxTab* zt = const_cast<AxTab*>(zg.zt);
@@ -905,27 +934,16 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_fast_kernel(const ZFast a)
 }
 
 // ---- everything else ---------------------------------------------------------------------------------------------
-// Second argument block of the rest kernel: what general coordinates, the mirror-mapped staging paths and the fix-up
-// read on top of ZFast.
-struct ZGen {
-    int in_len[3], out_len[3], off[3];
-    int mode;
-    float cval;
-    int* hint;                // spill feedback: tiles that do not fit the standard box
-    double period[3], inv_period[3];
-    double aff[12], offd[3];  // the affine map as the general kernels apply it (crop offset added per voxel)
-};
-
 // general coordinates of one voxel (deform.c:771-824): the arithmetic every tile kernel shares (ed_tile.h)
 template <int ORDER, bool AFFINE>
-__device__ __forceinline__ bool k1z_coords(const ZGen& zn, const double (&d)[3], const int (&b)[3], const double (&P)[3], int* start,
+__device__ __forceinline__ bool k1z_coords(czgen_p zn, const double (&d)[3], const int (&b)[3], const double (&P)[3], int* start,
                                            float* frac, int* raw_start = nullptr)
 {
     int ci[3];
     bool inr[3];
 #pragma unroll
     for (int h = 0; h < 3; ++h)
-        inr[h] = coord_axis_fast<ORDER, float>(AFFINE ? P[h] + d[h] : d[h], AFFINE ? 0 : b[h], zn.in_len[h], ci[h], frac[h]);
+        inr[h] = coord_axis_fast<ORDER, float>(AFFINE ? P[h] + d[h] : d[h], AFFINE ? 0 : b[h], zn->in_len[h], ci[h], frac[h]);
     if (raw_start) {
 #pragma unroll
         for (int h = 0; h < 3; ++h)
@@ -937,8 +955,8 @@ __device__ __forceinline__ bool k1z_coords(const ZGen& zn, const double (&d)[3],
 #pragma unroll
         for (int h = 0; h < 3; ++h) {
             if (!inr[h])
-                cst = coord_axis_mapped<ORDER, float>(AFFINE ? P[h] + d[h] : (double)b[h] + d[h], zn.in_len[h], zn.mode,
-                                                      zn.period[h], zn.inv_period[h], ci[h], frac[h]) || cst;
+                cst = coord_axis_mapped<ORDER, float>(AFFINE ? P[h] + d[h] : (double)b[h] + d[h], zn->in_len[h], zn->mode,
+                                                      zn->period[h], zn->inv_period[h], ci[h], frac[h]) || cst;
         }
     }
 #pragma unroll
@@ -953,7 +971,7 @@ __device__ __forceinline__ bool k1z_coords(const ZGen& zn, const double (&d)[3],
 // whose boxes are staged element by element -- overlap with the class-A work instead of trailing it.  Same walk, same R
 // and z table, same sums as the fast kernel: the same bits.
 template <int ORDER, bool AFFINE, bool OUT16, bool STEPS>
-__global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const ZGen zn)
+__global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, czgen_p zn)
 {
     constexpr int NT = ORDER + 1;
     constexpr int kPadX = NT & 1;
@@ -1008,7 +1026,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
         double Pyx[3];
 #pragma unroll
         for (int h = 0; h < 3; ++h)
-            Pyx[h] = AFFINE ? fma(zn.aff[h * 4 + 2], (double)ox, fma(zn.aff[h * 4 + 1], (double)oy, zn.aff[h * 4 + 3] + zn.offd[h])) : 0.0;
+            Pyx[h] = AFFINE ? fma(zn->aff[h * 4 + 2], (double)ox, fma(zn->aff[h * 4 + 1], (double)oy, zn->aff[h * 4 + 3] + zn->offd[h])) : 0.0;
         ZTaps tp;
         tp.key[0] = tp.key[1] = tp.key[2] = tp.key[3] = -1;
         // ---- staging: the source box of a tile into LDS, two copies, the second shifted by one element ----------
@@ -1026,11 +1044,11 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
                 // (deform.c:791-813), applied to the plane / row index
                 const float* g0 = src + (rc.b0x + 4 * q);
                 for (int zrow = wave; zrow < rc.ez; zrow += 4) {
-                    const float* gp = g0 + (long long)mirror_i32(rc.b0z + zrow, zn.in_len[0]) * vol_sz;
+                    const float* gp = g0 + (long long)mirror_i32(rc.b0z + zrow, zn->in_len[0]) * vol_sz;
                     const int lrow0 = zrow * by;
                     for (int y0 = 0; y0 < by; y0 += RW) {
                         if (lr < RW && y0 + lr < by) {
-                            const float* g = gp + (long long)mirror_i32(rc.b0y + y0 + lr, zn.in_len[1]) * vol_sy;
+                            const float* g = gp + (long long)mirror_i32(rc.b0y + y0 + lr, zn->in_len[1]) * vol_sy;
                             zglds16(g, box0 + (lrow0 + y0) * pitch);
                             zglds16(g + 1, box1 + (lrow0 + y0) * pitch);
                         }
@@ -1042,29 +1060,29 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
                 const int nrows = rc.ez * rc.ey;
                 const float inv_by = __frcp_rn((float)by);
                 const int sub = tid & 7;
-                // (four rows of a thread in flight: one row at a time every load waited for the one before -- the boxes of
+                // (two rows = four loads of a thread in flight: one element at a time every load waited for the one before -- the boxes of
                 // the columns on the x faces took ~10 us each)
-                for (int rb = tid >> 3; rb < nrows; rb += 4 * (kBlock / 8)) {
+                for (int rb = tid >> 3; rb < nrows; rb += 2 * (kBlock / 8)) {
                     for (int x0 = sub; x0 < rc.ex; x0 += 16) {
-                        float val[4][2];
+                        float val[2][2];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < 2; ++u) {
                             // (addresses clamped instead of loads predicated: a predicated load lands in a basic block
                             // of its own and is waited for right there)
                             const int r = min(rb + u * (kBlock / 8), nrows - 1);
                             const int zrow = (int)(((float)r + 0.5f) * inv_by), yr = r - zrow * by;
-                            const int zs = mirror_i32(rc.b0z + zrow, zn.in_len[0]);
-                            const int ys = mirror_i32(rc.b0y + yr, zn.in_len[1]);
+                            const int zs = mirror_i32(rc.b0z + zrow, zn->in_len[0]);
+                            const int ys = mirror_i32(rc.b0y + yr, zn->in_len[1]);
                             const float* rowp = src + (zs * vol_sz + ys * vol_sy);
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 const int xi = min(x0 + 8 * j, rc.ex - 1);
-                                const int xs = mirror_i32(rc.b0x + xi, zn.in_len[2]);
+                                const int xs = mirror_i32(rc.b0x + xi, zn->in_len[2]);
                                 val[u][j] = rowp[xs];
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < 2; ++u) {
                             const int r = rb + u * (kBlock / 8);
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
@@ -1092,19 +1110,19 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
                     continue;               // (a half of a split tile: the other voxel belongs to the other half)
                 const int oz = (sp.tz0 + t) * kT + wave + 4 * i;
                 double zw[4];
-                k1z_slice(zt, rcol, min(oz, zn.out_len[0] - 1), tp, zw);
+                k1z_slice(zt, rcol, min(oz, zn->out_len[0] - 1), tp, zw);
                 double d[3];
                 k1z_disp(tp, zw, d);
-                const int b[3] = {oz + zn.off[0], oy + zn.off[1], ox + zn.off[2]};
+                const int b[3] = {oz + zn->off[0], oy + zn->off[1], ox + zn->off[2]};
                 double P[3] = {0.0, 0.0, 0.0};
                 if (AFFINE) {
 #pragma unroll
                     for (int h = 0; h < 3; ++h)
-                        P[h] = fma(zn.aff[h * 4 + 0], (double)oz, Pyx[h]);
+                        P[h] = fma(zn->aff[h * 4 + 0], (double)oz, Pyx[h]);
                 }
                 int start[3];
                 const bool cst = k1z_coords<ORDER, AFFINE>(zn, d, b, P, start, vs.frac[i]);
-                const bool valid = oz < zn.out_len[0] && oy < zn.out_len[1] && ox < zn.out_len[2];
+                const bool valid = oz < zn->out_len[0] && oy < zn->out_len[1] && ox < zn->out_len[2];
                 const int rz = start[0] - rc.b0z, ry = start[1] - rc.b0y, rx = start[2] - rc.b0x;
                 // (a general tile without a box -- every sample maps to the constant: a voxel that does not is redone)
                 if (valid && !cst)
@@ -1159,7 +1177,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
                     for (int i = 0; i < 2; ++i) {
                         if (!(cur.flg & (4 << i)))
                             continue;
-                        float val = zn.cval;
+                        float val = zn->cval;
                         if (cur.flg & (1 << i))
                             val = k1z_voxel<ORDER>(smem, cur.addr[i], cur.frac[i], rc.pitch, rc.plane);
                         zstore_out<OUT16>(img, (STEPS ? steps[2 * ss + 1] : 0) + ozoff + (long long)(4 * i) * img_sz, val, io16);
@@ -1188,7 +1206,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, const
 // accumulation x, y, z as chains of fused multiply-adds from zero: the bits of the tile loops.  Per wave, no barriers,
 // no LDS.
 template <int ORDER, bool AFFINE, bool OUT16, bool STEPS>
-__global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, const ZGen zn)
+__global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, czgen_p zn)
 {
     constexpr int NT = ORDER + 1;
     constexpr int kPadX = NT & 1;
@@ -1236,7 +1254,7 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, const ZG
         double Pyx[3];
 #pragma unroll
         for (int h = 0; h < 3; ++h)
-            Pyx[h] = AFFINE ? fma(zn.aff[h * 4 + 2], (double)ox, fma(zn.aff[h * 4 + 1], (double)oy, zn.aff[h * 4 + 3] + zn.offd[h])) : 0.0;
+            Pyx[h] = AFFINE ? fma(zn->aff[h * 4 + 2], (double)ox, fma(zn->aff[h * 4 + 1], (double)oy, zn->aff[h * 4 + 3] + zn->offd[h])) : 0.0;
         ZTaps tp;
         tp.key[0] = tp.key[1] = tp.key[2] = tp.key[3] = -1;
         {
@@ -1254,20 +1272,20 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, const ZG
                     // (a split tile's voxel i worked with the box of half i)
                     const ZRecU rc = zrec_load(split ? rech0 + ((size_t)ti * tile_step * 2 + i) : rec0 + (size_t)ti * tile_step);
                     const int oz = (sp.tz0 + ti) * kT + wave + 4 * i;
-                    if (oz >= zn.out_len[0])
+                    if (oz >= zn->out_len[0])
                         continue;                   // (uniform)
                     double zw[4];
                     k1z_slice(zt, rcol, oz, tp, zw);
-                    if (oy >= zn.out_len[1] || ox >= zn.out_len[2])
+                    if (oy >= zn->out_len[1] || ox >= zn->out_len[2])
                         continue;
                     double d[3];
                     k1z_disp(tp, zw, d);
-                    const int b[3] = {oz + zn.off[0], oy + zn.off[1], ox + zn.off[2]};
+                    const int b[3] = {oz + zn->off[0], oy + zn->off[1], ox + zn->off[2]};
                     double P[3] = {0.0, 0.0, 0.0};
                     if (AFFINE) {
 #pragma unroll
                         for (int h = 0; h < 3; ++h)
-                            P[h] = fma(zn.aff[h * 4 + 0], (double)oz, Pyx[h]);
+                            P[h] = fma(zn->aff[h * 4 + 0], (double)oz, Pyx[h]);
                     }
                     int st[3], raw[3];
                     float fr[3];
@@ -1294,12 +1312,12 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, const ZG
                         const int stride = h == 0 ? vol_sz : (h == 1 ? vol_sy : 1);
 #pragma unroll
                         for (int l = 0; l < NT; ++l)
-                            tap[h][l] = mirror_i32(st[h] + l, zn.in_len[h]) * stride;
+                            tap[h][l] = mirror_i32(st[h] + l, zn->in_len[h]) * stride;
                     }
                     const long long ooff = (long long)oz * img_sz + obase;
                     ZSTAT(whole ? 2 : 1, 1);
                     for (int ss = 0; ss < nsteps; ++ss) {
-                        float val = zn.cval;
+                        float val = zn->cval;
                         if (!cst) {
                             const float* src = vol + (STEPS ? steps[2 * ss] : 0);
                             float a0 = 0.f;
@@ -1328,7 +1346,7 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, const ZG
 }
 
 template <int ORDER, bool AFFINE, bool OUT16, bool STEPS>
-hipError_t launch_k1z_kernels(const ZFast& zf, const ZGen& zn, unsigned ngen, unsigned nfix, size_t lds, hipStream_t stream, SideLane* side)
+hipError_t launch_k1z_kernels(const ZFast& zf, const void* znp, unsigned ngen, unsigned nfix, size_t lds, hipStream_t stream, SideLane* side)
 {
     const unsigned nfast = k1z_grid(zf.total_strips, zf.deal);
     // the general tiles next to the class-A tiles: fork a second stream behind the geometry kernel, join it in front of
@@ -1342,7 +1360,7 @@ hipError_t launch_k1z_kernels(const ZFast& zf, const ZGen& zn, unsigned ngen, un
     } else {
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL((k1z_gen_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(ngen), dim3(kBlock), lds, sg, zf, zn);
+    hipLaunchKernelGGL((k1z_gen_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(ngen), dim3(kBlock), lds, sg, zf, (czgen_p)znp);
     hipError_t e = hipGetLastError();
     if (forked) {
         const hipError_t e2 = hipEventRecord(side->join, sg);
@@ -1357,18 +1375,18 @@ hipError_t launch_k1z_kernels(const ZFast& zf, const ZGen& zn, unsigned ngen, un
     }
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL((k1z_fix_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(nfix), dim3(kBlock), 0, stream, zf, zn);
+    hipLaunchKernelGGL((k1z_fix_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(nfix), dim3(kBlock), 0, stream, zf, (czgen_p)znp);
     return hipGetLastError();
 }
 template <int ORDER, bool AFFINE, bool OUT16>
-hipError_t launch_k1z_variant(const ZFast& zf, const ZGen& zn, unsigned ngen, unsigned nfix, size_t lds, hipStream_t stream, SideLane* side,
+hipError_t launch_k1z_variant(const ZFast& zf, const void* zn, unsigned ngen, unsigned nfix, size_t lds, hipStream_t stream, SideLane* side,
                               bool steps)
 {
     return steps ? launch_k1z_kernels<ORDER, AFFINE, OUT16, true>(zf, zn, ngen, nfix, lds, stream, side)
                  : launch_k1z_kernels<ORDER, AFFINE, OUT16, false>(zf, zn, ngen, nfix, lds, stream, side);
 }
 template <int ORDER>
-hipError_t launch_k1z_order(const HotGeom& hg, const ZFast& zf, const ZGen& zn, unsigned ngen, unsigned nfix, size_t lds, hipStream_t stream,
+hipError_t launch_k1z_order(const HotGeom& hg, const ZFast& zf, const void* zn, unsigned ngen, unsigned nfix, size_t lds, hipStream_t stream,
                             SideLane* side)
 {
     const bool steps = hg.nstep != 0;
@@ -1472,21 +1490,7 @@ hipError_t launch_k1z(const HotGeom& hg, const ZGeom& zg, int order, size_t lds,
             zf.aff[h * 4 + k] = hg.affine[h * 4 + k];
         zf.aff[h * 4 + 3] = hg.affine[h * 4 + 3] + (double)hg.off[h];
     }
-    ZGen zn;
-    memset(&zn, 0, sizeof(zn));
-    for (int h = 0; h < 3; ++h) {
-        zn.in_len[h] = hg.in_len[h];
-        zn.out_len[h] = hg.out_len[h];
-        zn.off[h] = hg.off[h];
-        zn.period[h] = hg.period[h];
-        zn.inv_period[h] = hg.inv_period[h];
-        zn.offd[h] = (double)hg.off[h];
-    }
-    for (int k = 0; k < 12; ++k)
-        zn.aff[k] = hg.affine[k];
-    zn.mode = hg.mode;
-    zn.cval = hg.cval;
-    zn.hint = hg.hint;
+    const void* zn = zg.zgen;
     // persistent grids: the general tiles' list is worked off by up to 5 workgroups per CU; the fix-up list is empty on
     // a mild field (a launch of idle workgroups: ~2 us)
     const unsigned ngen = (unsigned)(zg.total_strips < 1280 ? ((zg.total_strips + 7) / 8) * 8 : 1280);

@@ -1164,7 +1164,7 @@ inline size_t k1z_extra_bytes(const GridGeom& g, int64_t ntiles, int nbatch)
     // (+ the strip summaries and the two work lists: one int per strip each)
     // (the lists are dealt per XCD, entry k of XCD x at slot 8 k + x: 8 slots per strip each, in case one XCD gets them all)
     // (+ 64 bytes per tile: the records of the two z halves)
-    return k1z_supported(g) ? k1z_zt_bytes(g) + (((size_t)ntiles * (size_t)nbatch * 168 + 63) & ~(size_t)63) + kK1zMaxSteps * 16 : 0;
+    return k1z_supported(g) ? k1z_zt_bytes(g) + (((size_t)ntiles * (size_t)nbatch * 168 + 63) & ~(size_t)63) + kK1zMaxSteps * 16 + 512 : 0;
 }
 
 // ================================================================================================
@@ -1723,6 +1723,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     zg.list_f = zg.list_g + (size_t)ntiles * nb * 8;
                     zg.recs_half = zg.list_f + (size_t)ntiles * nb * 8;
                     zg.steps = (long long*)(zx + k1z_zt_bytes(g) + (((size_t)ntiles * nb * 168 + 63) & ~(size_t)63));
+                    zg.zgen = (char*)zg.steps + kK1zMaxSteps * 16;
                     // the lists' counters: 32 ints in the (cleared) tail of the workspace head, in front of the hint words
                     zg.ctl = (int*)((char*)ws - 512);
                     zside = side_lane(stream);

@@ -477,6 +477,7 @@ struct ZGeom {
     int* list_f;
     int* ctl;
     int parity;
+    void* zgen;               // 512 bytes: the uniform values of the general paths (ZGen), written by the geometry kernel
     long long r_bstride;      // doubles between consecutive samples of r
     long long disp_bstride;   // bytes between the control grids of consecutive samples
     int ncpz;
