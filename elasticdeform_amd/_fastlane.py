@@ -229,6 +229,12 @@ class Lane(object):
                         if st:
                             _lib.raise_for_status(st, ebuf)
             else:
+                res = []
+                for i in range(self.n):
+                    o = torch.empty(self.shapes[i], dtype=self.dtypes[i], device=self.dev)
+                    self.outs[i].data = o.data_ptr()
+                    res.append(o)
+                bflag = dgm._box_flag_forward(displacement, displacement, self.dev, stream)
                 for i, f in enumerate(self.filters):
                     x = xs[i]
                     if f is not None:
@@ -237,12 +243,6 @@ class Lane(object):
                             _lib.raise_for_status(st, ebuf)
                         keep.append(x)
                     self.ins[i].data = x.data_ptr()
-                res = []
-                for i in range(self.n):
-                    o = torch.empty(self.shapes[i], dtype=self.dtypes[i], device=self.dev)
-                    self.outs[i].data = o.data_ptr()
-                    res.append(o)
-                bflag = dgm._box_flag_forward(displacement, displacement, self.dev, stream)
                 st = L.edhip_deform(0, self.n, self.ins, ctypes.byref(self.disp), a.off, self.outs, a.naxis,
                                     a.axis, a.orders, a.modes, a.cvals, a.aff, self.flags | bflag, stream,
                                     ebuf, 256)

@@ -122,27 +122,6 @@ __device__ __forceinline__ void zrow_box(int (&lo)[3], int (&hi)[3])
                  ED_RED6("row_mirror row_mask:0xf bank_mask:0xf")
                  : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
 }
-// The four rows are the four sampled z slices of a tile (0, 2, 4, 7): ranges of the whole tile, of its low half
-// (slices 0-3: the samples at 0, 2 and 4 -- the sample at 4 bounds slice 3 by interpolation) and of its high half
-// (slices 4-7: the samples at 4 and 7).  part 0 whole, 1 low, 2 high; scalar results.
-__device__ __forceinline__ void zparts(const int (&lo)[3], const int (&hi)[3], int (&plo)[3][3], int (&phi)[3][3])
-{
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {
-        int l[4], u[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            l[r] = __builtin_amdgcn_readlane(lo[h], 16 * r);
-            u[r] = __builtin_amdgcn_readlane(hi[h], 16 * r);
-        }
-        plo[1][h] = min(min(l[0], l[1]), l[2]);
-        phi[1][h] = max(max(u[0], u[1]), u[2]);
-        plo[2][h] = min(l[2], l[3]);
-        phi[2][h] = max(u[2], u[3]);
-        plo[0][h] = min(plo[1][h], l[3]);
-        phi[0][h] = max(phi[1][h], u[3]);
-    }
-}
 #undef ED_RED6
 __device__ __forceinline__ int zuni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ void zlds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -211,8 +190,8 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
     double* sMax = reinterpret_cast<double*>(sAx + 16);       // [3][waves] partial maxima
     AxTab* sZ = reinterpret_cast<AxTab*>(sMax + 3 * kGeoWaves);
     int* sCls = reinterpret_cast<int*>(sZ + 4 * hg.tiles[0]);        // [tiles_z]: class of every tile of the column
-    int* sBox = sCls + hg.tiles[0];                                  // [tiles_z][3 parts][16]: reduced sample ranges
-    int* sCnt = sBox + 48 * hg.tiles[0];                             // [4]          // [tiles_z][4]: z entries of the sampled slices
+    int* sBox = sCls + hg.tiles[0];                                  // [tiles_z][raw | mapped][4 sampled slices][8]: sample ranges
+    int* sCnt = sBox + 64 * hg.tiles[0];                             // [4]          // [tiles_z][4]: z entries of the sampled slices
     const int ty = blockIdx.x / hg.tiles[2], tx = blockIdx.x - ty * hg.tiles[2];
     if (ED_DBG(hg.dbg, 1 << 23))
         return;
@@ -390,15 +369,25 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
             lo[h] = (int)floor(cr - slack[h]);
             hi[h] = (int)floor(cr + slack[h]);
         }
-        zrow_box(lo, hi);
-        int rlo[3][3], rhi[3][3];          // [part][axis]: raw ranges
-        zparts(lo, hi, rlo, rhi);
         // fast: a full tile whose every coordinate, margin included, is one coord_axis_fast accepts
-        bool fast = nz == kT && ny == kT && nx == kT;
+        bool out_of_fast = false;
 #pragma unroll
         for (int h = 0; h < 3; ++h)
-            fast = fast && rlo[0][h] >= ((order & 1) ? 0 : 1) && rhi[0][h] <= hg.in_len[h] - 2;
-        int mlo[3][3], mhi[3][3];          // mapped ranges (general tiles)
+            out_of_fast = out_of_fast || lo[h] < ((order & 1) ? 0 : 1) || hi[h] > hg.in_len[h] - 2;
+        const bool fast = nz == kT && ny == kT && nx == kT && !__any(out_of_fast);
+        // every lane of a row of 16 holds the row's range = the range of one sampled z slice; the thread that derives
+        // the tile's record combines the slices (whole tile, low half, high half)
+        zrow_box(lo, hi);
+        int* dst = sBox + (tz * 8 + (lane >> 4)) * 8;
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                dst[h] = lo[h];
+                dst[4 + h] = hi[h];
+            }
+        }
+        if (lane == 0)
+            dst[3] = fast ? 1 : 0;
         if (!fast) {
             // general tile: the range of the MAPPED coordinate over the samples (a sample that maps to the constant has
             // no window); where the raw range straddles an end of the array, the end itself is included below
@@ -421,20 +410,12 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
                 }
             }
             zrow_box(lo, hi);
-            zparts(lo, hi, mlo, mhi);
-        }
-        if (lane == 63) {
-#pragma unroll
-            for (int part = 0; part < 3; ++part) {
-                int* dst = sBox + (tz * 3 + part) * 16;
+            if ((lane & 15) == 0) {
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
-                    dst[h] = fast ? rlo[part][h] : mlo[part][h];
-                    dst[4 + h] = fast ? rhi[part][h] : mhi[part][h];
-                    dst[8 + h] = rlo[part][h];
-                    dst[12 + h] = rhi[part][h];
+                    dst[32 + h] = lo[h];
+                    dst[36 + h] = hi[h];
                 }
-                dst[3] = fast ? 1 : 0;
             }
         }
     }
@@ -450,14 +431,22 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
         // tile's box does not fit LDS
 #pragma unroll 1
         for (int part = 0; part < 3; ++part) {
-            const int* sb = sBox + (tz * 3 + part) * 16;
+            // rows = the sampled z slices 0, 2, 4, 7: the whole tile; its low half (slices 0-3: the samples at 0, 2 and 4 --
+            // the sample at 4 bounds slice 3 by interpolation); its high half (slices 4-7: the samples at 4 and 7)
+            const int* sb = sBox + tz * 64;
             const bool fast = sb[3] != 0;
+            const int r0 = part == 2 ? 2 : 0, r1 = part == 1 ? 2 : 3;
             int blo[3], bhi[3];
             bool any = true;
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                int lo = sb[h], hi = sb[4 + h];
-                const int rlo = sb[8 + h], rhi = sb[12 + h];
+                int rlo = 0x7fffffff, rhi = (int)0x80000000, lo = 0x7fffffff, hi = (int)0x80000000;
+                for (int r = r0; r <= r1; ++r) {
+                    rlo = min(rlo, sb[r * 8 + h]);
+                    rhi = max(rhi, sb[r * 8 + 4 + h]);
+                    lo = min(lo, sb[(fast ? 0 : 32) + r * 8 + h]);
+                    hi = max(hi, sb[(fast ? 0 : 32) + r * 8 + 4 + h]);
+                }
                 if (!fast) {
                     any = any && hi >= lo;
                     // the lowest / highest floor a coordinate that stays in (or is folded / clamped back into) the array
@@ -1416,7 +1405,7 @@ size_t k1z_lds_bytes(int* box_cap, bool large)
 size_t k1z_geo_lds_bytes(const GridGeom& g, const HotGeom& hg)
 {
     const size_t ngrid = 3 * (size_t)g.ncp[0] * (size_t)g.ncp[1] * (size_t)g.ncp[2];
-    return 8 * ngrid + 8 * 64 * 3 * (size_t)g.ncp[0] + 16 * sizeof(AxTab) + 3 * kGeoWaves * 8 + (sizeof(AxTab) * 4 + 4 + 192) * (size_t)hg.tiles[0] + 16;
+    return 8 * ngrid + 8 * 64 * 3 * (size_t)g.ncp[0] + 16 * sizeof(AxTab) + 3 * kGeoWaves * 8 + (sizeof(AxTab) * 4 + 4 + 256) * (size_t)hg.tiles[0] + 16;
 }
 
 size_t k1z_r_bytes(const GridGeom& g) { return 8 * (size_t)g.out_len[1] * (size_t)g.out_len[2] * 4 * (size_t)g.ncp[0]; }
@@ -1426,7 +1415,7 @@ bool k1z_supported(const GridGeom& g)
     const size_t ngrid = 3 * (size_t)g.ncp[0] * (size_t)g.ncp[1] * (size_t)g.ncp[2];
     const size_t tiles_z = (size_t)((g.out_len[0] + kT - 1) / kT);
     return ngrid <= 4096 && g.ncp[0] <= 16 &&
-           8 * ngrid + 8 * 64 * 3 * (size_t)g.ncp[0] + 16 * sizeof(AxTab) + 3 * kGeoWaves * 8 + (sizeof(AxTab) * 4 + 4 + 192) * tiles_z + 16 <= 60 * 1024;
+           8 * ngrid + 8 * 64 * 3 * (size_t)g.ncp[0] + 16 * sizeof(AxTab) + 3 * kGeoWaves * 8 + (sizeof(AxTab) * 4 + 4 + 256) * tiles_z + 16 <= 60 * 1024;
 }
 
 hipError_t launch_k1z_geo(const GridGeom& g, const HotGeom& hg, const ZGeom& zg, const GridPrefilter& gp, int nbatch,

@@ -1149,22 +1149,18 @@ inline size_t q_global_bytes(const GridGeom& g, bool wide_opt = false)
         const size_t per_strip = strips * (size_t)wide_window(g);
         cols = per_strip > cols ? per_strip : cols;
     }
-    const size_t q = 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 4 * cols;
-    // (the forward route of deform_k1z.hip keeps R[o_y][o_x][ncp_z][4] in the same region instead: one of the two
-    // tables per call)
-    const size_t r = k1z_supported(g) ? k1z_r_bytes(g) : 0;
-    return q > r ? q : r;
+    return 8 * (size_t)g.out_len[0] * (size_t)g.out_len[1] * 4 * cols;
 }
-// z table + tile records of deform_k1z.hip, behind the label list
+// The geometry buffer of the forward route of deform_k1z.hip (SideLane::geo_ptr, its own allocation):
+//   counters (4 KiB, cleared at allocation) | ZGen (512) | z table | tile records (32 bytes per tile), flags and summaries
+//   (4 + 4 per strip, at most one strip per tile), two work lists dealt per XCD (entry k of XCD x at slot 8 k + x: 32 + 32
+//   per strip, in case one XCD gets them all), records of the tiles' z halves (64) | step offsets | R
 constexpr size_t kK1zMaxSteps = 4096;
 inline size_t k1z_zt_bytes(const GridGeom& g) { return (sizeof(AxTab) * (size_t)g.out_len[0] + 63) & ~(size_t)63; }
-inline size_t k1z_extra_bytes(const GridGeom& g, int64_t ntiles, int nbatch)
+inline size_t k1z_geo_bytes(const GridGeom& g, int64_t ntiles, int nbatch)
 {
-    // z table | tile records (32 bytes each) | one flag per strip (at most one strip per tile) | step offsets
-    // (+ the strip summaries and the two work lists: one int per strip each)
-    // (the lists are dealt per XCD, entry k of XCD x at slot 8 k + x: 8 slots per strip each, in case one XCD gets them all)
-    // (+ 64 bytes per tile: the records of the two z halves)
-    return k1z_supported(g) ? k1z_zt_bytes(g) + (((size_t)ntiles * (size_t)nbatch * 168 + 63) & ~(size_t)63) + kK1zMaxSteps * 16 + 512 : 0;
+    return 4096 + 512 + k1z_zt_bytes(g) + (((size_t)ntiles * (size_t)nbatch * 168 + 63) & ~(size_t)63) + kK1zMaxSteps * 16 +
+           ((k1z_r_bytes(g) * (size_t)nbatch + 63) & ~(size_t)63);
 }
 
 // ================================================================================================
@@ -1442,7 +1438,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // (edhip_deform reserved deform_tile_workspace_bytes() up front, so this does not move the
     // prefiltered control grid that may sit in the head of the workspace)
     void* ws = workspace_reserve(stream, kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + q_all +
-                                             label_list_bytes(g) + k1z_extra_bytes(g, ntiles, nb), &e);
+                                             label_list_bytes(g), &e);
     if (!ws)
         return e;
     ws = (char*)ws + kWorkspaceGridBytes;
@@ -1712,9 +1708,13 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         r2 += r * r;
                     }
                     zg.slack_scale = 0.15 * 1.125 * 4.0 * r2;
-                    zg.r = tg.q_global;
-                    zg.r_bstride = tg.q_bstride;
-                    char* zx = (char*)ws + 2 * list_bytes + xt_bytes + q_all + label_list_bytes(g);
+                    zside = side_lane(stream);
+                    char* gb = zside ? (char*)geo_reserve(stream, zside, k1z_geo_bytes(g, ntiles, nb), &e) : nullptr;
+                    if (!gb)
+                        return e != hipSuccess ? e : hipErrorOutOfMemory;
+                    zg.ctl = (int*)gb;                       // the lists' counters: 32 ints in the cleared head
+                    zg.zgen = gb + 4096;
+                    char* zx = gb + 4096 + 512;
                     zg.zt = (const AxTab*)zx;
                     zg.recs = (int*)(zx + k1z_zt_bytes(g));
                     zg.missed = zg.recs + (size_t)ntiles * nb * 8;
@@ -1723,11 +1723,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     zg.list_f = zg.list_g + (size_t)ntiles * nb * 8;
                     zg.recs_half = zg.list_f + (size_t)ntiles * nb * 8;
                     zg.steps = (long long*)(zx + k1z_zt_bytes(g) + (((size_t)ntiles * nb * 168 + 63) & ~(size_t)63));
-                    zg.zgen = (char*)zg.steps + kK1zMaxSteps * 16;
-                    // the lists' counters: 32 ints in the (cleared) tail of the workspace head, in front of the hint words
-                    zg.ctl = (int*)((char*)ws - 512);
-                    zside = side_lane(stream);
-                    zg.parity = zside ? (int)(zside->parity & 1) : 0;
+                    zg.r = (const double*)((char*)zg.steps + kK1zMaxSteps * 16);
+                    zg.r_bstride = (long long)(((k1z_r_bytes(g) + 63) & ~(size_t)63) / 8);
+                    zg.parity = (int)(zside->parity & 1);
                     zg.disp_bstride = tg.disp_bstride;
                     zg.ncpz = (int)g.ncp[0];
                     zg.order = ORDER;
@@ -1873,7 +1871,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     }
                 }
                 if (k1z && e == hipSuccess) {
-                    // the geometry kernel in place of the tables kernel: R, the z table, tile records (and boxes)
+                    // the geometry kernel in place of the tables kernel: R, the z table, tile records (and boxes), work lists
                     GridPrefilter gp;
                     memset(&gp, 0, sizeof(gp));
                     const bool own = batch && batch->gridpf && nb == 1 && batch->gridpf->total <= 4096;
@@ -1882,12 +1880,14 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                         gp.zero_ptr = nullptr;
                         gp.zero_bytes = 0;
                     }
-                    e = launch_k1z_geo(g, hg, zg, gp, nb, stream);
-                    if (e == hipSuccess && zside)
-                        ++zside->parity;       // (the launch is in the stream: the next call uses the other counters)
-                    if (own && e == hipSuccess)
-                        batch->gridpf_done = true;
-                    tables_done = true;
+                    if (!tables_done && e == hipSuccess) {
+                        e = launch_k1z_geo(g, hg, zg, gp, nb, stream);
+                        if (e == hipSuccess)
+                            ++zside->parity;       // (the launch is in the stream: the next call uses the other counters)
+                        if (own && e == hipSuccess)
+                            batch->gridpf_done = true;
+                        tables_done = true;
+                    }
                 } else
                     launch_tables();
                 if (rec_route && e == hipSuccess) {
@@ -2121,7 +2121,7 @@ size_t deform_tile_workspace_bytes(const GridGeom& g, int nbatch, bool f64)
     if (q > ((size_t)512 << 20))
         return kWorkspaceGridBytes;
     return kWorkspaceGridBytes + 2 * list_bytes + xt_bytes + ((q * (size_t)nbatch + 63) & ~(size_t)63) +
-           label_list_bytes(g) + k1z_extra_bytes(g, ntiles, nbatch);
+           label_list_bytes(g);
 }
 
 bool deform_tile_supported(const GridGeom& g, const IOView& v, int gradient)

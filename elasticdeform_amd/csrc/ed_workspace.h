@@ -74,8 +74,14 @@ struct SideLane {
     hipEvent_t fork = nullptr, join = nullptr;
     unsigned parity = 0;
     bool usable = false;
+    // the geometry stage's own buffer (tables, tile records, work lists + their counters): nothing else writes it
+    void* geo_ptr = nullptr;
+    size_t geo_cap = 0;
 };
 SideLane* side_lane(hipStream_t stream);
+// at least `bytes` of the lane's geometry buffer (grown on demand: both streams are drained first);
+// the first 4 KiB -- the work lists' counters -- are cleared when the buffer is allocated
+void* geo_reserve(hipStream_t stream, SideLane* lane, size_t bytes, hipError_t* err);
 
 // Drains the devices that own scratch and frees every cached buffer.
 void workspace_release_all();

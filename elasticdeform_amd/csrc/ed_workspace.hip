@@ -145,6 +145,8 @@ SideLane* side_lane(hipStream_t stream)
         sl.tried = true;
         hipStream_t s2 = nullptr;
         hipEvent_t e1 = nullptr, e2 = nullptr;
+        // (default priority: at the lowest one the general-tile kernel was starved until the class-A kernel had finished,
+        // 110 -> 167 us)
         if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) {
@@ -161,6 +163,45 @@ SideLane* side_lane(hipStream_t stream)
         }
     }
     return &sl.lane;
+}
+
+void* geo_reserve(hipStream_t stream, SideLane* lane, size_t bytes, hipError_t* err)
+{
+    *err = hipSuccess;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (lane->geo_ptr && lane->geo_cap >= bytes)
+        return lane->geo_ptr;
+    hipError_t e = hipSuccess;
+    if (lane->geo_ptr) {
+        // kernels of earlier calls (either stream) may still be using the old buffer
+        e = hipStreamSynchronize(stream);
+        if (e == hipSuccess && lane->stream)
+            e = hipStreamSynchronize(lane->stream);
+        if (e == hipSuccess)
+            e = hipFree(lane->geo_ptr);
+        lane->geo_ptr = nullptr;
+        lane->geo_cap = 0;
+        if (e != hipSuccess) {
+            *err = e;
+            return nullptr;
+        }
+    }
+    size_t want = bytes + bytes / 4;
+    want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    e = hipMalloc(&lane->geo_ptr, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        lane->geo_ptr = nullptr;
+        *err = e;
+        return nullptr;
+    }
+    lane->geo_cap = want;
+    e = hipMemsetAsync(lane->geo_ptr, 0, 4096, stream);
+    if (e != hipSuccess) {
+        *err = e;
+        return nullptr;
+    }
+    return lane->geo_ptr;
 }
 
 void* keep_reserve(hipStream_t stream, size_t bytes, KeepKey** key, hipError_t* err)
@@ -351,6 +392,15 @@ void workspace_release_all()
         kv.second.ptr = nullptr;
         kv.second.cap = 0;
         kv.second.key = KeepKey();       // (entries stay: callers may hold the key's address)
+    }
+    for (auto& kv : g_sides) {
+        if (kv.second.lane.geo_ptr && hipSetDevice(kv.first.first) == hipSuccess) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(kv.second.lane.geo_ptr);
+        }
+        kv.second.lane.geo_ptr = nullptr;
+        kv.second.lane.geo_cap = 0;
+        // (the second stream and its events stay)
     }
     for (auto& kv : g_hints) {
         if (kv.second.h.host && hipSetDevice(kv.first.first) == hipSuccess) {

@@ -297,7 +297,6 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
     StreamGuard guard(stream);      // the stream's scratch is ours until every launch is enqueued
     if (err && errlen)
         err[0] = 0;
-
     // ---- the checks of _deform_grid.c:121-255 -------------------------------------------------
     if (!inputs || !outputs || ninputs <= 0 || ninputs > EDHIP_MAX_INPUTS)
         return fail(err, errlen, EDHIP_ERR_INVALID, "invalid number of inputs/outputs");
