@@ -469,7 +469,9 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
 #pragma unroll
             for (int h = 0; h < 3; ++h)
                 ext[h] = (unsigned)bhi[h] - (unsigned)blo[h] + 1u;
-            const int pitch = ext[2] <= 16u ? 16 : (ext[2] <= 48u ? 48 : 0);
+            // floats per box row: 16 for the mild fields; 24 / 32 / 48 where the deformation stretches a tile along x
+            // (every pitch a multiple of 8 floats: the pairs of the shifted copy stay aligned)
+            const int pitch = ext[2] <= 16u ? 16 : (ext[2] <= 24u ? 24 : (ext[2] <= 32u ? 32 : (ext[2] <= 48u ? 48 : 0)));
             const bool sane = any && ext[0] < 1024u && ext[1] < 1024u;
             const int nrows = sane ? (int)(ext[0] * ext[1]) : 0;
             const bool fits = sane && pitch > 0 && nrows * pitch <= hg.box_cap;
@@ -677,7 +679,7 @@ __device__ __forceinline__ void k1z_disp(const ZTaps& tp, const double (&zw)[4],
 // 64-tap (order 3) separable gather of one voxel from the staged box (see deform_k1.hip: reads kept apart, aligned
 // 8-byte pairs from the copy that matches the window's parity)
 template <int ORDER, int PITCH>
-__device__ __forceinline__ float k1z_gather(const float* bp, int plane, const float* w0, const float* w1, const float* w2)
+__device__ __forceinline__ float k1z_gather(const float* bp, int plane, int pitch_rt, const float* w0, const float* w1, const float* w2)
 {
     constexpr int NT = ORDER + 1;
     constexpr int NTX = NT + (NT & 1);
@@ -688,7 +690,7 @@ __device__ __forceinline__ float k1z_gather(const float* bp, int plane, const fl
         float a1 = 0.f;
 #pragma unroll
         for (int l1 = 0; l1 < NT; ++l1) {
-            const float* rp = pp + l1 * PITCH;
+            const float* rp = pp + l1 * (PITCH ? PITCH : pitch_rt);
             float a2 = 0.f;
 #pragma unroll
             for (int l2 = 0; l2 < NTX; l2 += 2) {
@@ -720,7 +722,8 @@ __device__ __forceinline__ float k1z_voxel(const char* smem, int addr, const flo
     if (NT & 1)
         w2[NT] = 0.f;
     const float* bp = reinterpret_cast<const float*>(smem + addr);
-    return pitch == 16 ? k1z_gather<ORDER, 16>(bp, plane, w0, w1, w2) : k1z_gather<ORDER, 48>(bp, plane, w0, w1, w2);
+    // (PITCH 0: the row offsets of the rare wide boxes are computed, not immediates)
+    return pitch == 16 ? k1z_gather<ORDER, 16>(bp, plane, 16, w0, w1, w2) : k1z_gather<ORDER, 0>(bp, plane, pitch, w0, w1, w2);
 }
 
 // ---- class-A tiles ---------------------------------------------------------------------------------------------
@@ -807,7 +810,6 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_fast_kernel(const ZFast a)
     cdbl_p zt = (cdbl_p)(const void*)a.zt;
     // staging: lane -> (row of a plane, 16-byte chunk of the row); 16 rows of 64 bytes or 5 rows of 192 bytes per KiB
     const int lr16 = lane >> 2, q16 = lane & 3;
-    const int lr48 = (lane * 21846) >> 18, q48 = lane - lr48 * 12;      // lane / 12
 
     ZTaps tp;
     tp.key[0] = tp.key[1] = tp.key[2] = tp.key[3] = -1;
@@ -829,15 +831,18 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_fast_kernel(const ZFast a)
                 }
             }
         } else {
-            const float* g0 = src + (rc.goff + lr48 * vol_sy + 4 * q48);
+            // wider rows: 6 / 8 / 12 chunks of 16 bytes, 10 / 8 / 5 rows per wave-instruction
+            const int cpr = rc.pitch >> 2, RW = 64 / cpr;
+            const int lr = (lane * (65536 / cpr + 1)) >> 16, q = lane - lr * cpr;
+            const float* g0 = src + (rc.goff + lr * vol_sy + 4 * q);
             for (int zrow = wave; zrow < rc.ez; zrow += 4) {
                 const float* gp = g0 + zrow * vol_sz;
                 const int lrow0 = zrow * rc.ey;
-                for (int y0 = 0; y0 < rc.ey; y0 += 5) {
-                    if (lr48 < 5 && y0 + lr48 < rc.ey) {
+                for (int y0 = 0; y0 < rc.ey; y0 += RW) {
+                    if (lr < RW && y0 + lr < rc.ey) {
                         const float* g = gp + y0 * vol_sy;
-                        zglds16(g, box0 + (lrow0 + y0) * 48);
-                        zglds16(g + 1, box1 + (lrow0 + y0) * 48);
+                        zglds16(g, box0 + (lrow0 + y0) * rc.pitch);
+                        zglds16(g + 1, box1 + (lrow0 + y0) * rc.pitch);
                     }
                 }
             }
@@ -1025,10 +1030,8 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, czgen
                 return;
             const int by = rc.ey, pitch = rc.pitch;
             if (flags & kZDma) {
-                const bool p16 = pitch == 16;
-                const int RW = p16 ? 16 : 5;
-                const int lr = p16 ? lane >> 2 : (lane * 21846) >> 18;      // lane / 12
-                const int q = p16 ? lane & 3 : lane - lr * 12;
+                const int cpr = pitch >> 2, RW = 64 / cpr;                  // 16-byte chunks per row, rows per KiB
+                const int lr = (lane * (65536 / cpr + 1)) >> 16, q = lane - lr * cpr;      // lane / cpr
                 // planes / rows beyond the array's z / y ends: the mirror map of the reference's taps
                 // (deform.c:791-813), applied to the plane / row index
                 const float* g0 = src + (rc.b0x + 4 * q);
@@ -1249,7 +1252,9 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, czgen_p 
         {
             if (missed && lane == 0)
                 ZSTAT(0, 1);
-            for (int ti = 0; ti < ntile; ++ti) {
+            // (blockIdx.y = 2 * tile + voxel: a strip's fix-up is dealt to 2 * strip_tiles workgroups -- one workgroup
+            // walking a whole tile that does not fit, 128 dependent gathers per lane, took ~90 us, and there are few of them)
+            for (int ti = (int)(blockIdx.y >> 1); ti < ntile; ti += ntile) {
                 const int c4 = (sinfo >> (4 * ti)) & 7;
                 const int cls = c4 & 3;
                 const bool split = c4 == 7;
@@ -1257,7 +1262,7 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, czgen_p 
                 if (!whole && !missed)
                     continue;
 #pragma unroll 1
-                for (int i = 0; i < 2; ++i) {
+                for (int i = (int)(blockIdx.y & 1); i < 2; i += 2) {
                     // (a split tile's voxel i worked with the box of half i)
                     const ZRecU rc = zrec_load(split ? rech0 + ((size_t)ti * tile_step * 2 + i) : rec0 + (size_t)ti * tile_step);
                     const int oz = (sp.tz0 + ti) * kT + wave + 4 * i;
@@ -1364,7 +1369,7 @@ hipError_t launch_k1z_kernels(const ZFast& zf, const void* znp, unsigned ngen, u
     }
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL((k1z_fix_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(nfix), dim3(kBlock), 0, stream, zf, (czgen_p)znp);
+    hipLaunchKernelGGL((k1z_fix_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(nfix, 2 * zf.strip_tiles), dim3(kBlock), 0, stream, zf, (czgen_p)znp);
     return hipGetLastError();
 }
 template <int ORDER, bool AFFINE, bool OUT16>
@@ -1483,7 +1488,7 @@ hipError_t launch_k1z(const HotGeom& hg, const ZGeom& zg, int order, size_t lds,
     // persistent grids: the general tiles' list is worked off by up to 5 workgroups per CU; the fix-up list is empty on
     // a mild field (a launch of idle workgroups: ~2 us)
     const unsigned ngen = (unsigned)(zg.total_strips < 1280 ? ((zg.total_strips + 7) / 8) * 8 : 1280);
-    const unsigned nfix = (unsigned)(zg.total_strips < 1024 ? ((zg.total_strips + 7) / 8) * 8 : 1024);
+    const unsigned nfix = (unsigned)(zg.total_strips < 512 ? ((zg.total_strips + 7) / 8) * 8 : 512);
     switch (order) {
     case 1: return launch_k1z_order<1>(hg, zf, zn, ngen, nfix, lds, stream, side);
     case 2: return launch_k1z_order<2>(hg, zf, zn, ngen, nfix, lds, stream, side);
