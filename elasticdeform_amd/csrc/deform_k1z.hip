@@ -752,14 +752,14 @@ struct ZFast {
 };
 
 template <int ORDER, bool AFFINE, bool OUT16, bool STEPS>
-__global__ __launch_bounds__(kBlock, 4) void k1z_fast_kernel(const ZFast a)
+__device__ __forceinline__ void k1z_fast_body(const ZFast& a, const int vblock)
 {
     constexpr int NT = ORDER + 1;
     constexpr int kPadX = NT & 1;          // even orders read one zero-weight padding tap
     constexpr int NTX = NT + kPadX;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // the box pair, nothing else
     ZStrip sp;
-    if (!k1z_strip(a.total_strips, a.nstrips, a.tiles_z, a.tiles_y, a.tiles_x, a.strip_tiles, a.deal, sp, blockIdx.x))
+    if (!k1z_strip(a.total_strips, a.nstrips, a.tiles_z, a.tiles_y, a.tiles_x, a.strip_tiles, a.deal, sp, vblock))
         return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_fast_kernel(const ZFast a)
     if (__any(bad < 0) && lane == 0) {
         // the fix-up kernel redoes the voxels of this strip whose window is not inside the box
         if (atomicOr(a.missed + sp.id, 1) == 0) {
-            const int xcd = (int)(blockIdx.x & 7);
+            const int xcd = vblock & 7;
             a.list_f[(size_t)atomicAdd(a.ctl + zctl(a.parity, 1, xcd), 1) * 8 + xcd] = sp.id;
         }
     }
@@ -965,7 +965,7 @@ __device__ __forceinline__ bool k1z_coords(czgen_p zn, const double (&d)[3], con
 // whose boxes are staged element by element -- overlap with the class-A work instead of trailing it.  Same walk, same R
 // and z table, same sums as the fast kernel: the same bits.
 template <int ORDER, bool AFFINE, bool OUT16, bool STEPS>
-__global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, czgen_p zn)
+__device__ __forceinline__ void k1z_gen_body(const ZFast& a, czgen_p zn, const int vblock, const int ngen)
 {
     constexpr int NT = ORDER + 1;
     constexpr int kPadX = NT & 1;
@@ -975,9 +975,9 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, czgen
     const int lane = tid & 63;
     const int wave = zuni(tid >> 6);
     const int io16 = OUT16 ? a.io16 : 0;
-    const int xcd = (int)(blockIdx.x & 7), nper = (int)(gridDim.x >> 3);
+    const int xcd = vblock & 7, nper = ngen >> 3;
     const int nwork = ((cint_p)(const void*)a.ctl)[zctl(a.parity, 0, xcd)];      // (this XCD's share of list G)
-    if ((int)(blockIdx.x >> 3) >= nwork)
+    if ((vblock >> 3) >= nwork)
         return;
     const int box_cap = a.box_cap;
     const int odd_shift = (box_cap - 1) * 4;
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, czgen
     const int nsteps = STEPS ? a.nsteps : 1;
     const int yy = lane >> 3, xx = lane & 7;
 
-    for (int work = blockIdx.x >> 3; work < nwork; work += nper) {
+    for (int work = vblock >> 3; work < nwork; work += nper) {
         ZStrip sp;
         {
             int sid = ((cint_p)(const void*)a.list_g)[(size_t)work * 8 + xcd];
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, czgen
         crec_p rech0 = (crec_p)(const void*)a.recs_half + ((size_t)sp.sample * a.ntiles + ((size_t)sp.tz0 * a.tiles_y + sp.ty) * a.tiles_x + sp.tx) * 2;
         if (tid == 0)
             ZSTAT(7, 1);
-        if (work != (int)(blockIdx.x >> 3))
+        if (work != (vblock >> 3))
             zlds_barrier();                        // (the previous strip's gathers are done with the box)
         const int oy = sp.ty * kT + yy, ox = sp.tx * kT + xx;
         const int obase = oy * a.img_sy + ox;
@@ -1185,11 +1185,30 @@ __global__ __launch_bounds__(kBlock, 4) void k1z_gen_kernel(const ZFast a, czgen
         if (__any(bad < 0) && lane == 0) {
             // the fix-up kernel redoes the voxels of this strip whose window is not inside the box
             if (atomicOr(a.missed + sp.id, 1) == 0) {
-                const int xcd = (int)(blockIdx.x & 7);
+                const int xcd = vblock & 7;
                 a.list_f[(size_t)atomicAdd(a.ctl + zctl(a.parity, 1, xcd), 1) * 8 + xcd] = sp.id;
             }
         }
     }
+}
+
+// ONE launch for both: rows of 8 consecutive workgroups (one per XCD) take the role of the fast kernel or -- every
+// `every`-th row, until there are `ngen` of them -- of the general kernel, so that the persistent general workgroups start
+// with the first class-A strips and run beside them.  (As two launches on two streams the fork and the join cost the
+// caller's stream ~6 us of idle each, and at the stream priorities on offer the general kernel either took the class-A
+// kernel's slots or was starved until it had finished.)
+template <int ORDER, bool AFFINE, bool OUT16, bool STEPS>
+__global__ __launch_bounds__(kBlock, 4) void k1z_tile_kernel(const ZFast a, czgen_p zn, const int ngen, const int every)
+{
+    const int row = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    const int gen_rows = ngen >> 3;
+    // rows every - 1, 2 every - 1, ... are general rows while they last
+    const int gens_before = min((row + 1) / every, gen_rows);         // general rows among rows 0 .. row (inclusive)
+    const bool is_gen = gens_before > 0 && (row + 1) % every == 0 && (row + 1) / every <= gen_rows;
+    if (is_gen)
+        k1z_gen_body<ORDER, AFFINE, OUT16, STEPS>(a, zn, (gens_before - 1) * 8 + xcd, ngen);
+    else
+        k1z_fast_body<ORDER, AFFINE, OUT16, STEPS>(a, (row - gens_before) * 8 + xcd);
 }
 
 // What the tile kernels could not serve, straight from global memory: every voxel of a tile whose box does not fit LDS,
@@ -1340,33 +1359,17 @@ __global__ __launch_bounds__(kBlock) void k1z_fix_kernel(const ZFast a, czgen_p 
 }
 
 template <int ORDER, bool AFFINE, bool OUT16, bool STEPS>
-hipError_t launch_k1z_kernels(const ZFast& zf, const void* znp, unsigned ngen, unsigned nfix, size_t lds, hipStream_t stream, SideLane* side)
+hipError_t launch_k1z_kernels(const ZFast& zf, const void* znp, unsigned ngen, unsigned nfix, size_t lds, hipStream_t stream, SideLane*)
 {
     const unsigned nfast = k1z_grid(zf.total_strips, zf.deal);
-    // the general tiles next to the class-A tiles: fork a second stream behind the geometry kernel, join it in front of
-    // the fix-up kernel (capturable: the second stream joins the capture of the first and leaves it again)
-    hipStream_t sg = stream;
-    bool forked = false;
-    if (side && side->usable && !ed_env("EDHIP_ZNOFORK") && hipEventRecord(side->fork, stream) == hipSuccess &&
-        hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
-        sg = side->stream;
-        forked = true;
-    } else {
-        (void)hipGetLastError();
-    }
-    hipLaunchKernelGGL((k1z_gen_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(ngen), dim3(kBlock), lds, sg, zf, (czgen_p)znp);
+    // general rows interleaved with the fast rows in proportion, all of them within the first fast rows' reach
+    const unsigned fast_rows = nfast >> 3, gen_rows = ngen >> 3;
+    unsigned every = gen_rows ? fast_rows / gen_rows + 1 : 2;
+    if (every < 2)
+        every = 2;
+    hipLaunchKernelGGL((k1z_tile_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(nfast + ngen), dim3(kBlock), lds, stream, zf, (czgen_p)znp,
+                       (int)ngen, (int)every);
     hipError_t e = hipGetLastError();
-    if (forked) {
-        const hipError_t e2 = hipEventRecord(side->join, sg);
-        e = e == hipSuccess ? e2 : e;
-    }
-    hipLaunchKernelGGL((k1z_fast_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(nfast), dim3(kBlock), lds, stream, zf);
-    if (e == hipSuccess)
-        e = hipGetLastError();
-    if (forked) {
-        const hipError_t e2 = hipStreamWaitEvent(stream, side->join, 0);      // (always: the capture must be rejoined)
-        e = e == hipSuccess ? e2 : e;
-    }
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL((k1z_fix_kernel<ORDER, AFFINE, OUT16, STEPS>), dim3(nfix, 2 * zf.strip_tiles), dim3(kBlock), 0, stream, zf, (czgen_p)znp);
@@ -1487,7 +1490,9 @@ hipError_t launch_k1z(const HotGeom& hg, const ZGeom& zg, int order, size_t lds,
     const void* zn = zg.zgen;
     // persistent grids: the general tiles' list is worked off by up to 5 workgroups per CU; the fix-up list is empty on
     // a mild field (a launch of idle workgroups: ~2 us)
-    const unsigned ngen = (unsigned)(zg.total_strips < 1280 ? ((zg.total_strips + 7) / 8) * 8 : 1280);
+    unsigned ngen = (unsigned)(zg.total_strips < 1280 ? ((zg.total_strips + 7) / 8) * 8 : 1280);
+    if (const char* ng = ed_env("EDHIP_ZNGEN"))
+        ngen = (unsigned)((atoi(ng) + 7) / 8 * 8);
     const unsigned nfix = (unsigned)(zg.total_strips < 512 ? ((zg.total_strips + 7) / 8) * 8 : 512);
     switch (order) {
     case 1: return launch_k1z_order<1>(hg, zf, zn, ngen, nfix, lds, stream, side);

@@ -1,5 +1,8 @@
 cp tools/libedhip_exp.so elasticdeform_amd/libedhip.so
-run() { echo "== $*"; env "$@" KSTATS_ROWS=8 tools/kstats.sh x tools/prof_fwd.py 5 | grep "k1z" | cut -c1-100; }
-run A=1
-run EDHIP_TILE_DBG=8388608
-run EDHIP_TILE_DBG=2130706432
+run() { echo "== $*"; env "$@" python tools/time_fwd.py; }
+run A=0
+run EDHIP_ZNGEN=2048
+run EDHIP_ZNGEN=640
+run EDHIP_ZNGEN=320
+run EDHIP_ZKB=31
+run EDHIP_ZKB=31 EDHIP_ZNGEN=640
