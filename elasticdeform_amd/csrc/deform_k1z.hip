@@ -41,6 +41,7 @@
 #include "ed_params.h"
 #include "ed_tile.h"
 #include "ed_workspace.h"
+#include "ed_zwalk.h"
 
 namespace ed {
 namespace tile {
@@ -101,10 +102,6 @@ __device__ __forceinline__ ZRecU zrec_load(crec_p p)
 // work-list counters (ZGeom::ctl): [parity][list: 0 = G, 1 = F][XCD]; entry k of XCD x's list sits at slot 8 k + x
 __host__ __device__ __forceinline__ int zctl(int parity, int list, int xcd) { return (parity * 2 + list) * 8 + xcd; }
 
-typedef const __attribute__((address_space(4))) int* cint_p;          // constant address space: uniform reads are s_load
-typedef const __attribute__((address_space(4))) double* cdbl_p;
-typedef const __attribute__((address_space(4))) long long* cll_p;
-
 #define ED_RED6(CTRL)                                      \
     "v_min_i32_dpp %0, %0, %0 " CTRL "\n\t"                \
     "v_min_i32_dpp %1, %1, %1 " CTRL "\n\t"                \
@@ -153,19 +150,6 @@ __device__ __forceinline__ void zaxis_entry(const GridGeom& g, int a, int oi, do
         idx[l] = edge ? mirror_i32((int)start + l, (int)g.ncp[a]) : (int)start + l;
 }
 
-// What general coordinates, the mirror-mapped staging paths and the fix-up read on top of ZFast: written to the workspace
-// by the geometry kernel and read from there on demand (constant address space: scalar loads where they are used) -- as
-// a by-value kernel argument its 30 doubles were preloaded into scalar registers and spilled (150 SGPR spills).
-struct ZGen {
-    int in_len[3], out_len[3], off[3];
-    int mode;
-    float cval;
-    int* hint;                // spill feedback: tiles that do not fit the standard box
-    double period[3], inv_period[3];
-    double aff[12], offd[3];  // the affine map as the general kernels apply it (crop offset added per voxel)
-};
-typedef const __attribute__((address_space(4))) ZGen* czgen_p;
-
 constexpr int kGeoBlock = 256;            // (4 waves: the records of a column's tiles are a latency chain per tile)
 constexpr int kGeoWaves = kGeoBlock / 64;
 // ================================================================================================
@@ -192,6 +176,18 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
     int* sCls = reinterpret_cast<int*>(sZ + 4 * hg.tiles[0]);        // [tiles_z]: class of every tile of the column
     int* sBox = sCls + hg.tiles[0];                                  // [tiles_z][raw | mapped][4 sampled slices][8]: sample ranges
     int* sCnt = sBox + 64 * hg.tiles[0];                             // [4]          // [tiles_z][4]: z entries of the sampled slices
+    if ((int)blockIdx.x >= hg.tiles[1] * hg.tiles[2]) {
+        // spare workgroups: clear the gradient accumulators (EDHIP_FLAG_ZERO_GRADIENT) while the others compute the tables
+        const long long nfill = (long long)(gridDim.x - hg.tiles[1] * hg.tiles[2]) * kGeoBlock;
+        const long long me = (long long)(blockIdx.x - hg.tiles[1] * hg.tiles[2]) * kGeoBlock + tid;
+        const long long n16 = zg.zero_bytes >> 4;
+        int4* p16 = reinterpret_cast<int4*>(zg.zero_ptr);
+        for (long long i = me; i < n16; i += nfill)
+            p16[i] = make_int4(0, 0, 0, 0);
+        if (me < (zg.zero_bytes & 15))
+            zg.zero_ptr[(n16 << 4) + me] = 0;
+        return;
+    }
     const int ty = blockIdx.x / hg.tiles[2], tx = blockIdx.x - ty * hg.tiles[2];
     if (ED_DBG(hg.dbg, 1 << 23))
         return;
@@ -249,7 +245,7 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
         zaxis_entry(g, a, oi, t.w, t.idx);
         sAx[tid] = t;
     }
-    for (int e = tid; e < 4 * hg.tiles[0] && !ED_DBG(hg.dbg, 1 << 26); e += kGeoBlock) {
+    for (int e = tid; e < 4 * hg.tiles[0] && !zg.tables_only && !ED_DBG(hg.dbg, 1 << 26); e += kGeoBlock) {
         const int tz = e >> 2, nz = min(kT, hg.out_len[0] - tz * kT);
         AxTab t;
         zaxis_entry(g, 0, tz * kT + ((e & 3) * (nz - 1)) / 3, t.w, t.idx);
@@ -334,6 +330,8 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
                 rg[((int64_t)oy * hg.out_len[2] + ox) * (4 * ncpz) + kz * 4 + h] = acc;
         }
     }
+    if (zg.tables_only)
+        return;          // (the gradient route: R, the z table and ZGen are all it reads)
     __syncthreads();
     ZTICK(5);
     // ---- tile boxes of the patch's z column: wave w samples tiles w, w + 8, ...; lane 63 leaves the reduced ranges in LDS
@@ -622,60 +620,6 @@ inline unsigned k1z_grid(int total_strips, int deal)
     return (unsigned)(((chunks + 7) / 8) * 8 * deal);
 }
 
-// the lane's control planes: 4 taps x 3 components, and the z-table entry they were loaded for
-struct ZTaps {
-    double r[4][3];
-    int key[4];          // byte offsets of the planes held (wave-uniform)
-};
-// z-table entry of a slice: cubic weights + byte offsets of the control planes in an R column (scalar loads when the
-// slice is wave-uniform)
-typedef double zv4d __attribute__((ext_vector_type(4)));
-typedef int zv4i __attribute__((ext_vector_type(4)));
-struct ZEnt {
-    zv4d w;
-    zv4i idx;
-};
-__device__ __forceinline__ ZEnt k1z_entry(cdbl_p zt, int oz)
-{
-    ZEnt e;
-    e.w = *reinterpret_cast<const __attribute__((address_space(4))) zv4d*>(zt + (size_t)oz * 6);
-    e.idx = *reinterpret_cast<const __attribute__((address_space(4))) zv4i*>(zt + (size_t)oz * 6 + 4);
-    return e;
-}
-// if the walk has entered another control interval: the lane's planes of R
-__device__ __forceinline__ void k1z_taps(const ZEnt& e, const char* rcol, ZTaps& tp)
-{
-    if (e.idx[0] != tp.key[0] || e.idx[1] != tp.key[1] || e.idx[2] != tp.key[2] || e.idx[3] != tp.key[3]) {
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            const double2 a = *reinterpret_cast<const double2*>(rcol + e.idx[l]);
-            const double b = *reinterpret_cast<const double*>(rcol + e.idx[l] + 16);
-            tp.r[l][0] = a.x;
-            tp.r[l][1] = a.y;
-            tp.r[l][2] = b;
-            tp.key[l] = e.idx[l];
-        }
-    }
-}
-__device__ __forceinline__ void k1z_slice(cdbl_p zt, const char* rcol, int oz, ZTaps& tp, double (&zw)[4])
-{
-    const ZEnt e = k1z_entry(zt, oz);
-#pragma unroll
-    for (int l = 0; l < 4; ++l)
-        zw[l] = e.w[l];
-    k1z_taps(e, rcol, tp);
-}
-__device__ __forceinline__ void k1z_disp(const ZTaps& tp, const double (&zw)[4], double (&d)[3])
-{
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {
-        d[h] = zw[0] * tp.r[0][h];
-#pragma unroll
-        for (int l = 1; l < 4; ++l)
-            d[h] = fma(zw[l], tp.r[l][h], d[h]);
-    }
-}
-
 // 64-tap (order 3) separable gather of one voxel from the staged box (see deform_k1.hip: reads kept apart, aligned
 // 8-byte pairs from the copy that matches the window's parity)
 template <int ORDER, int PITCH>
@@ -928,37 +872,6 @@ __device__ __forceinline__ void k1z_fast_body(const ZFast& a, const int vblock)
 }
 
 // ---- everything else ---------------------------------------------------------------------------------------------
-// general coordinates of one voxel (deform.c:771-824): the arithmetic every tile kernel shares (ed_tile.h)
-template <int ORDER, bool AFFINE>
-__device__ __forceinline__ bool k1z_coords(czgen_p zn, const double (&d)[3], const int (&b)[3], const double (&P)[3], int* start,
-                                           float* frac, int* raw_start = nullptr)
-{
-    int ci[3];
-    bool inr[3];
-#pragma unroll
-    for (int h = 0; h < 3; ++h)
-        inr[h] = coord_axis_fast<ORDER, float>(AFFINE ? P[h] + d[h] : d[h], AFFINE ? 0 : b[h], zn->in_len[h], ci[h], frac[h]);
-    if (raw_start) {
-#pragma unroll
-        for (int h = 0; h < 3; ++h)
-            raw_start[h] = ci[h] - ORDER / 2;
-    }
-    bool cst = false;
-    if (!(inr[0] && inr[1] && inr[2])) {
-        // one divergent region: the axes along which the source point left the array
-#pragma unroll
-        for (int h = 0; h < 3; ++h) {
-            if (!inr[h])
-                cst = coord_axis_mapped<ORDER, float>(AFFINE ? P[h] + d[h] : (double)b[h] + d[h], zn->in_len[h], zn->mode,
-                                                      zn->period[h], zn->inv_period[h], ci[h], frac[h]) || cst;
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < 3; ++h)
-        start[h] = cst ? 0 : ci[h] - ORDER / 2;
-    return cst;
-}
-
 // General tiles (array faces, partial tiles, boxes that touch the array's ends): general coordinates (deform.c:771-824)
 // with the boundary map, constant and valid flags, every staging path.  Persistent over list G (the strips with such
 // tiles); launched on a second stream next to the fast kernel, so that its long strips -- the columns on the x faces,
@@ -1429,7 +1342,12 @@ bool k1z_supported(const GridGeom& g)
 hipError_t launch_k1z_geo(const GridGeom& g, const HotGeom& hg, const ZGeom& zg, const GridPrefilter& gp, int nbatch,
                           hipStream_t stream)
 {
-    hipLaunchKernelGGL(k1z_geo_kernel, dim3((unsigned)(hg.tiles[1] * hg.tiles[2]), (unsigned)nbatch), dim3(kGeoBlock),
+    unsigned fill = 0;
+    if (zg.zero_ptr && zg.zero_bytes > 0) {
+        const long long want = (zg.zero_bytes + 65535) / 65536;       // 64 KiB per workgroup and round
+        fill = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    }
+    hipLaunchKernelGGL(k1z_geo_kernel, dim3((unsigned)(hg.tiles[1] * hg.tiles[2]) + fill, (unsigned)nbatch), dim3(kGeoBlock),
                        k1z_geo_lds_bytes(g, hg), stream, g, hg, zg, gp);
     return hipGetLastError();
 }

@@ -1888,8 +1888,78 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                             batch->gridpf_done = true;
                         tables_done = true;
                     }
-                } else
+                }
+                // round 6, gradient, PROFILING BUILD ONLY: the scatter on the z-walk tables (tools/experiments/
+                // deform_k2z.hip; EDHIP_K2Z / EDHIP_K2Y / EDHIP_K2S pick the variant) for the geometries that serve
+                // themselves.  Measured against hot_grad_kernel (profiles/r06_k2_zwalk.txt): 327 / 514 / 391 against 323 us
+                // per gradient call -- not shipped; everything the shipped library launches here is tables + hot_grad_kernel
+                bool k2z = false;
+#ifdef EDHIP_EXPERIMENTS
+                if constexpr (GRAD && ORDER <= 3) {
+                    k2z = hlds && !rec_route && !wide && !v.out16 && hg.self_serve && k1z_supported(g) &&
+                          ve.nsteps <= (int64_t)kK1zMaxSteps && (ed_env("EDHIP_K2Z") || ed_env("EDHIP_K2Y") || ed_env("EDHIP_K2S")) &&
+                          !ed_env("EDHIP_WAVE") && e == hipSuccess;
+                }
+#endif
+                size_t k2lds = 0;
+                if (k2z) {
+                    zside = side_lane(stream);
+                    char* gb = zside ? (char*)geo_reserve(stream, zside, k1z_geo_bytes(g, ntiles, nb), &e) : nullptr;
+                    if (!gb)
+                        return e != hipSuccess ? e : hipErrorOutOfMemory;
+                    zg.ctl = (int*)gb;
+                    zg.zgen = gb + 4096;
+                    char* zx = gb + 4096 + 512;
+                    zg.zt = (const AxTab*)zx;
+                    zg.steps = (long long*)(zx + k1z_zt_bytes(g) + (((size_t)ntiles * nb * 168 + 63) & ~(size_t)63));
+                    zg.r = (const double*)((char*)zg.steps + kK1zMaxSteps * 16);
+                    zg.r_bstride = (long long)(((k1z_r_bytes(g) + 63) & ~(size_t)63) / 8);
+                    zg.disp_bstride = tg.disp_bstride;
+                    zg.ncpz = (int)g.ncp[0];
+                    zg.order = ORDER;
+                    zg.tables_only = 1;
+                    zg.strip_tiles = 4;
+                    while (zg.strip_tiles > 1 && (int64_t)nb * tg.tiles[1] * ((tg.tiles[2] + 1) / 2) *
+                                                         ((tg.tiles[0] + zg.strip_tiles - 1) / zg.strip_tiles) < 1024)
+                        zg.strip_tiles >>= 1;
+                    zg.hint = hg.hint;
+                    zg.hint_host = tg.hint_host;
+                    zg.hint_seq = tg.hint_seq;
+                    if (batch && batch->zero_ptr && !batch->zero_done && nb == 1 && ((uintptr_t)batch->zero_ptr & 15) == 0) {
+                        zg.zero_ptr = batch->zero_ptr;
+                        zg.zero_bytes = batch->zero_bytes;
+                    }
+                    GridPrefilter gp;
+                    memset(&gp, 0, sizeof(gp));
+                    const bool own = batch && batch->gridpf && nb == 1 && batch->gridpf->total <= 4096;
+                    if (own) {
+                        gp = *batch->gridpf;
+                        gp.zero_ptr = nullptr;
+                        gp.zero_bytes = 0;
+                    }
+#ifdef EDHIP_EXPERIMENTS
+                    k2lds = k2z_lds_bytes(&hg.box_cap);
+#endif
+                    hg.small_cap = hg.box_cap;
+                    e = launch_k1z_geo(g, hg, zg, gp, nb, stream);
+                    if (e == hipSuccess) {
+                        if (zg.zero_ptr)
+                            batch->zero_done = true;
+                        if (own)
+                            batch->gridpf_done = true;
+                    }
+                    tables_done = true;
+                }
+                if (!tables_done)
                     launch_tables();
+#ifdef EDHIP_EXPERIMENTS
+                if (k2z && e == hipSuccess) {
+                    profile_mark(false, stream);
+                    e = launch_k2z(hg, zg, ORDER, k2lds, stream);
+                    hot_done = true;
+                    served_all = true;
+                }
+#endif
                 if (rec_route && e == hipSuccess) {
                     // gradient from records: (1) K1 in records-only form -- its workgroups leave at once for the
                     // samples whose records the forward call made from these very grid values -- (2) the

@@ -478,6 +478,9 @@ struct ZGeom {
     int* ctl;
     int parity;
     void* zgen;               // 512 bytes: the uniform values of the general paths (ZGen), written by the geometry kernel
+    int tables_only;          // the gradient route (deform_k2z.hip): R, the z table and ZGen, no records
+    char* zero_ptr;           // EDHIP_FLAG_ZERO_GRADIENT: spare workgroups of the geometry launch clear this block
+    long long zero_bytes;
     long long r_bstride;      // doubles between consecutive samples of r
     long long disp_bstride;   // bytes between the control grids of consecutive samples
     int ncpz;
@@ -496,6 +499,9 @@ size_t k1z_r_bytes(const GridGeom& g);
 hipError_t launch_k1z_geo(const GridGeom& g, const HotGeom& hg, const ZGeom& zg, const GridPrefilter& gp, int nbatch,
                           hipStream_t stream);
 hipError_t launch_k1z(const HotGeom& hg, const ZGeom& zg, int order, size_t lds, hipStream_t stream, ed::SideLane* side);
+// K2 of round 6 (deform_k2z.hip): the gradient on the z-walk tables (geometry kernel in its tables-only form)
+size_t k2z_lds_bytes(int* box_cap);
+hipError_t launch_k2z(const HotGeom& hg, const ZGeom& zg, int order, size_t lds, hipStream_t stream);
 
 // one-wavefront-per-tile kernels (deform_wave.hip): same argument block; `strip_tiles`, `strips_x`,
 // `nstrips`, `total_strips` describe the strips of the 64-thread workgroups, `box_cap` the floats /

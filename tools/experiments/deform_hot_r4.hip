@@ -6,7 +6,7 @@
 //
 // K1 of round 4: same algorithm and LDS tiling as the general kernels of deform_tile.hip, the exact bounding box of a
 // tile's tap windows reduced per tile (DPP + LDS atomics), coordinates of tile t + 1 under the LDS-DMA copies of tile t.
-#include "../ed_hot.h"
+#include "ed_hot.h"
 
 #ifndef EDHIP_EXPERIMENTS
 #error "experiments/deform_hot_r4.hip is part of the profiling build only"
