@@ -49,6 +49,11 @@ Extra objects on the JSON line:
   fresh_grid    the step as an augmentation loop runs it: a NEW displacement tensor every step (sigma 5 and
                 sigma 10), so that whatever the library keeps from call to call (tile boxes, spill feedback,
                 the repeat-call lane) is measured as that pattern uses it; cfg2, rank 0, N = 1 only.
+  repeat_ms_per_step  the K-step region timed `--repeats` more times behind the headline region: median / min / max
+                (the headline number stays the first region, as the contract says).  An idle MI355X runs the step
+                ~7 % slower for its first ~25 repetitions (profiles/r06_step_ramp.txt: 0.71 -> 0.66 ms, again after
+                0.5 s of idling; 60-200 ms of element-wise torch work in front does not shorten it), so the headline
+                region -- steps 6..25 of the process -- sits on that ramp and the repeats show the settled rate.
   stress        SURVEY.md 8(d) "report both": the same step at sigma = 10 (the README example's
                 aggressiveness: displacement gradient ~1.25, many tiles take the spill levels), a few
                 timed steps after the headline region; cfg2, rank 0, N = 1 only.
@@ -84,6 +89,9 @@ def parse():
                     help="cfg2 with 16-bit float STORAGE (float32 arithmetic; the reduced-precision opt-in): its own line")
     ap.add_argument("--batch", type=int, default=64, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=6,
+                    help="cfg2, N = 1: the K-step region timed this many more times behind the headline region "
+                         "(median / min / max reported as `repeat_ms_per_step`; 0 = off)")
     ap.add_argument("--no-stress", action="store_true", help=argparse.SUPPRESS)      # profile collection: headline kernels only
     return ap.parse_args()
 
@@ -168,7 +176,7 @@ def relaunch(args):
 # What K1 / K2 and their launch routing are built from: the PMC-derived numbers of profiles/hbm_traffic.json (HBM
 # bytes per launch, VALUBusy, LDS busy) are reported only while the hash of these files matches the tree the bench
 # runs in -- an edit to a kernel, to the strip length / routing in the launcher or to the API layer voids the stamp.
-KERNEL_SOURCES = ("deform_k1.hip", "deform_hot.hip", "ed_hot.h", "ed_tile.h", "ed_device.h", "deform_tile.hip",
+KERNEL_SOURCES = ("deform_k1z.hip", "ed_zwalk.h", "deform_k1.hip", "deform_hot.hip", "ed_hot.h", "ed_tile.h", "ed_device.h", "deform_tile.hip",
                   "edhip_api.hip", "ed_params.h")
 
 
@@ -627,9 +635,10 @@ def main():
         except Exception:
             return None
 
-    k1_obj = kernel_obj("K1", "K1 forward deform: k1_fwd_kernel<3,false> (deform_k1.hip; the strip launch of "
-                        "one edhip_deform gradient=0 call on the prefiltered input; whole_call adds the "
-                        "tables kernel)", k1_us, k1_med, k1_ms)
+    k1_obj = kernel_obj("K1", "K1 forward deform: k1z_tile_kernel<3,false> (deform_k1z.hip, the z-walk kernel of "
+                        "round 6; the tile launch of one edhip_deform gradient=0 call on the prefiltered input; "
+                        "whole_call adds the geometry kernel in front of it and the fix-up kernel behind it)",
+                        k1_us, k1_med, k1_ms)
     k2_obj = kernel_obj("K2", "K2 gradient scatter-add: hot_grad_kernel<3,false> (deform_hot.hip; the strip "
                         "launch of one edhip_deform gradient=1 call; whole_call adds the tables kernel and "
                         "the two spill passes)", k2_us, k2_med, k2_ms)
@@ -641,6 +650,18 @@ def main():
                         "(gather / scatter, no MFMA); both tile kernels are LDS- and issue-bound today, "
                         "see DESIGN.md 5" % (k3_ms * 1e3 / 3, k4_ms * 1e3 / 3))
     ms_per_step = elapsed / args.steps * 1e3
+    # box-to-box and run-to-run noise is a few per cent: the same K-step region REPEATS more times (outside the headline
+    # number, which stays "exactly K steps after W warm-up steps"); median, minimum and maximum are reported beside it
+    repeats = []
+    if rank == 0 and world == 1 and args.repeats > 0:
+        for _ in range(args.repeats):
+            fence()
+            tr = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            repeats.append((time.perf_counter() - tr) / args.steps * 1e3)
+        repeats.sort()
     step_bytes = 64.0 * vox
     step_obj = {"bound": "hbm", "algorithmic_bytes_per_step": int(step_bytes),
                 "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1), "peak": 8000.0,
@@ -730,6 +751,12 @@ def main():
             "fwd_only_mvox_s": round(vox / (fwd_ms * 1e-3) / 1e6, 1),
             "k1_only_mvox_s": round(vox / (k1_ms * 1e-3) / 1e6, 1),
         }
+        if repeats:
+            res["repeat_ms_per_step"] = {"repeats": len(repeats), "steps_each": args.steps,
+                                         "median": round(repeats[len(repeats) // 2], 4),
+                                         "min": round(repeats[0], 4), "max": round(repeats[-1], 4),
+                                         "note": "the same K-step region timed again after the headline region "
+                                                 "(value / ms_per_step above are the first region alone)"}
         if stress is not None:
             res["stress"] = stress
         if fresh is not None:

@@ -35,7 +35,7 @@ def mean(c, k):
     return sum(c[k]) / len(c[k]) if c.get(k) else None
 
 
-for tag, key in (("K1", "k1_fwd_kernel<3, false"), ("K2", "hot_grad_kernel<3, false")):
+for tag, key in (("K1", "k1z_tile_kernel<3, false"), ("K2", "hot_grad_kernel<3, false")):
     for name, c in vals.items():
         if key in name and c.get("FETCH_SIZE") and c.get("WRITE_SIZE"):
             fkb = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
