@@ -265,7 +265,7 @@ ED_UNROLL(ED_K2_U1)
         const int nrows = ext[0] * by;
         const int nbox = nrows * pitch;
         if (hg.hint && tid == 0 && half < 0 && (pitch == 0 || nbox > hg.small_cap))
-            atomicAdd(hg.hint, TX / kT);   // spill feedback, in 8-wide tiles
+            atomicAdd(hg.hint, (hg.large_cap > 0 && (pitch == 0 || nbox > hg.large_cap)) ? kHintHuge * (TX / kT) : TX / kT);   // spill feedback, in 8-wide tiles
         // self_serve: a tile that does not fit keeps an EMPTY box -- every live voxel then fails the window test
         // below and scatters its taps straight to global memory (the path of a stale handed-over box)
         bool direct_tile = false;
@@ -474,21 +474,30 @@ hipError_t launch_grad_order(const HotGeom& hg, unsigned nblk, size_t lds, hipSt
         return hipGetLastError();
     }
 #endif
+    // (a cell block beyond 64 KiB -- the "huge" boxes of strongly deformed volumes, two workgroups per CU -- needs the
+    // kernel's dynamic-LDS limit raised; per call: the attribute belongs to the device the call runs on)
+    auto go = [&](auto kern, bool&) -> hipError_t {
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess)
+                return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(kBlock), lds, stream, hg);
+        return hipGetLastError();
+    };
+    bool raised[4] = {false, false, false, false};
     if (hg.io16) {
         if constexpr (ORDER <= 3) {
             if (hg.has_affine)
-                hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 4, 16, 1, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
-            else
-                hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4, 16, 1, true>), dim3(nblk), dim3(kBlock), lds, stream, hg);
-            return hipGetLastError();
+                return go(hot_grad_kernel<ORDER, true, 4, 16, 1, true>, raised[0]);
+            return go(hot_grad_kernel<ORDER, false, 4, 16, 1, true>, raised[1]);
         }
         return hipErrorNotSupported;
     }
     if (hg.has_affine)
-        hipLaunchKernelGGL((hot_grad_kernel<ORDER, true, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
-    else
-        hipLaunchKernelGGL((hot_grad_kernel<ORDER, false, 4, 16>), dim3(nblk), dim3(kBlock), lds, stream, hg);
-    return hipGetLastError();
+        return go(hot_grad_kernel<ORDER, true, 4, 16>, raised[2]);
+    return go(hot_grad_kernel<ORDER, false, 4, 16>, raised[3]);
 }
 
 }  // namespace
@@ -504,7 +513,7 @@ hipError_t launch_hot_grad2(const HotGeom&, int, unsigned, size_t, hipStream_t) 
 
 // LDS: x table | reduction slots | wave sums | parameters | 64 Q rows | box.  Returns 0 when the
 // control grid is too wide for a useful box (the general kernels take the call).
-size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, bool large)
+size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, int level)
 {
     const size_t q = (size_t)kT * kT * 32 * (size_t)ncpx;
     const size_t off = (kOffQ + q + 15) & ~(size_t)15;
@@ -513,13 +522,17 @@ size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, bool l
     // whole call, standard -> large: sigma 5 forward 262 -> 286 us, gradient 325 -> 357; sigma 10 forward
     // 368 -> 340, gradient 501 -> 427; sigma 15 forward 614 -> 496, gradient 1412 -> 1264
     // (profiles/r03_bench_misc.txt): launch_tile picks them when recent calls of the geometry spilled.
+    const bool large = level >= 1;
     if (gradient) {
-        size_t box = large ? 36 * 1024 : kGradBoxBytes;
+        // Huge boxes (64 KiB of cells, two workgroups per CU) where a tenth of the tiles does not fit the large ones.
+        // 256^3 order 3, gradient call after a forward call, large -> huge: sigma 10 434 -> 497 us, sigma 12.5
+        // 546 -> 528, sigma 15 837 -> 579, sigma 20 3600 -> 779 (profiles/r06_k2_box_sweep.txt)
+        size_t box = level >= 2 ? 64 * 1024 : (large ? 36 * 1024 : kGradBoxBytes);
         if (const char* kb = ed_env("EDHIP_GRAD_BOX_KB"))
             box = (size_t)atoi(kb) * 1024;
         *box_cap = (int)(box / 4);
         const size_t total = off + box;
-        return total <= 64 * 1024 ? total : 0;
+        return total <= 80 * 1024 ? total : 0;
     }
     // forward: two shifted float copies; 4 workgroups per CU -> 40960 bytes each (wide control
     // grids: a 64 KiB block, fewer workgroups per CU)

@@ -1310,11 +1310,13 @@ hipError_t launch_k1z_order(const HotGeom& hg, const ZFast& zf, const void* zn, 
 }  // namespace
 
 // LDS of both kernels: the box pair.  Five workgroups per
-// CU -> 31 KiB each (3904 floats per copy: a 13 x 13 x 16 box of the benchmark field takes 2704); large boxes (40 KiB,
-// four per CU) for strongly deformed volumes, chosen by the spill feedback
+// CU -> 31 KiB each (3904 floats per copy: a 13 x 13 x 16 box of the benchmark field takes 2704); large boxes (52 KiB,
+// three per CU) for strongly deformed volumes, chosen by the spill feedback
 size_t k1z_lds_bytes(int* box_cap, bool large)
 {
-    size_t budget = large ? 40 * 1024 : 31 * 1024;
+    // (large: 52 KiB, three workgroups per CU -- against 40 KiB / four per CU: forward call at sigma 10 / 12.5 / 15 / 20
+    // 248 / 288 / 343 / 609 -> 239 / 292 / 331 / 457 us, profiles/r06_k1_box_sweep.txt)
+    size_t budget = large ? 52 * 1024 : 31 * 1024;
     if (const char* kb = ed_env("EDHIP_ZKB"))
         budget = (size_t)atoi(kb) * 1024;
     size_t cap = budget / 8;

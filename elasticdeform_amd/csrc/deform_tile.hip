@@ -1465,7 +1465,7 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
     // level-1 spill feedback (float32, the kernels of deform_hot.hip and deform_wave.hip): what the recent
     // calls of this geometry on this stream reported decides between the standard and the large boxes
     SpillHint* sh = nullptr;
-    bool large_boxes = false;
+    bool large_boxes = false, huge_boxes = false;
     // self-serve: the recent calls of this geometry left at most a handful of tiles to the spill list -- level 1
     // then takes such tiles itself (straight from / to global memory) and the two spill launches are not made
     bool self_serve = false, self_serve_boxes = false;
@@ -1488,6 +1488,8 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
             const unsigned long long key = geometry_key(GRAD);
             sh->absorb();
             large_boxes = sh->fraction(key) > 0.10f;
+            // (K2 counts a tile beyond the LARGE box kHintHuge times: a tenth of the tiles there -> the huge boxes)
+            huge_boxes = GRAD && sh->fraction(key) > 0.10f * (float)tile::kHintHuge;
             // Forward: a tile gathered straight from global memory costs its workgroup ~10 us, so a handful may stay.
             // Gradient: 64 global float atomics per voxel, ~50 us per 16-wide tile (31 such tiles of a 128^3 volume
             // took K2 from 56 to 141 us).  A gradient call WITH the forward call's boxes takes its oversize tiles as
@@ -1503,7 +1505,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
             if (const char* ss = ed_env("EDHIP_SELF_SERVE"))
                 self_serve = self_serve_boxes = atoi(ss) != 0;
             if (const char* lb = ed_env("EDHIP_LARGE_BOXES"))       // 0 never, 1 always, 2 forward only, 3 gradient only
-                large_boxes = atoi(lb) == 1 || (atoi(lb) == 2 && !GRAD) || (atoi(lb) == 3 && GRAD);
+                large_boxes = atoi(lb) == 1 || (atoi(lb) == 2 && !GRAD) || (atoi(lb) == 3 && GRAD) || atoi(lb) == 4;
+            if (const char* lb = ed_env("EDHIP_LARGE_BOXES"))
+                huge_boxes = GRAD && atoi(lb) == 4;
 #endif
             tg.hint_host = sh->dev;
             tg.hint_seq = sh->begin_call(key, (unsigned)(ntiles * nb));
@@ -1769,11 +1773,14 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
 #endif
                 } else {
                     int off_small = 0;
-                    (void)hot_lds_bytes(GRAD, hot_cols, &hg.small_cap, &off_small, false);
-                    if (large_boxes)
-                        hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, true);
+                    (void)hot_lds_bytes(GRAD, hot_cols, &hg.small_cap, &off_small, 0);
+                    (void)hot_lds_bytes(GRAD, hot_cols, &hg.large_cap, &off_small, 1);
+                    if (huge_boxes)
+                        hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, 2);
+                    if (!hlds && large_boxes)
+                        hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, 1);
                     if (!hlds)
-                        hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, false);
+                        hlds = hot_lds_bytes(GRAD, hot_cols, &hg.box_cap, &hg.off_box, 0);
                     hg.hint = sh ? tg.hint : nullptr;
                 }
                 if (v.out16 && !hlds)

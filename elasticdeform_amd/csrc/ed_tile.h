@@ -382,6 +382,9 @@ __device__ __forceinline__ bool strip_position(const TileGeom& tg, int work, Str
 // Argument block of the hot kernels: 3 deformed axes, float32, unit stride along x on both sides.
 // `vol` is the array with the INPUT's deformed extents (forward: the source volume, read; gradient:
 // dX, accumulated into), `img` the one with the OUTPUT's extents (forward: written; gradient: dY).
+// spill feedback of K2: a tile beyond the standard box counts 1, one beyond the LARGE box counts kHintHuge (the launcher
+// reads "a tenth of the tiles beyond the large box" off the same counter: ed_workspace.h)
+constexpr int kHintHuge = 64;
 struct HotGeom {
     const float* vol_r;       // forward: source volume
     float* vol_w;             // gradient: dX
@@ -393,6 +396,7 @@ struct HotGeom {
     int* spill;               // tiles the LDS box cannot hold -> the general kernels
     int* hint;                // [0]: count of the tiles whose box exceeds small_cap elements (or nullptr)
     int small_cap;            // box_cap of the standard configuration (== box_cap unless the large boxes are in use)
+    int large_cap;            // K2: box_cap of the large configuration -- a tile beyond it weighs kHintHuge in the count
     long long vol_bstride, img_bstride, q_bstride;      // elements between consecutive samples
     int in_len[3], out_len[3], off[3];
     int vol_sz, vol_sy;       // element strides of vol along z, y (x: 1)
@@ -448,7 +452,8 @@ constexpr unsigned kRecDead = 0x80000000u;
 hipError_t launch_hot_level1(const HotGeom& hg, int order, bool gradient, unsigned nblk, size_t lds,
                              hipStream_t stream);
 // large: the configuration with one workgroup per CU fewer and larger boxes (chosen from the spill feedback)
-size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, bool large = false);
+// level: 0 standard, 1 large, 2 huge (gradient only: 64 KiB of cells, two workgroups per CU)
+size_t hot_lds_bytes(bool gradient, int ncpx, int* box_cap, int* off_box, int level = 0);
 // the records route of a gradient call: K1 in records-only form (grid / LDS of the forward launch), then the
 // gradient kernel that reads records and boxes (orders 1-3)
 hipError_t launch_hot_records(const HotGeom& hg, int order, unsigned nblk, size_t lds, hipStream_t stream);
