@@ -1487,7 +1487,9 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
             };
             const unsigned long long key = geometry_key(GRAD);
             sh->absorb();
-            large_boxes = sh->fraction(key) > 0.10f;
+            // (forward, K1z: the large boxes pay from ~6 % of the tiles beyond the standard box -- 256^3, sigma 7.5: 1.2 %,
+            // 202 against 225 us; sigma 10: 8.9 %, 249 against 237 us -- profiles/r06_sigma_sweep.txt)
+            large_boxes = sh->fraction(key) > (GRAD ? 0.10f : 0.06f);
             // (K2 counts a tile beyond the LARGE box kHintHuge times: a tenth of the tiles there -> the huge boxes)
             huge_boxes = GRAD && sh->fraction(key) > 0.10f * (float)tile::kHintHuge;
             // Forward: a tile gathered straight from global memory costs its workgroup ~10 us, so a handful may stay.
