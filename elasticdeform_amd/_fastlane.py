@@ -199,7 +199,10 @@ class Lane(object):
             ax0 = plan.axis[0]
             in_len = [int(in_shapes[0][a]) for a in ax0]
             out_len = [int(plan.output_shapes[0][a]) for a in ax0]
-            self.window_pays = dgm._crop_window_pays(plan, in_shapes, names, todo, in_len, out_len)
+            # (gradient lanes filter dX, which the lane allocates contiguous; forward lanes filter the inputs as given)
+            self.window_pays = dgm._crop_window_pays(plan, in_shapes, names, todo, in_len, out_len,
+                                                     disp_shape=[int(d) for d in displacement.shape],
+                                                     contiguous=[True] * n if gradient else [bool(x.is_contiguous()) for x in xs])
 
     def run(self, dgm, X, xs, displacement):
         torch = _torch

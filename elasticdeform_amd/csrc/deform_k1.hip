@@ -19,7 +19,9 @@
 //     boundary map: its voxels skip the "left the array?" tests, the constant / valid flags and their branches
 //     (a third of the old coordinate phase).  A voxel that leaves the array anyway has a window outside the
 //     box and is caught by the check above.  Every other tile (array faces, partial tiles) takes the general
-//     coordinates, and its box is the exact one, reduced in the strip prologue.
+//     coordinates; its box is SAMPLED too (the mapped coordinate at the same 64 lattice points, plus the margin)
+//     and every voxel's window is checked against it -- correctness rests on that check and on k1_fix, as for
+//     the fast tiles.
 //   * Q rows are staged as [control column][row][component]: the two voxels of a lane differ by an immediate
 //     offset, a voxel's table reads need no address arithmetic, and the 8 rows of a wave-instruction are
 //     contiguous 32-byte pieces (the old [row][column] layout spread them 160 bytes apart).
@@ -55,7 +57,7 @@ namespace {
 constexpr int kK1Strip = ED_K1_STRIP;                    // tiles per strip, at most
 constexpr int kK1Tab = 0;                                // AxTab[kK1Strip * 8]; idx = byte offset of the control column
 constexpr int kK1Rec = kK1Tab + kK1Strip * kT * 48;      // TileRec[kK1Strip]
-constexpr int kK1Red = kK1Rec + kK1Strip * 64;           // int[kK1Strip][8]: exact boxes of the general tiles
+constexpr int kK1Red = kK1Rec + kK1Strip * 64;           // (128 bytes, unused since the general tiles' boxes are sampled: the offsets behind stay put)
 constexpr int kK1Hot = kK1Red + kK1Strip * 32;           // HotParams
 constexpr int kK1Q = kK1Hot + 416;                       // Q[control column][64 rows][4 doubles]
 constexpr int kQCol = 64 * 32;                           // bytes per control column
@@ -172,10 +174,6 @@ __device__ __forceinline__ void k1_prologue(const HotGeom& hg, const K1Strip& sp
         const double2* src = reinterpret_cast<const double2*>(hg.q + sp.sample * hg.q_bstride + qrow_id * (4 * hg.ncpx));
         for (int p = tid & 3; p < row16; p += 4)
             *reinterpret_cast<double2*>(smem + kK1Q + (p >> 1) * kQCol + r * 32 + (p & 1) * 16) = src[p];
-    }
-    if (tid < kK1Strip * 8) {
-        const int k = tid & 7;
-        reinterpret_cast<int*>(smem + kK1Red)[tid] = k < 3 ? 0x7fffffff : (int)0x80000000;
     }
     if (tid >= 128 && tid < 128 + 12) {
         HotParams* hp = reinterpret_cast<HotParams*>(smem + kK1Hot);

@@ -1542,16 +1542,23 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
         }
         GridPrefilter gp;
         memset(&gp, 0, sizeof(gp));
-        if (batch && batch->gridpf && nb == 1 && batch->gridpf->total <= 4096) {
+        // a raw grid is filtered inside this launch when the launch's LDS holds it next to the plane slab (the kernel
+        // has ~1.2 KB of static LDS on top: a flat grid of 1342-1365 points would pass 64 KiB); otherwise gridpf_done
+        // stays false and edhip_deform issues the one-workgroup prefilter first
+        bool own = false;
+        if (batch && batch->gridpf && nb == 1 && batch->gridpf->total <= 4096 &&
+            sizeof(double) * (3 * (size_t)g.ncp[1] * (size_t)g.ncp[2] + (size_t)batch->gridpf->total) <= 60 * 1024) {
             gp = *batch->gridpf;
             gp.zero_ptr = nullptr;
             gp.zero_bytes = 0;
-            batch->gridpf_done = true;
+            own = true;
         }
         hipLaunchKernelGGL(tile_tables_kernel, dim3((unsigned)g.out_len[0] + fill_blocks, (unsigned)nb), dim3(kBlock),
                            sizeof(double) * (3 * (size_t)g.ncp[1] * (size_t)g.ncp[2] + (size_t)gp.total), stream, g, tg,
                            gp);
         e = hipGetLastError();
+        if (own && e == hipSuccess)
+            batch->gridpf_done = true;       // (only a launch that went out has filtered the grid: ADVICE r5)
     };
     if (std::is_integral<T>::value || ORDER < 1)
         launch_tables();

@@ -450,7 +450,11 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
         DeformBatch lone;
         lone.nbatch = 1;
         lone.in_bstride = lone.out_bstride = lone.disp_bstride = 0;
-        lone.gridpf = (gpf.total > 0 && (use_label || use_int) && !ed_env("EDHIP_GRIDPF_SEPARATE")) ? &gpf : nullptr;
+        // (the tables launch filters a raw grid in LDS next to its plane slab: only where both fit -- a flat grid of
+        // 1342-1365 points would pass 64 KiB with the kernel's static LDS; such a grid gets the one-workgroup launch first)
+        const bool gpf_in_tables = gpf.total > 0 && !ed_env("EDHIP_GRIDPF_SEPARATE") &&
+                                   8 * (3 * (size_t)g.ncp[1] * (size_t)g.ncp[2] + (size_t)gpf.total) <= 60 * 1024;
+        lone.gridpf = (gpf_in_tables && (use_label || use_int)) ? &gpf : nullptr;
         if (!tile && !lone.gridpf)
             e = grid_now();
         if (e == hipSuccess && zero && !tile)
@@ -476,7 +480,7 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
                            : ((gradient && (flags & EDHIP_FLAG_USE_BOXES)) ? 2 : 0);
             one.disp_id = displacement->data;
             one.raw = (flags & EDHIP_FLAG_RAW_DISPLACEMENT) ? 1 : 0;
-            one.gridpf = (gpf.total > 0 && !ed_env("EDHIP_GRIDPF_SEPARATE")) ? &gpf : nullptr;      // (A/B switch, profiling build)
+            one.gridpf = gpf_in_tables ? &gpf : nullptr;
             if (!one.gridpf && grid_now() != hipSuccess)
                 return fail(err, errlen, EDHIP_ERR_DEVICE, "grid prefilter launch");
             // (several inputs share the geometry: the boxes are those of the last forward launch,

@@ -76,6 +76,51 @@ def set_reduced_precision(enabled):
     return prev
 
 
+_strict_crop = os.environ.get('EDHIP_STRICT_CROP', '') not in ('', '0')
+
+
+def set_crop_identity(strict):
+    """The reference's crop guarantee, bit for bit (README.md:113 ``full[crop] == cropped``): with ``strict=True`` the
+    spline prefilter of a cropped call always runs over the WHOLE input, exactly as in the uncropped call, so the
+    cropped result equals the same region of the full result in every bit.  Off by default: large inputs with a small
+    crop then prefilter only the part of the volume the crop can reach (plus a decay margin), which changes float32 /
+    float64 results by ~1e-9 of the data's scale -- far inside every tolerance, but not identical bits -- and saves
+    most of the prefilter (BASELINE cfg4: forward 263 -> 140 us).  Integer volumes and 'exact' arithmetic never use
+    the window.  Returns the previous setting."""
+    global _strict_crop
+    prev = _strict_crop
+    _strict_crop = bool(strict)
+    return prev
+
+
+_GRAD_ACCUMULATION = ('fixed', 'float')
+_grad_accumulation = os.environ.get('EDHIP_GRAD_ACCUMULATION', 'fixed').lower()
+if _grad_accumulation not in _GRAD_ACCUMULATION:
+    _grad_accumulation = 'fixed'
+
+
+def set_gradient_accumulation(kind):
+    """How ``deform_grid_gradient`` sums the taps of float32 / float64 gradients (deform.c:926-997 adds every tap
+    into the output array in its own precision):
+
+    * 'fixed' (default): the tile kernels accumulate in fixed-point LDS cells whose scale comes from the sum of |dY|
+      over the tile (include/edhip.h).  Every contribution is resolved to ~1.4e-10 of its TILE's sum of |dY|: exact
+      to float32 rounding for gradients of ordinary dynamic range, but one 1e6 outlier costs the other voxels of its
+      8 x 8 x 16 tile ~1e-4 absolute.
+    * 'float': every tap is added with a floating-point atomic in the array's own type, as the reference does -- the
+      precision of a contribution is relative to the contribution itself, whatever its neighbours hold.  The scatter
+      runs on the one-thread-per-voxel kernel with the reference's fp64 coordinate arithmetic (several times slower
+      than the tile kernels); prefilter transposes are unchanged.
+
+    Returns the previous setting."""
+    global _grad_accumulation
+    if kind not in _GRAD_ACCUMULATION:
+        raise ValueError("gradient accumulation must be one of %s" % list(_GRAD_ACCUMULATION))
+    prev = _grad_accumulation
+    _grad_accumulation = kind
+    return prev
+
+
 def _torch():
     import torch
     return torch
@@ -293,7 +338,7 @@ _WINDOW_MARGIN = {'float32': {2: 12, 3: 16}, 'float64': {2: 24, 3: 32}}
 _WINDOW_MIN_LINE = 64                # the whole-line tile kernels' shortest line
 
 
-def _crop_window_pays(plan, shapes, names, todo, in_len, out_len):
+def _crop_window_pays(plan, shapes, names, todo, in_len, out_len, disp_shape=None, contiguous=None):
     """What the host knows without the device: does the smallest possible window (output box + margins + taps, at
     least a tile kernel's shortest line) save enough filter work, summed over the inputs `todo`?  One rule for the
     general path (_crop_windows) and for the repeat-call lanes (_fastlane.Lane.window_pays), so that repeated
@@ -308,6 +353,14 @@ def _crop_window_pays(plan, shapes, names, todo, in_len, out_len):
         m = _WINDOW_MARGIN[names[i]][int(plan.order[i])]
         return [min(n_in, max(n_out + 2 * m + int(plan.order[i]) + 3, _WINDOW_MIN_LINE))
                 for n_in, n_out in zip(in_len, out_len)]
+    if not todo or _strict_crop:
+        return False
+    if disp_shape is not None and (len(disp_shape) < 2 or len(disp_shape) > 5 or
+                                   numpy.prod([int(d) for d in disp_shape]) > 7680):
+        return False                # (control grid in LDS, up to 4 deformed axes: edhip_source_window)
+    # inputs the window kernels take: contiguous, every deformed axis at least a tile kernel's shortest line
+    todo = [i for i in todo if (contiguous is None or contiguous[i]) and
+            all(int(shapes[i][a]) >= _WINDOW_MIN_LINE for a in plan.axis[i])]
     if not todo:
         return False
     full = sum(volume(i, in_len) for i in todo)
@@ -321,18 +374,18 @@ def _crop_windows(plan, xs, disp_desc, dflag, crop, prefilter, device, stream, g
     window's coefficients equal the whole-volume ones to below the data's rounding, not bit for bit."""
     n = len(xs)
     wins = [None] * n
-    if crop is None or not prefilter or (_flags & _lib.FLAG_EXACT):
+    if crop is None or not prefilter or (_flags & _lib.FLAG_EXACT) or _strict_crop:
         return wins
     todo = [i for i in range(n) if int(plan.order[i]) in _WINDOW_MARGIN.get(_dtype_name(xs[i]), {})]
     if not todo:
         return wins
-    if disp_desc.ndim < 2 or disp_desc.ndim > 5 or numpy.prod(list(disp_desc.shape)[:disp_desc.ndim]) > 7680:
-        return wins                 # (control grid in LDS, up to 4 deformed axes)
     ax0 = plan.axis[0]
     in_len = [int(xs[0].shape[a]) for a in ax0]
     out_len = [int(plan.output_shapes[0][a]) for a in ax0]
+    # (one rule -- grid size, layout, shortest line, pay-off -- for this path and for the repeat-call lanes)
     if not _crop_window_pays(plan, [tuple(int(d) for d in x.shape) for x in xs], [_dtype_name(x) for x in xs], todo,
-                             in_len, out_len):
+                             in_len, out_len, disp_shape=list(disp_desc.shape)[:disp_desc.ndim],
+                             contiguous=[bool(x.is_contiguous()) for x in xs]):
         return wins
     torch = _torch()
     for i in todo:
@@ -374,6 +427,8 @@ def _lane_lookup(gradient, X, displacement, order, mode, cval, crop, prefilter, 
     call the lane does not serve; (sig, None) for a signature seen for the first time."""
     if _reduced or affine is not None or rotate is not None or zoom is not None or not _fastlane.enabled:
         return None, None
+    if _strict_crop or (gradient and _grad_accumulation != 'fixed'):
+        return None, None           # (the lanes are built for the default routes)
     sig = _fastlane.signature(gradient, X, displacement, order, mode, cval, crop, prefilter, axis,
                               X_shape, _flags)
     if sig is None:
@@ -393,7 +448,7 @@ def _lane_build(sig, gradient, xs, dd, plan, prefilter, X_shape, crop):
         return
     try:
         lane = _fastlane.Lane(_this, gradient, xs, dd, plan, prefilter, X_shape, _flags, crop)
-    except (RuntimeError, ValueError, TypeError, MemoryError) as exc:
+    except Exception as exc:     # noqa: BLE001 -- whatever went wrong, the computed result must not be lost
         # the result of this call is already computed: a lane that cannot be built is no lane -- but say so once
         warnings.warn("elasticdeform_amd: no repeat-call lane for this signature (%s: %s)" % (type(exc).__name__, exc),
                       RuntimeWarning, stacklevel=3)
@@ -614,6 +669,9 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
 
         stream = _stream(device)
         gflags = _flags | dflag | _lib.FLAG_ZERO_GRADIENT | _box_flag_gradient(displacement, df, device, stream)
+        if _grad_accumulation == 'float':
+            # floating-point atomics in the array's own type (set_gradient_accumulation): the exact kernel's scatter
+            gflags = (gflags & ~(_lib.FLAG_FAST | _lib.FLAG_AUTO)) | _lib.FLAG_EXACT
         if _lib.deform(True, [_desc(x) for x in dXs], _desc(df), plan.output_offset,
                        [_desc(dy) for dy in dYd], plan.axis, plan.order, plan.mode, plan.cval,
                        plan.inverse_affine, gflags | (_lib.FLAG_FAST if any(direct) else 0),
