@@ -41,8 +41,9 @@ Extra objects on the JSON line:
                 (edhip_profile_dominant); the larger one is reported (today K2), HBM-bound.
                 achieved = algorithmic bytes per launch (8 B/voxel: 4 read + 4 written,
                 SURVEY.md 8d) / average launch duration; peak 8 TB/s.  `traffic` = HBM bytes per
-                launch from the PMC passes recorded in profiles/hbm_traffic.json, reported only
-                when that file was measured for the kernel named here (stamped with its commit).
+                launch from the PMC passes recorded in profiles/hbm_traffic.json (L2 <-> Infinity Cache /
+                HBM requests by size: profiles/r06_traffic_calibration.txt), reported only when that file
+                was measured on the kernel sources of this tree (stamped with its commit).
   north_star_kernel   the same numbers for K1, the kernel BASELINE.json's 50 % target is quoted on;
                 `frac_read_only` prices it on the READ bytes alone (4 B/voxel), the literal
                 "HBM-read roofline" of north_star.
@@ -619,6 +620,11 @@ def main():
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4),
                 "traffic": t.get("bytes_per_launch") if t else None,
+                # (bytes between the L2s and the Infinity Cache / HBM, read + written, from the request-size counters:
+                # profiles/r06_traffic_calibration.txt; Infinity-Cache hits are included)
+                "traffic_read": t.get("read_bytes") if t else None,
+                "traffic_written": t.get("write_bytes") if t else None,
+                "l2_hit_rate": t.get("l2_hit_rate") if t else None,
                 "traffic_measured_at": t.get("commit") if t else None,
                 # (PMC passes of the same stamp: SQ_ACTIVE_INST_VALU x 4 / SIMDs / busy cycles, SQ_LDS_IDX_ACTIVE / CUs / busy cycles)
                 "valu_busy": t.get("valu_busy") if t else None,

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, one counter per pass) -> profiles/hbm_traffic.json.
-usage: hbm_traffic.py <pmc dir> <commit>.  Raw counters are in KB per dispatch.  Calibration
-(profiles/r01_traffic_calibration.txt): FETCH_SIZE counts 64-byte requests at face value and reports
-half of the bytes of wide streams; K1 reads its volume with 16-byte lanes in 64-byte runs (face value:
-rd16_runs), K2 reads dY with 4-byte lanes in 64-byte rows, which the counter reports at HALF
-(profiles/r02_traffic_calibration.txt, rd4_k2rows): the missing half of the 64 MiB of dY is added
-back for K2 (`fetch_correction_kb`).  WRITE_SIZE is exact for full streams and 32-byte runs."""
+"""Fabric-side traffic of the L2s per launch (rocprofv3 --pmc, one counter group per pass: tools/pmc_k1.sh) -> profiles/hbm_traffic.json.
+usage: hbm_traffic.py <pmc dir> <commit>.
+
+    read bytes  = 128 x TCC_EA0_RDREQ_128B + 64 x TCC_EA0_RDREQ_64B + 32 x TCC_EA0_RDREQ_32B
+    write bytes = 64 x TCC_EA0_WRREQ_64B + 32 x (TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B)
+
+calibrated on known byte counts in the kernels' own access patterns (profiles/r06_traffic_calibration.txt, tools/ubench_traffic.hip):
+every read pattern of K1z / K2 issues 128-byte requests, which FETCH_SIZE (= requests x 64 B) reports at HALF -- the guide's gfx950
+correction -- and the rounds 1-5 stamps took "64-byte runs" at face value, i.e. they under-reported K1's reads by 2x.  These are
+bytes between the L2s and the Infinity Cache / HBM: re-reads that hit the 256 MiB Infinity Cache are included.  The L2 hit rate
+(TCC_HIT / (TCC_HIT + TCC_MISS)) is reported next to them."""
 import collections
 import csv
 import glob
@@ -25,11 +29,14 @@ from bench import kernel_sources_sha16      # noqa: E402  (one list of files for
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+        if r["Counter_Name"] in ("FETCH_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum",
+                                 "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_HIT_sum", "TCC_MISS_sum",
+                                 "SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
                                  "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
             vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/time_k12.py (the bench workload: "
-               "256^3 float32, order 3, mirror, sigma 5), mean per dispatch, KB -> bytes",
+out = {"note": "rocprofv3 --pmc TCC_EA0_RDREQ / WRREQ by request size (separate passes) on tools/time_k12.py (the bench workload: "
+               "256^3 float32, order 3, mirror, sigma 5), mean per dispatch; bytes between the L2s and the Infinity Cache / HBM "
+               "(profiles/r06_traffic_calibration.txt)",
        "algorithmic_bytes_per_launch": 134217728, "kernel_sources_sha16": kernel_sources_sha16(), "kernels": {}}
 def mean(c, k):
     return sum(c[k]) / len(c[k]) if c.get(k) else None
@@ -37,13 +44,15 @@ def mean(c, k):
 
 for tag, key in (("K1", "k1z_tile_kernel<3, false"), ("K2", "hot_grad_kernel<3, false")):
     for name, c in vals.items():
-        if key in name and c.get("FETCH_SIZE") and c.get("WRITE_SIZE"):
-            fkb = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
-            wkb = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
-            corr = 32768 if tag == "K2" else 0       # KB: the uncounted half of dY (256^3 float32)
-            out["kernels"][tag] = {"kernel": name, "fetch_kb": round(fkb), "fetch_correction_kb": corr,
-                                   "write_kb": round(wkb),
-                                   "bytes_per_launch": int((fkb + corr + wkb) * 1024), "commit": commit}
+        if key in name and c.get("TCC_EA0_RDREQ_sum") and c.get("TCC_EA0_WRREQ_sum"):
+            rd = 128.0 * mean(c, "TCC_EA0_RDREQ_128B_sum") + 64.0 * mean(c, "TCC_EA0_RDREQ_64B_sum") + 32.0 * mean(c, "TCC_EA0_RDREQ_32B_sum")
+            wr = 64.0 * mean(c, "TCC_EA0_WRREQ_64B_sum") + 32.0 * (mean(c, "TCC_EA0_WRREQ_sum") - mean(c, "TCC_EA0_WRREQ_64B_sum"))
+            out["kernels"][tag] = {"kernel": name, "read_bytes": int(rd), "write_bytes": int(wr),
+                                   "bytes_per_launch": int(rd + wr), "commit": commit}
+            if mean(c, "FETCH_SIZE"):
+                out["kernels"][tag]["fetch_size_kb_raw"] = round(mean(c, "FETCH_SIZE"))
+            if mean(c, "TCC_HIT_sum") is not None and mean(c, "TCC_MISS_sum") is not None:
+                out["kernels"][tag]["l2_hit_rate"] = round(mean(c, "TCC_HIT_sum") / (mean(c, "TCC_HIT_sum") + mean(c, "TCC_MISS_sum")), 3)
             # busy fractions: GRBM_GUI_ACTIVE is summed over the 8 XCDs -> cycles of the launch = / 8;
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, SQ_LDS_IDX_ACTIVE cycles over the 256 CUs
             gui = mean(c, "GRBM_GUI_ACTIVE")

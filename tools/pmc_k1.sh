@@ -9,6 +9,9 @@ run() { ITERS=6 rocprofv3 --kernel-trace --pmc $2 -d $OUT/$1 -o p --output-forma
 run a "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM"
 run b "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
 run g "GRBM_GUI_ACTIVE GRBM_COUNT"
+# fabric-side bytes of the L2s (profiles/r06_traffic_calibration.txt): requests by size, not FETCH_SIZE (= requests x 64 B whatever their size)
+run r "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum"
+run w "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
+run h "TCC_HIT_sum TCC_MISS_sum"
 run f "FETCH_SIZE"
-run w "WRITE_SIZE"
 python $R/tools/pmc_summary.py $OUT > $OUT/summary.txt

@@ -71,6 +71,38 @@ __global__ void rd4_k2rows(const float* buf, size_t nrows, float* sink)
     }
     if (acc == -1.f) *sink = acc;
 }
+// read: K1z's staging (round 6).  buf is [rows][256 floats]; a wave-instruction is ONE global_load_lds of 16 bytes per
+// lane: CPR lanes cover a run of CPR * 16 bytes of a row (64-byte runs: 16 rows per instruction, 192-byte runs: 5 rows,
+// 60 lanes), consecutive runs of an instruction are one row (1 KiB) apart.  SHIFT: the second copy of the box, the same
+// runs one element (4 bytes) further -- a 16-byte lane then straddles two 16-byte chunks and the run two 64-byte lines.
+// Every run is requested once per copy; coverage per row: 256 floats (CPR 4), 240 of 256 (CPR 12).
+template <int CPR, bool SHIFT>
+__global__ void lds16_box(const float* buf, size_t nrows, float* sink)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 256];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int RW = 64 / CPR;
+    const int lr = l / CPR, q = l - lr * CPR;
+    constexpr int NCH = 256 / (CPR * 4);
+    size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t nitems = (nrows / RW) * NCH;
+    float* dst = lds + w * 512;
+    for (size_t it = wave; it < nitems; it += nwaves) {
+        const size_t rg = it / NCH, ch = it % NCH;
+        const float* g = buf + (rg * RW + lr) * 256 + ch * (CPR * 4) + q * 4;
+        if (lr < RW) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            if (SHIFT)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 1),
+                                                 (__attribute__((address_space(3))) void*)(dst + 256), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lds[threadIdx.x] == -1.f) *sink = lds[threadIdx.x];
+}
 int main()
 {
     const size_t bytes = (size_t)1 << 30;       // 1 GiB: larger than the 256 MiB Infinity Cache
@@ -82,6 +114,10 @@ int main()
     hipLaunchKernelGGL(rd16_runs, dim3(4096), dim3(256), 0, 0, buf, n16, 1031, sink);
     hipLaunchKernelGGL(rd4_k2rows<0>, dim3(4096), dim3(256), 0, 0, buf, nf / 256, sink);
     hipLaunchKernelGGL(rd4_k2rows<1>, dim3(4096), dim3(256), 0, 0, buf, nf / 256, sink);
+    hipLaunchKernelGGL((lds16_box<4, false>), dim3(4096), dim3(256), 0, 0, buf, nf / 256 - 1, sink);
+    hipLaunchKernelGGL((lds16_box<4, true>), dim3(4096), dim3(256), 0, 0, buf, nf / 256 - 1, sink);
+    hipLaunchKernelGGL((lds16_box<12, false>), dim3(4096), dim3(256), 0, 0, buf, nf / 256 - 1, sink);
+    hipLaunchKernelGGL((lds16_box<12, true>), dim3(4096), dim3(256), 0, 0, buf, nf / 256 - 1, sink);
     hipLaunchKernelGGL(wr4_stream, dim3(4096), dim3(256), 0, 0, buf, nf);
     hipLaunchKernelGGL(wr4_runs32, dim3(4096), dim3(256), 0, 0, buf, nf);
     CK(hipDeviceSynchronize());
