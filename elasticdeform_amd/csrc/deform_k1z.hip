@@ -692,6 +692,7 @@ struct ZFast {
     int rcol_bytes, out_y, out_x;
     int kz0, ky0, kx0;        // window start = floor part of the coordinate + k: crop offset - order / 2 (affine: - order / 2)
     int io16, nsteps, deal;
+    int dbg;                  // profiling build: ablation bits (1 << 17 no gather, 1 << 18 no staging, 1 << 20 no stores)
     double aff[12];           // AFFINE: inverse map, the crop offset folded into column 3
 };
 
@@ -839,7 +840,8 @@ __device__ __forceinline__ void k1z_fast_body(const ZFast& a, const int vblock)
         const int tl = tn < ntile ? tn : ti;
         const zv8i rnv = *(rec0 + (size_t)tl * tile_step);
         const ZEnt zn[2] = {k1z_entry(zt, (sp.tz0 + tl) * kT + wave), k1z_entry(zt, (sp.tz0 + tl) * kT + wave + 4)};
-        stage(rc, vol + (STEPS ? steps[0] : 0));
+        if (!ED_DBG(a.dbg, 1 << 18))
+            stage(rc, vol + (STEPS ? steps[0] : 0));
         if (tn < ntile) {
             rn = zrec_unpack(rnv);
             tile_coords(tn, rn, zn, nxt);
@@ -852,9 +854,11 @@ __device__ __forceinline__ void k1z_fast_body(const ZFast& a, const int vblock)
             zdma_barrier();       // B2: retires this wave's copies (vmcnt) and everyone's
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float val = k1z_voxel<ORDER>(smem, cur.addr[i], cur.frac[i], rc.pitch, rc.plane);
+                const float val = ED_DBG(a.dbg, 1 << 17) ? cur.frac[i][0] + cur.frac[i][1] + cur.frac[i][2] + __int_as_float(cur.addr[i])
+                                                         : k1z_voxel<ORDER>(smem, cur.addr[i], cur.frac[i], rc.pitch, rc.plane);
                 // streaming store (a tile writes 32-byte row segments)
-                zstore_out<OUT16>(img, (STEPS ? steps[2 * ss + 1] : 0) + ozoff + (long long)(4 * i) * img_sz, val, io16);
+                if (!ED_DBG(a.dbg, 1 << 20) || val == 123.456f)
+                    zstore_out<OUT16>(img, (STEPS ? steps[2 * ss + 1] : 0) + ozoff + (long long)(4 * i) * img_sz, val, io16);
             }
             zlds_barrier();       // B1: every gather of this tile is done with the box
         }
@@ -1396,6 +1400,7 @@ hipError_t launch_k1z(const HotGeom& hg, const ZGeom& zg, int order, size_t lds,
     zf.kx0 = (hg.has_affine ? 0 : hg.off[2]) - H;
     zf.io16 = hg.io16;
     zf.nsteps = (int)hg.nsteps;
+    zf.dbg = hg.dbg;
     // chunks of a few rows of strips; small launches: smaller chunks, so that every XCD gets some
     zf.deal = 4 * hg.tiles[2];
     while (zf.deal > 1 && zg.total_strips < 16 * zf.deal)
