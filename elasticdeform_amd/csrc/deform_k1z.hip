@@ -306,28 +306,42 @@ __global__ __launch_bounds__(kGeoBlock) void k1z_geo_kernel(const GridGeom g, co
     }
     ZTICK(4);
     // ---- R of the patch: contraction over y and x (deform.c:693-758, two of its three axes) --------
-    {
-        double* rg = const_cast<double*>(zg.r) + (int64_t)sample * zg.r_bstride;
-        for (int e = tid; e < 64 * ncpz * 3 && !ED_DBG(hg.dbg, 1 << 25); e += kGeoBlock) {
-            const int col = e / (ncpz * 3), r = e - col * (ncpz * 3);
+    // A thread keeps ONE column's axis entries in registers and computes every fourth (k_z, component) of it (the
+    // entries used to be re-read from LDS per output); the patch's R leaves through LDS in rows of 8 columns x ncp_z x 4
+    // doubles, which are contiguous in the global layout (it left as 960 scattered 8-byte stores per workgroup).
+    if (!ED_DBG(hg.dbg, 1 << 25)) {
+        const int col = tid & 63;
+        const AxTab ay = sAx[col >> 3];
+        const AxTab ax = sAx[8 + (col & 7)];
+        int rowoff[4];
+#pragma unroll
+        for (int ly = 0; ly < 4; ++ly)
+            rowoff[ly] = ay.idx[ly] * ncpx;
+        for (int r = tid >> 6; r < ncpz * 3; r += kGeoWaves) {
             const int kz = r / 3, h = r - kz * 3;
-            const AxTab& ay = sAx[col >> 3];
-            const AxTab& ax = sAx[8 + (col & 7)];
             const double* gp0 = sG + (h * ncpz + kz) * nyx;
             double acc = 0.0;
 #pragma unroll
             for (int ly = 0; ly < 4; ++ly) {
-                const double* row = gp0 + ay.idx[ly] * ncpx;
+                const double* row = gp0 + rowoff[ly];
                 double t = ax.w[0] * row[ax.idx[0]];
 #pragma unroll
                 for (int lx = 1; lx < 4; ++lx)
                     t = fma(ax.w[lx], row[ax.idx[lx]], t);
                 acc = fma(ay.w[ly], t, acc);
             }
-            sR[e] = acc;
-            const int oy = ty * kT + (col >> 3), ox = tx * kT + (col & 7);
+            sR[col * (ncpz * 3) + r] = acc;
+        }
+        __syncthreads();
+        double* rg = const_cast<double*>(zg.r) + (int64_t)sample * zg.r_bstride;
+        const int rowlen = 8 * 4 * ncpz;                      // doubles of a row of 8 columns in the global layout
+        for (int e = tid; e < 8 * rowlen; e += kGeoBlock) {
+            const int py = e / rowlen, j = e - py * rowlen;
+            const int px = j / (4 * ncpz), jj = j - px * (4 * ncpz);
+            const int kz = jj >> 2, h = jj & 3;
+            const int oy = ty * kT + py, ox = tx * kT + px;
             if (oy < hg.out_len[1] && ox < hg.out_len[2])
-                rg[((int64_t)oy * hg.out_len[2] + ox) * (4 * ncpz) + kz * 4 + h] = acc;
+                rg[((int64_t)oy * hg.out_len[2] + ox) * (4 * ncpz) + jj] = h < 3 ? sR[(py * 8 + px) * (ncpz * 3) + kz * 3 + h] : 0.0;
         }
     }
     if (zg.tables_only)
