@@ -475,18 +475,26 @@ hipError_t launch_grad_order(const HotGeom& hg, unsigned nblk, size_t lds, hipSt
     }
 #endif
     // (a cell block beyond 64 KiB -- the "huge" boxes of strongly deformed volumes, two workgroups per CU -- needs the
-    // kernel's dynamic-LDS limit raised; per call: the attribute belongs to the device the call runs on)
-    auto go = [&](auto kern, bool&) -> hipError_t {
+    // kernel's dynamic-LDS limit raised: once per kernel and DEVICE (the attribute belongs to the device's copy of the
+    // function); not per call, so that a call captured into a HIP graph makes no attribute call once the geometry has
+    // run outside a capture)
+    auto go = [&](auto kern, unsigned& raised_on) -> hipError_t {
         if (lds > 64 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess)
-                return e;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const unsigned bit = 1u << (dev & 31);
+            if (!(__atomic_load_n(&raised_on, __ATOMIC_RELAXED) & bit)) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess)
+                    return e;
+                __atomic_fetch_or(&raised_on, bit, __ATOMIC_RELAXED);
+            }
         }
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(kBlock), lds, stream, hg);
         return hipGetLastError();
     };
-    bool raised[4] = {false, false, false, false};
+    static unsigned raised[4] = {0, 0, 0, 0};        // (per ORDER: this is a function template)
     if (hg.io16) {
         if constexpr (ORDER <= 3) {
             if (hg.has_affine)

@@ -1627,6 +1627,10 @@ def test_repeated_calls_with_spill_feedback_stay_identical():
         sl = (slice(20, 52), slice(24, 56), slice(30, 62))
         ref = orc.deform_grid(X, disp, crop=sl, **kw)
         np.testing.assert_allclose(first.cpu().numpy()[sl], ref, **F32_TOL)
+        # the gradient of the LAST call -- by now on the largest boxes the feedback picks (round 6: 64 KiB of cells once
+        # a tenth of the tiles is beyond the large ones) -- against the oracle
+        _f32_grad_check(g.cpu().numpy(), orc.deform_grid_gradient(dY, disp, **kw),
+                        orc.deform_grid_gradient(dY.astype(np.float64), disp, **kw))
 
 
 def test_channel_last_layouts_are_relaid_out_and_match_the_oracle():
