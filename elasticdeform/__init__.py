@@ -12,5 +12,5 @@ There is no CPU fallback behind this name either.
 """
 from elasticdeform_amd import (deform_grid, deform_grid_gradient, deform_random_grid,  # noqa: F401
                                deform_grid_batch, deform_grid_gradient_batch, set_arithmetic,
-                               set_reduced_precision, set_crop_identity, set_gradient_accumulation,
+                               set_reduced_precision, set_crop_identity, set_gradient_accumulation, set_field_strength,
                                release_scratch, __version__)

@@ -16,7 +16,8 @@ batch of samples with one control grid each.
 """
 from .deform_grid import (deform_grid, deform_grid_gradient, deform_random_grid,  # noqa: F401
                           deform_grid_batch, deform_grid_gradient_batch, set_arithmetic,
-                          set_reduced_precision, set_crop_identity, set_gradient_accumulation)
+                          set_reduced_precision, set_crop_identity, set_gradient_accumulation,
+                          set_field_strength)
 
 from ._lib import release_scratch  # noqa: F401,E402  (frees the library's cached device scratch)
 

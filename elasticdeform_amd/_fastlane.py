@@ -228,7 +228,7 @@ class Lane(object):
                     _lib.raise_for_status(st, ebuf)
                 for i, f in enumerate(self.filters):
                     if f is not None:
-                        res[i], st = f.run(L, res[i], self.flags & ~_lib.FLAG_RAW_DISPLACEMENT, stream, ebuf)
+                        res[i], st = f.run(L, res[i], self.flags & ~(_lib.FLAG_RAW_DISPLACEMENT | _lib.FLAG_STRONG_FIELD), stream, ebuf)
                         if st:
                             _lib.raise_for_status(st, ebuf)
             else:
@@ -241,7 +241,7 @@ class Lane(object):
                 for i, f in enumerate(self.filters):
                     x = xs[i]
                     if f is not None:
-                        x, st = f.run(L, x, self.flags & ~_lib.FLAG_RAW_DISPLACEMENT, stream, ebuf)
+                        x, st = f.run(L, x, self.flags & ~(_lib.FLAG_RAW_DISPLACEMENT | _lib.FLAG_STRONG_FIELD), stream, ebuf)
                         if st:
                             _lib.raise_for_status(st, ebuf)
                         keep.append(x)

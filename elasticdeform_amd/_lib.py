@@ -19,6 +19,7 @@ FLAG_AUTO, FLAG_EXACT, FLAG_FAST = 0, 1, 2
 FLAG_RAW_DISPLACEMENT = 4      # edhip_deform prefilters the control grid itself (<= 4096 points)
 FLAG_GRID_STAYS = 64           # with RAW_DISPLACEMENT: the raw grid of the previous RAW call on the stream, unchanged
 FLAG_SCRATCH_INPUT = 128       # edhip_spline_filter_axes: in place on the input, the last pass input -> output
+FLAG_STRONG_FIELD = 256        # forward hint: a strong displacement field -> the z-walk route for every geometry it supports
 ERR_UNSUPPORTED = 5             # EDHIP_ERR_UNSUPPORTED: legal, outside this build's limits (nothing was launched)
 FLAG_KEEP_BOXES = 8            # forward: leave the tiles' bounding boxes for the gradient call that follows
 FLAG_USE_BOXES = 16            # gradient: same displacement contents and geometry as that forward call

@@ -1706,7 +1706,21 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                 [[maybe_unused]] const bool k1_new = !GRAD && ORDER <= 3 && tg.strip_tiles <= 8 && !ed_env("EDHIP_K1_OLD") &&
                                                      !ed_env("EDHIP_RECORDS");
                 // round 6: strips along z on R tables (deform_k1z.hip) for every grid its geometry kernel holds in LDS
-                const bool k1z = k1_new && !wide && k1z_supported(g) && ve.nsteps <= (int64_t)kK1zMaxSteps && !ed_env("EDHIP_K1_R5");
+#ifdef EDHIP_NO_K1Z          // (A/B build of the shipped library without the z-walk route: tools/abl_k1_size.sh)
+                const bool k1z = false;
+#else
+                // Which forward kernel (a function of the call's arguments alone: the two routes differ in the last bits).
+                // Measured on shipped builds (profiles/r06_k1_route_sweep.txt): on mild fields the z-walk wins where the
+                // x-strip kernel stumbles -- single volumes whose z and y extents are multiples of 256 (256^3 +7 %,
+                // 512 x 256 x 256 +18 %) -- and loses elsewhere (128^3 -50 %, 192^3 -24 %, 288^3 -10 %, batches -7 ... -26 %: its
+                // geometry kernel costs 20-35 us per call and its tables are per sample); on strong fields (sigma 15) it wins
+                // everywhere by 5-35 %.  The library cannot see the field's strength without a host round trip: the caller
+                // can say so (EDHIP_FLAG_STRONG_FIELD).
+                const bool z_shape = nb == 1 && g.out_len[0] % 256 == 0 && g.out_len[1] % 256 == 0 && g.in_len[0] % 256 == 0 &&
+                                     g.in_len[1] % 256 == 0;
+                const bool z_pick = ed_env("EDHIP_K1Z_ALWAYS") || (batch && batch->strong) || z_shape;
+                const bool k1z = k1_new && !wide && z_pick && k1z_supported(g) && ve.nsteps <= (int64_t)kK1zMaxSteps && !ed_env("EDHIP_K1_R5");
+#endif
                 ZGeom zg;
                 memset(&zg, 0, sizeof(zg));
                 SideLane* zside = nullptr;

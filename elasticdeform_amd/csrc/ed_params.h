@@ -89,6 +89,7 @@ struct DeformBatch {
     int box_mode = 0;               // 1: EDHIP_FLAG_KEEP_BOXES (forward), 2: EDHIP_FLAG_USE_BOXES (gradient)
     const void* disp_id = nullptr;  // the caller's displacement pointer (identity of the control grid)
     int raw = 0;                    // EDHIP_FLAG_RAW_DISPLACEMENT was set
+    int strong = 0;                 // EDHIP_FLAG_STRONG_FIELD was set
     // EDHIP_FLAG_ZERO_GRADIENT: the dense block to clear before the scatter; the tile path does it in its
     // tables launch and sets zero_done (left false: nothing has been launched that reads or adds to it)
     char* zero_ptr = nullptr;

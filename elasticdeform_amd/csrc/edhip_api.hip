@@ -480,6 +480,7 @@ int edhip_deform(int gradient, int ninputs, const edhip_array* inputs,
                            : ((gradient && (flags & EDHIP_FLAG_USE_BOXES)) ? 2 : 0);
             one.disp_id = displacement->data;
             one.raw = (flags & EDHIP_FLAG_RAW_DISPLACEMENT) ? 1 : 0;
+            one.strong = (flags & EDHIP_FLAG_STRONG_FIELD) ? 1 : 0;
             one.gridpf = gpf_in_tables ? &gpf : nullptr;
             if (!one.gridpf && grid_now() != hipSuccess)
                 return fail(err, errlen, EDHIP_ERR_DEVICE, "grid prefilter launch");
@@ -570,6 +571,7 @@ int edhip_deform_batch(int gradient, int nbatch, const edhip_array* inputs,
         db.box_mode = (!gradient && (flags & EDHIP_FLAG_KEEP_BOXES)) ? 1
                       : ((gradient && (flags & EDHIP_FLAG_USE_BOXES)) ? 2 : 0);
         db.disp_id = displacements[0].data;
+        db.strong = (flags & EDHIP_FLAG_STRONG_FIELD) ? 1 : 0;
         const bool candidate = nbatch >= 2 && naxis == 3 && axis && !(flags & (EDHIP_FLAG_EXACT | EDHIP_FLAG_RAW_DISPLACEMENT)) &&
                                (inputs[0].dtype == EDHIP_F32 || inputs[0].dtype == EDHIP_F64) &&
                                outputs[0].dtype == inputs[0].dtype && inputs[0].ndim == outputs[0].ndim &&

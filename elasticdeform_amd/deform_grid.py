@@ -93,6 +93,33 @@ def set_crop_identity(strict):
     return prev
 
 
+_FIELD_STRENGTH = ('auto', 'strong')
+_field_strength = os.environ.get('EDHIP_FIELD_STRENGTH', 'auto').lower()
+if _field_strength not in _FIELD_STRENGTH:
+    _field_strength = 'auto'
+
+
+def set_field_strength(kind):
+    """A performance hint for the forward kernels of float32 volumes with three deformed axes (results agree to float32
+    rounding either way).  'strong' says the displacement fields are strong -- a displacement gradient of ~0.15 per voxel
+    and more, e.g. sigma >= 10 on a 5^3 grid over 256^3, or the reference README's ``sigma=25, points=3`` on a 200 x 300
+    image: the z-walk kernels (tiles split in halves, wide row pitches) then serve every geometry they support and are
+    5-35 % faster on such fields; on mild fields they are 5-50 % slower than the default choice for small volumes and
+    batches (profiles/r06_k1_route_sweep.txt).  'auto' (default) picks by the volume's shape alone.  The library never
+    picks by looking at earlier calls: a call's bits depend on its arguments and on this setting only.  Returns the
+    previous value."""
+    global _field_strength
+    if kind not in _FIELD_STRENGTH:
+        raise ValueError("field strength must be one of %s" % list(_FIELD_STRENGTH))
+    prev = _field_strength
+    _field_strength = kind
+    return prev
+
+
+def _route_flags():
+    return _lib.FLAG_STRONG_FIELD if _field_strength == 'strong' else 0
+
+
 _GRAD_ACCUMULATION = ('fixed', 'float')
 _grad_accumulation = os.environ.get('EDHIP_GRAD_ACCUMULATION', 'fixed').lower()
 if _grad_accumulation not in _GRAD_ACCUMULATION:
@@ -430,7 +457,7 @@ def _lane_lookup(gradient, X, displacement, order, mode, cval, crop, prefilter, 
     if _strict_crop or (gradient and _grad_accumulation != 'fixed'):
         return None, None           # (the lanes are built for the default routes)
     sig = _fastlane.signature(gradient, X, displacement, order, mode, cval, crop, prefilter, axis,
-                              X_shape, _flags)
+                              X_shape, _flags | _route_flags())
     if sig is None:
         return None, None
     lane = _fastlane.lookup(sig)
@@ -447,7 +474,7 @@ def _lane_build(sig, gradient, xs, dd, plan, prefilter, X_shape, crop):
         _fastlane.remember(sig, False)
         return
     try:
-        lane = _fastlane.Lane(_this, gradient, xs, dd, plan, prefilter, X_shape, _flags, crop)
+        lane = _fastlane.Lane(_this, gradient, xs, dd, plan, prefilter, X_shape, _flags | _route_flags(), crop)
     except Exception as exc:     # noqa: BLE001 -- whatever went wrong, the computed result must not be lost
         # the result of this call is already computed: a lane that cannot be built is no lane -- but say so once
         warnings.warn("elasticdeform_amd: no repeat-call lane for this signature (%s: %s)" % (type(exc).__name__, exc),
@@ -591,7 +618,7 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
         fast16 = _lib.FLAG_FAST if any(direct) else 0
         if _lib.deform(False, in_descs, _desc(df), plan.output_offset,
                        [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
-                       plan.inverse_affine, _flags | dflag | bflag | fast16, stream, prepared=_prepared(plan, len(Xd)),
+                       plan.inverse_affine, _flags | dflag | bflag | fast16 | _route_flags(), stream, prepared=_prepared(plan, len(Xd)),
                        may_decline=bool(fast16)) != 0:
             # the library declined the 16-bit stores: float32 outputs, narrowed by a cast like the other route
             outs = [torch.empty(o.shape, dtype=torch.float32, device=device) if d else o for o, d in zip(outs, direct)]
@@ -599,7 +626,7 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
             direct = [False] * len(direct)
             _lib.deform(False, in_descs, _desc(df), plan.output_offset,
                         [_desc(o) for o in outs], plan.axis, plan.order, plan.mode, plan.cval,
-                        plan.inverse_affine, _flags | dflag | bflag, stream, prepared=_prepared(plan, len(Xd)))
+                        plan.inverse_affine, _flags | dflag | bflag | _route_flags(), stream, prepared=_prepared(plan, len(Xd)))
         outs = [_narrow(o, xs) if w is not None else o for o, xs, w in zip(outs, Xs_dev, wide)]
         res = [_from_device(o, x) for o, x in zip(outs, Xs)]
         if sig is not None:
@@ -772,7 +799,7 @@ def deform_grid_batch(X, displacements, order=3, mode='constant', cval=0.0, crop
         _box_owner[(device.index, stream)] = None
         _lib.deform_batch_strided(False, B, xd, xs, dd0, ds, plan.output_offset, od, os_, ax, o,
                                   int(plan.mode[0]), float(plan.cval[0]), plan.inverse_affine,
-                                  _flags | (_lib.FLAG_KEEP_BOXES if ident is not None else 0), stream)
+                                  _flags | _route_flags() | (_lib.FLAG_KEEP_BOXES if ident is not None else 0), stream)
         return _from_device(out, X)
 
 

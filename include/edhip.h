@@ -168,7 +168,17 @@ enum edhip_flags {
      * it and the last one writes `output` (instead of: input -> output, then in place on the output).  With a
      * float32 input and an EDHIP_F16 / EDHIP_BF16 output the chain is computed in float32 and only its result is
      * rounded to 16 bits (the last pass narrows on its way out: 6 instead of 8 bytes per sample, and no cast pass). */
-    EDHIP_FLAG_SCRATCH_INPUT = 128
+    EDHIP_FLAG_SCRATCH_INPUT = 128,
+    /* edhip_deform / edhip_deform_batch*, forward, float32 volumes, 3 deformed axes, orders 1-3: a HINT that the
+     * displacement field is strong (displacement gradient of ~0.15 per voxel and more: sigma >= 10 on a 5^3 grid over
+     * 256^3, the reference README's own example).  The forward call then takes the z-walk route (csrc/deform_k1z.hip:
+     * per-call geometry kernel, tiles split in halves, four row pitches) for EVERY geometry that route supports; without
+     * the flag only single volumes whose z and y extents are multiples of 256 take it -- where it is measured faster
+     * on mild fields too (profiles/r06_k1_route_sweep.txt) -- and everything else runs on the x-strip kernel
+     * (csrc/deform_k1.hip), which is 5-50 % faster on mild fields and 5-35 % slower on strong ones.  The route is a
+     * function of the call's arguments alone, never of earlier calls; the two routes agree to float32 rounding
+     * (coordinates differ by ~1e-15), each is bit-reproducible. */
+    EDHIP_FLAG_STRONG_FIELD = 256
 };
 
 /* strided N-d array in device memory: the POD stand-in for PyArrayObject* */

@@ -45,8 +45,12 @@ for case in range(ncases):
         kw["crop"] = tuple(crop)
     if rng.integers(0, 3) == 0:
         kw["affine"] = np.eye(3, 4) + rng.standard_normal((3, 4)) * 0.08
-    desc = "case %d: B=%d shape=%s pts=%s o%d %s sigma=%g %s" % (
-        case, B, full, pts, order, mode, sigma, {k: v for k, v in kw.items() if k not in ("order", "mode")})
+    # every other case on the z-walk forward route (EDHIP_FLAG_STRONG_FIELD: csrc/deform_k1z.hip serves the geometry
+    # wherever it can), the others on the default routing
+    strong = bool(rng.integers(0, 2))
+    ed.set_field_strength("strong" if strong else "auto")
+    desc = "case %d%s: B=%d shape=%s pts=%s o%d %s sigma=%g %s" % (
+        case, " [strong]" if strong else "", B, full, pts, order, mode, sigma, {k: v for k, v in kw.items() if k not in ("order", "mode")})
     try:
         if B == 1:
             X = rng.random(full).astype(np.float32)
