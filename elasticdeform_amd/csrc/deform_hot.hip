@@ -243,9 +243,9 @@ ED_UNROLL(ED_K2_U1)
         if (given && !any) {
             // an empty box may be a stale one: keep going with zero cells -- every live voxel then
             // fails the window test below and is scattered directly
-            bhi[0] = b0[0] - 1;
-            bhi[1] = b0[1] - 1;
-            bhi[2] = b0[2] - 1;
+            // (canonical empty box: the stored one may hold the reduction's start values, and `start - INT_MAX` wraps)
+            b0[0] = b0[1] = b0[2] = 0;
+            bhi[0] = bhi[1] = bhi[2] = -1;
             any = true;
         }
         const int ext[3] = {bhi[0] - b0[0] + 1, bhi[1] - b0[1] + 1, bhi[2] - b0[2] + 1};

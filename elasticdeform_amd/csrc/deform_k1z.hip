@@ -1369,6 +1369,9 @@ hipError_t launch_k1z_geo(const GridGeom& g, const HotGeom& hg, const ZGeom& zg,
     }
     hipLaunchKernelGGL(k1z_geo_kernel, dim3((unsigned)(hg.tiles[1] * hg.tiles[2]) + fill, (unsigned)nbatch), dim3(kGeoBlock),
                        k1z_geo_lds_bytes(g, hg), stream, g, hg, zg, gp);
+    if (ed_env("EDHIP_GEO_TWICE"))        // (profiling build: the launch again, warm -- what of its 34 us is a cold instruction cache?)
+        hipLaunchKernelGGL(k1z_geo_kernel, dim3((unsigned)(hg.tiles[1] * hg.tiles[2]) + fill, (unsigned)nbatch), dim3(kGeoBlock),
+                           k1z_geo_lds_bytes(g, hg), stream, g, hg, zg, gp);
     return hipGetLastError();
 }
 

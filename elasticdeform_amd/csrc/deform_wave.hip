@@ -743,6 +743,16 @@ __global__ __launch_bounds__(64, OCC) void wave_grad_kernel(const HotGeom hg, co
                 lo[h] = uni(bx[h]);
                 hi[h] = uni(bx[3 + h]);
             }
+            // An EMPTY handed-over box (every voxel of the forward tile mapped to the constant) is stored with the
+            // reduction's start values, INT_MAX / INT_MIN.  It may be stale -- under THIS call's grid the tile can have
+            // live voxels, whose windows are tested against the box below: `start - INT_MAX` wraps for a window start of
+            // -2 (orders 4 / 5 at the array's corner), the test then passed on all three axes and the voxel's taps went
+            // to cells outside LDS, i.e. nowhere (found by tests/fuzz/fuzz_hot.py seed 501, round 6; there since round 3).
+            // Canonical empty box instead: every live voxel fails the window test and scatters directly.
+            if (!(hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2])) {
+                lo[0] = lo[1] = lo[2] = 0;
+                hi[0] = hi[1] = hi[2] = -1;
+            }
         } else
             row_box<ORDER, AFFINE>(hg, hp, rw, qc, xt, ox_tile, kT, lo, hi);
         CellLayout cl;

@@ -48,6 +48,8 @@ for case in range(ncases):
     # every other case on the z-walk forward route (EDHIP_FLAG_STRONG_FIELD: csrc/deform_k1z.hip serves the geometry
     # wherever it can), the others on the default routing
     strong = bool(rng.integers(0, 2))
+    if os.environ.get("FUZZ_FIELD_STRENGTH"):          # (debugging aid: the same cases with the route forced)
+        strong = os.environ["FUZZ_FIELD_STRENGTH"] == "strong"
     ed.set_field_strength("strong" if strong else "auto")
     desc = "case %d%s: B=%d shape=%s pts=%s o%d %s sigma=%g %s" % (
         case, " [strong]" if strong else "", B, full, pts, order, mode, sigma, {k: v for k, v in kw.items() if k not in ("order", "mode")})
@@ -63,6 +65,7 @@ for case in range(ncases):
             got = ed.deform_grid(torch.from_numpy(X).to(dev), dd, **kw).cpu().numpy()
             err = float(np.abs(got - want).max()) if want.size else 0.0
             assert err <= 2e-5, "forward max abs err %.3e" % err
+            disp_fwd = disp
             if rng.integers(0, 4) == 0:
                 disp = rng.standard_normal((3,) + pts) * float(rng.choice([0.5, 5.0, 20.0]))
                 dd.data.copy_(torch.from_numpy(disp))
@@ -74,6 +77,9 @@ for case in range(ncases):
             gs = max(1.0, float(np.abs(truth).max()))
             eref = float(np.abs(gw.astype(np.float64) - truth).max())
             egpu = float(np.abs(gg.astype(np.float64) - truth).max())
+            if os.environ.get("FUZZ_DUMP") and not egpu <= 4 * eref + 4 * np.finfo(np.float32).eps * gs:
+                np.savez(os.environ["FUZZ_DUMP"], X=X, disp_fwd=disp_fwd, disp=disp, dY=dY, truth=truth, gg=gg,
+                         order=order, mode=mode, cval=kw["cval"], prefilter=kw["prefilter"])
             assert egpu <= 4 * eref + 4 * np.finfo(np.float32).eps * gs, \
                 "gradient err vs exact %.3e, reference's own %.3e (scale %.3g)" % (egpu, eref, gs)
         else:

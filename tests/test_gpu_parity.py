@@ -1294,6 +1294,39 @@ def test_gradient_with_stale_forward_boxes():
     _f32_grad_check(got, want, truth)
 
 
+@pytest.mark.parametrize("order", [1, 3, 4, 5])
+def test_gradient_with_stale_empty_forward_boxes(order):
+    """A forward call whose every voxel maps to the constant leaves EMPTY tile boxes (the reduction's start values,
+    INT_MAX / INT_MIN).  Stale, under a mild grid, they must send every live voxel the direct way -- including the
+    voxel at the array's corner, whose window start of -2 (orders 4 / 5) made `start - INT_MAX` wrap past the window
+    test: its taps went to cells outside LDS and were lost (tests/fuzz/fuzz_hot.py seed 501, round 6)."""
+    rng = np.random.default_rng(order)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    shape, pts = (40, 61, 49), (3, 4, 2)
+    X = torch.from_numpy(rng.random(shape).astype(np.float32)).to(dev)
+    D = torch.full((3,) + pts, 200.0, dtype=torch.float64, device=dev)       # every source point far outside: constant
+    dY = torch.from_numpy(rng.random(shape).astype(np.float32)).to(dev)
+    kw = dict(order=order, mode="constant", cval=0.0, prefilter=False)
+    out = ed.deform_grid(X, D, **kw)
+    assert float(out.abs().max()) == 0.0
+    # a mild grid, non-negative so that the corner voxel's source point stays inside the array (window start -H)
+    D.data.copy_(torch.from_numpy(np.abs(rng.standard_normal((3,) + pts)) * 0.4))
+    got = ed.deform_grid_gradient(dY, D, **kw).cpu().numpy()
+    want = orc.deform_grid_gradient(dY.cpu().numpy(), D.cpu().numpy(), **kw)
+    truth = orc.deform_grid_gradient(dY.cpu().numpy().astype(np.float64), D.cpu().numpy(), **kw)
+    _f32_grad_check(got, want, truth)
+    # the corner voxel alone
+    one = torch.zeros_like(dY)
+    one[0, 0, 0] = 1.0
+    Dm = D.clone()
+    D.data.fill_(200.0)
+    ed.deform_grid(X, D, **kw)
+    D.data.copy_(Dm)
+    g1 = ed.deform_grid_gradient(one, D, **kw).cpu().numpy()
+    t1 = orc.deform_grid_gradient(one.cpu().numpy().astype(np.float64), D.cpu().numpy(), **kw)
+    assert abs(float(t1.sum()) - 1.0) < 1e-9 and abs(float(g1.sum()) - 1.0) < 1e-5, (float(t1.sum()), float(g1.sum()))
+
+
 def test_batch_gradient_with_forward_boxes():
     """deform_grid_gradient_batch after deform_grid_batch with the same displacement tensor: the
     filtered grids and the forward call's tile boxes are reused; same gradient as without."""
