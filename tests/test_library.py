@@ -49,6 +49,7 @@ def test_header_constants_match_the_python_binding():
     assert enums["EDHIP_FLAG_ZERO_GRADIENT"] == _lib.FLAG_ZERO_GRADIENT
     assert enums["EDHIP_FLAG_GRID_STAYS"] == _lib.FLAG_GRID_STAYS
     assert enums["EDHIP_FLAG_SCRATCH_INPUT"] == _lib.FLAG_SCRATCH_INPUT
+    assert enums["EDHIP_FLAG_STRONG_FIELD"] == _lib.FLAG_STRONG_FIELD
     flags = [v for k, v in enums.items() if k.startswith("EDHIP_FLAG_") and v]
     assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)     # distinct bits
     assert defs["EDHIP_MAX_DIMS"] == _lib.MAX_DIMS and defs["EDHIP_MAX_AXES"] == _lib.MAX_AXES
