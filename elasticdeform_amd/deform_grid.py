@@ -23,6 +23,7 @@ There is no CPU fallback: without a GPU or without the built library the call ra
 """
 import os
 import sys
+import threading
 
 import warnings
 
@@ -116,8 +117,36 @@ def set_field_strength(kind):
     return prev
 
 
+_tls = threading.local()
+# deform_random_grid knows what the library cannot see without a host round trip: sigma and the control-point spacing.
+# sigma * (points - 1) / (extent - 1) is the displacement gradient's scale; the z-walk kernels win from ~0.18
+# (256^3, 5 points: sigma 10 = 0.157 is a draw, sigma 12.5 = 0.196 and beyond they win -- profiles/r06_k1_route_sweep.txt)
+RANDOM_GRID_STRONG_FROM = 0.18
+
+
+class _random_grid_hint(object):
+    """Context of one deform_random_grid call: the forward call inside it carries EDHIP_FLAG_STRONG_FIELD when the
+    drawn field is strong by construction.  A function of the call's own arguments (sigma, points, shape)."""
+
+    def __init__(self, sigma, points, deform_shape):
+        try:
+            self.strong = any(abs(float(sigma)) * (int(p) - 1) >= RANDOM_GRID_STRONG_FROM * (int(n) - 1)
+                              for p, n in zip(points, deform_shape) if int(n) > 1)
+        except (TypeError, ValueError):
+            self.strong = False
+
+    def __enter__(self):
+        self.prev = getattr(_tls, 'strong', False)
+        _tls.strong = self.strong
+        return self
+
+    def __exit__(self, *exc):
+        _tls.strong = self.prev
+        return False
+
+
 def _route_flags():
-    return _lib.FLAG_STRONG_FIELD if _field_strength == 'strong' else 0
+    return _lib.FLAG_STRONG_FIELD if (_field_strength == 'strong' or getattr(_tls, 'strong', False)) else 0
 
 
 _GRAD_ACCUMULATION = ('fixed', 'float')
@@ -528,8 +557,9 @@ def deform_random_grid(X, sigma=25, points=3, order=3, mode='constant', cval=0.0
     if not isinstance(points, (list, tuple)):
         points = [points] * len(deform_shape)
     displacement = numpy.random.randn(len(deform_shape), *points) * sigma
-    return deform_grid(X, displacement, order, mode, cval, crop, prefilter, axis,
-                       affine, rotate, zoom)
+    with _random_grid_hint(sigma, points, deform_shape):
+        return deform_grid(X, displacement, order, mode, cval, crop, prefilter, axis,
+                           affine, rotate, zoom)
 
 
 def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, prefilter=True,

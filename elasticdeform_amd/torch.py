@@ -93,7 +93,11 @@ def deform_random_grid(X, sigma=25, points=3, order=3, mode='constant', cval=0.0
     _, deform_shape = _host.normalize_axis_list(axis, Xs)
     displacement = random_displacement(len(deform_shape), points, sigma, device=Xs[0].device,
                                        generator=generator)
-    return deform_grid(X, displacement, order, mode, cval, crop, prefilter, axis, affine, rotate, zoom)
+    import importlib
+    _dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    pts = points if isinstance(points, (list, tuple)) else [points] * len(deform_shape)
+    with _dgm._random_grid_hint(sigma, pts, deform_shape):       # (a strong field by construction -> the z-walk route)
+        return deform_grid(X, displacement, order, mode, cval, crop, prefilter, axis, affine, rotate, zoom)
 
 
 class ElasticDeformBatch(torch.autograd.Function):
@@ -132,4 +136,8 @@ def deform_random_grid_batch(X, sigma=25, points=3, axis=None, generator=None, *
     _, deform_shape = _host.normalize_axis_list(axis, [X[0]])
     disp = random_displacement(len(deform_shape), points, sigma, batch=X.shape[0], device=X.device,
                                generator=generator)
-    return deform_grid_batch(X, disp, axis=axis, **kwargs)
+    import importlib
+    _dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    pts = points if isinstance(points, (list, tuple)) else [points] * len(deform_shape)
+    with _dgm._random_grid_hint(sigma, pts, deform_shape):
+        return deform_grid_batch(X, disp, axis=axis, **kwargs)

@@ -123,3 +123,48 @@ def test_routes_agree_to_float_rounding():
     np.testing.assert_allclose(s.cpu().numpy(), orc.deform_grid(X, disp, **kw), **TOL)
     with pytest.raises(ValueError):
         ed.set_field_strength("mild")
+
+
+def test_deform_random_grid_hints_by_its_own_arguments():
+    """deform_random_grid knows sigma and the control-point spacing: a field that is strong by construction takes the
+    z-walk route without the caller's setting (here: 'auto'), a mild one the default routing -- same values as the
+    oracle on the grid NumPy's global RNG draws, as in the reference (deform_grid.py:42-48)."""
+    import importlib
+    dgm = importlib.import_module("elasticdeform_amd.deform_grid")
+    ed.set_field_strength("auto")
+    assert dgm._random_grid_hint(25, [3, 3], (200, 300)).strong             # the README example
+    assert dgm._random_grid_hint(15, [5, 5, 5], (256, 256, 256)).strong
+    assert not dgm._random_grid_hint(5, [5, 5, 5], (256, 256, 256)).strong  # the benchmark's field
+    assert not dgm._random_grid_hint(25, [3, 1, 3], (1, 1, 1)).strong
+    seen = []
+    orig = dgm._route_flags
+
+    def spy():
+        f = orig()
+        seen.append(f)
+        return f
+    dgm._route_flags = spy
+    try:
+        rng = np.random.default_rng(3)
+        X = rng.random((64, 72, 80)).astype(np.float32)
+        for sigma, strong in ((12.0, True), (1.0, False)):
+            del seen[:]
+            np.random.seed(1234)
+            got = ed.deform_random_grid(X, sigma=sigma, points=4, order=3, mode="mirror")
+            assert seen and all(bool(f) == strong for f in seen), (sigma, seen)
+            np.random.seed(1234)
+            disp = np.random.randn(3, 4, 4, 4) * sigma
+            np.testing.assert_allclose(got, orc.deform_grid(X, disp, order=3, mode="mirror"), **TOL)
+        # on the device (torch wrapper): the hint is set for the forward call, the values are those of the drawn grid
+        import elasticdeform_amd.torch as etorch
+        del seen[:]
+        g = torch.Generator(device="cuda")
+        g.manual_seed(7)
+        Xd = torch.from_numpy(X).cuda()
+        y = etorch.deform_random_grid(Xd, sigma=12.0, points=4, order=3, mode="mirror", generator=g)
+        assert seen and all(seen)
+        g.manual_seed(7)
+        disp = etorch.random_displacement(3, 4, 12.0, device=Xd.device, generator=g).cpu().numpy()
+        np.testing.assert_allclose(y.cpu().numpy(), orc.deform_grid(X, disp, order=3, mode="mirror"), **TOL)
+    finally:
+        dgm._route_flags = orig
