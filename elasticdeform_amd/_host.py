@@ -186,6 +186,39 @@ def compose_rotation_zoom(rotate, zoom, inverse_affine, out_deform_shape):
     return numpy.dot(m, base)[:2, :]
 
 
+_INT_LIMITS = {'uint8': (0.0, 255.0), 'uint16': (0.0, 65535.0), 'uint32': (0.0, 4294967295.0),
+               'uint64': (0.0, 18446744073709551615.0), 'int8': (-128.0, 127.0), 'int16': (-32768.0, 32767.0),
+               'int32': (-2147483648.0, 2147483647.0), 'int64': (-9223372036854775808.0, 9223372036854775807.0)}
+
+
+def stored_constant(cval, dtype_name):
+    """The value the reference stores for a voxel that maps to the constant (deform.c:287-306,906-919): float types take
+    the C cast of ``cval``; signed integers round half away from zero and clamp; unsigned ones add 0.5 to positives,
+    send everything else to 0, clamp; bool takes the C cast to unsigned char.  Returns a Python scalar for numpy.full /
+    torch.full of that dtype."""
+    t = float(cval)
+    if dtype_name == 'bool':
+        return bool(int(t) & 0xFF) if t == t and abs(t) < 2.0 ** 31 else False
+    if dtype_name in _INT_LIMITS:
+        lo, hi = _INT_LIMITS[dtype_name]
+        if not t == t:
+            return 0
+        if lo < 0:
+            t = t + 0.5 if t > 0 else t - 0.5
+        else:
+            t = t + 0.5 if t > 0 else 0.0
+        t = min(max(t, lo), hi)
+        return max(int(lo), min(int(t), int(hi) if hi < 9e18 else (2 ** 64 - 1 if lo == 0 else 2 ** 63 - 1)))
+    return t
+
+
+def degenerate_axis(shapes, axes):
+    """True when a deformed axis of an input has length 1: the reference divides by (I - 1) = 0 there (deform.c:643),
+    every control coordinate is inf or NaN, every voxel maps to the constant in every mode -- the result is ``cval``
+    everywhere and the gradient is zero (checked against the real reference: tests/test_oracle.py)."""
+    return any(int(sh[a]) == 1 for sh, ax in zip(shapes, axes) for a in ax)
+
+
 class ShapeOnly(object):
     """Stand-in for an array of which only the shape is known (the dX of a gradient call before it
     is allocated): Plan inspects ``.shape`` / ``.ndim`` only."""

@@ -13,8 +13,9 @@ stream that needs more scratch than that stream's cached workspace holds waits f
 
 Limits that differ from the reference (status EDHIP_ERR_UNSUPPORTED / EDHIP_ERR_INVALID ->
 RuntimeError): at most 8 array dimensions, hence at most 7 deformed axes (the control grid has one
-dimension more; the reference takes whatever NumPy does, _deform_grid.c:158-175); a deformed axis of length 1 is refused (the reference divides by I - 1 = 0 there,
-deform.c:643, and yields inf / NaN coordinates that map to cval).
+dimension more; the reference takes whatever NumPy does, _deform_grid.c:158-175).  A deformed axis of length 1 gives what
+the reference gives -- it divides by I - 1 = 0 there (deform.c:643), every coordinate is inf / NaN and maps to cval: the
+output is cval everywhere, the gradient zero -- decided on the host (the C ABI itself refuses such an axis).
 
 * numpy.ndarray in  -> numpy.ndarray out (one H2D and one D2H copy; the drop-in path)
 * torch.Tensor in   -> torch.Tensor out on the same device (CUDA tensors never touch the host)
@@ -233,6 +234,19 @@ def _from_device(t, like):
     if like.device != t.device:
         return t.to(like.device)
     return t
+
+
+def _constant_result(like, shape, cval):
+    """An array of `shape` in the family, dtype and device of `like`, filled with the value the reference stores for
+    a constant voxel (_host.stored_constant)."""
+    shape = tuple(int(v) for v in shape)
+    if isinstance(like, numpy.ndarray):
+        name = like.dtype.name
+        if name not in _lib.DTYPE_CODES or (name in _lib.REDUCED_DTYPES and not _reduced):
+            raise RuntimeError('data type not supported')     # deform.c:744,891
+        return numpy.full(shape, _host.stored_constant(cval, name), dtype=like.dtype)
+    torch = _torch()
+    return torch.full(shape, _host.stored_constant(cval, _dtype_name(like)), dtype=like.dtype, device=like.device)
 
 
 _INT_RANGE = {'uint8': (0.0, 255.0), 'uint16': (0.0, 65535.0), 'uint32': (0.0, 4294967295.0),
@@ -581,6 +595,10 @@ def deform_grid(X, displacement, order=3, mode='constant', cval=0.0, crop=None, 
     plan = _host.cached_plan(Xs, displacement, order, mode, cval, crop, axis, affine, rotate, zoom)
 
     torch = _torch()
+    if _host.degenerate_axis([x.shape for x in Xs], plan.axis):
+        # a deformed axis of length 1: every voxel maps to the constant, as in the reference (_host.degenerate_axis)
+        res = [_constant_result(x, plan.output_shapes[i], plan.cval[i]) for i, x in enumerate(Xs)]
+        return res if isinstance(X, list) else res[0]
     device = _device_for(list(Xs) + [displacement])
     perms = _relayout_perms(plan, Xs)
     if perms is not None:
@@ -695,6 +713,10 @@ def deform_grid_gradient(dY, displacement, order=3, mode='constant', cval=0.0, c
                          % (str(plan.output_shapes), str([tuple(dy.shape) for dy in dYs])))
 
     torch = _torch()
+    if _host.degenerate_axis(X_shape, plan.axis):
+        # (a deformed axis of length 1: no voxel contributes, the gradient is zero -- deform.c:928)
+        res = [_constant_result(dy, tuple(int(v) for v in sh), 0.0) for dy, sh in zip(dYs, X_shape)]
+        return res if isinstance(dY, list) else res[0]
     device = _device_for(list(dYs) + [displacement])
     perms = _relayout_perms(plan, [_host.ShapeOnly(sh) for sh in X_shape])
     if perms is not None:

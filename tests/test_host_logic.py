@@ -271,3 +271,46 @@ def test_sixteen_bit_volumes_stay_in_16_bits_only_where_the_tile_kernels_can_tak
     finally:
         dgm.set_arithmetic("auto")
         dgm.set_reduced_precision(prev)
+
+
+def test_a_deformed_axis_of_length_one_gives_the_reference_result():
+    """The reference divides by (I - 1) = 0 for a deformed axis of length 1 (deform.c:643): every control coordinate is
+    inf / NaN, every voxel maps to the constant in EVERY mode, the output is cval stored with the dtype's own rule
+    (deform.c:287-306) and the gradient is zero.  Decided on the host (no GPU needed); against the oracle and, in the
+    build container, the real reference."""
+    import warnings
+    import elasticdeform_amd as ed
+    ref = ref_loader.load_reference()
+    rng = np.random.default_rng(4)
+    cases = [((1, 20), (3, 3), {}), ((12, 1, 9), (2, 3, 3), {}), ((1,), (3,), {}),
+             ((3, 1, 7, 5), (2, 2, 2), dict(axis=(1, 2, 3))), ((9, 1), (3, 2), dict(crop=(slice(2, 7), slice(0, 1))))]
+    for shape, pts, extra in cases:
+        for dt in (np.float64, np.float32, np.uint8, np.int16, np.int32, np.uint16, bool):
+            X = (rng.random(shape) * 50).astype(dt)
+            disp = rng.standard_normal((len(pts),) + pts)
+            for mode in ("constant", "nearest", "mirror", "reflect", "wrap"):
+                for order, cval in ((0, 0.25), (1, -3.6), (3, 300.5)):
+                    kw = dict(order=order, mode=mode, cval=cval, **extra)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        want = orc.deform_grid(X, disp, **kw)
+                        if ref is not None:
+                            np.testing.assert_array_equal(ref.deform_grid(X, disp, **kw), want)
+                    got = ed.deform_grid(X, disp, **kw)
+                    assert got.dtype == want.dtype and got.shape == want.shape
+                    np.testing.assert_array_equal(got, want)
+        # gradient: zero, in dY's dtype and X's shape; lists in, lists out
+        kw = dict(order=3, mode="mirror", **extra)
+        Xf = rng.random(shape)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = orc.deform_grid(Xf, disp, **kw)
+            gw = orc.deform_grid_gradient(np.ones_like(out), disp, X_shape=shape, **kw)
+        g = ed.deform_grid_gradient(np.ones_like(out), disp, X_shape=shape, **kw)
+        assert g.shape == gw.shape == tuple(shape) and g.dtype == gw.dtype
+        np.testing.assert_array_equal(g, gw)
+        assert not g.any()
+        both = ed.deform_grid([Xf, Xf.astype(np.float32)], disp, **kw)
+        assert isinstance(both, list) and both[1].dtype == np.float32 and not both[0].any()
+    with pytest.raises(RuntimeError):
+        ed.deform_grid(np.zeros((1, 5), dtype=np.complex64), np.zeros((2, 2, 2)))
