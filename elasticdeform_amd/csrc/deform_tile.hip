@@ -1756,10 +1756,15 @@ hipError_t launch_tile(const GridGeom& g, const IOView& v, hipStream_t stream, c
                     zg.disp_bstride = tg.disp_bstride;
                     zg.ncpz = (int)g.ncp[0];
                     zg.order = ORDER;
+                    // strips of 4 tiles where that leaves the chip enough of them (256^3: 8192); strips of 2 below ~4096 (128^3:
+                    // 1024 -> 2048 strips, level-1 launch 45.8 -> 37.0 us; 192^3: 105.8 -> 91.8; at 256^3 strips of 2 cost 6 %);
+                    // single tiles only for volumes that have fewer than 1024 pairs (profiles/r06_k1_route_sweep.txt)
                     zg.strip_tiles = 4;
-                    while (zg.strip_tiles > 1 &&
-                           (int64_t)nb * tg.tiles[1] * tg.tiles[2] * ((tg.tiles[0] + zg.strip_tiles - 1) / zg.strip_tiles) < 1024)
-                        zg.strip_tiles >>= 1;
+                    auto zstrips = [&](int st) { return (int64_t)nb * tg.tiles[1] * tg.tiles[2] * ((tg.tiles[0] + st - 1) / st); };
+                    if (zstrips(4) < 4096)
+                        zg.strip_tiles = 2;
+                    if (zstrips(2) < 1024)
+                        zg.strip_tiles = 1;
 #ifdef EDHIP_EXPERIMENTS
                     if (const char* st = ed_env("EDHIP_ZSTRIP"))
                         zg.strip_tiles = atoi(st) >= 1 ? atoi(st) : zg.strip_tiles;

@@ -120,9 +120,10 @@ def set_field_strength(kind):
 
 _tls = threading.local()
 # deform_random_grid knows what the library cannot see without a host round trip: sigma and the control-point spacing.
-# sigma * (points - 1) / (extent - 1) is the displacement gradient's scale; the z-walk kernels win from ~0.18
-# (256^3, 5 points: sigma 10 = 0.157 is a draw, sigma 12.5 = 0.196 and beyond they win -- profiles/r06_k1_route_sweep.txt)
-RANDOM_GRID_STRONG_FROM = 0.18
+# sigma * (points - 1) / (extent - 1) is the displacement gradient's scale; the z-walk kernels win from ~0.15
+# (5 points: sigma 10 at 256^3 = 0.157: 128^3 +23 %, 192^3 +5 %, 256^3 +19 %, batches even; sigma 15: +20 ... +27 %; sigma 5:
+# -7 ... -23 % -- profiles/r06_k1_route_sweep.txt, last table)
+RANDOM_GRID_STRONG_FROM = 0.15
 
 
 class _random_grid_hint(object):
